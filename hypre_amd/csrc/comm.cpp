@@ -1,0 +1,248 @@
+// hypre_amd — communicator table and the RCCL provider.
+//
+// Reference counterpart: utilities/mpistubs.[ch] (the hypre_MPI_* shim) and the
+// MPI calls of parcsr_mv/par_csr_communication.c:483-526.  Here the neighbour
+// exchange of a halo update is one ncclGroupStart/ncclSend.../ncclRecv.../
+// ncclGroupEnd batch on the communication stream: every neighbour pair is a
+// direct xGMI link on an MI355X node, so the batch is link-parallel.
+#include "internal.hpp"
+#include "hypre_amd_comm.h"
+#include <rccl/rccl.h>
+#include <vector>
+#include <mutex>
+
+namespace {
+
+struct CommObj
+{
+   bool              live = false;
+   hypre_amd_CommOps ops{};
+};
+
+std::vector<CommObj> &table()
+{
+   static std::vector<CommObj> t(1);   // slot 0 = single-rank world
+   if (!t[0].live) { t[0].live = true; t[0].ops.rank = 0; t[0].ops.size = 1; }
+   return t;
+}
+
+#define NCCL_CHECK(call)                                                            \
+   do {                                                                             \
+      ncclResult_t r_ = (call);                                                     \
+      if (r_ != ncclSuccess) {                                                      \
+         char msg_[512];                                                            \
+         snprintf(msg_, sizeof(msg_), "RCCL error %d (%s) in %s", (int) r_,         \
+                  ncclGetErrorString(r_), #call);                                   \
+         hypre_error_handler(__FILE__, __LINE__, HYPRE_ERROR_GENERIC, msg_);        \
+         return 1;                                                                  \
+      }                                                                             \
+   } while (0)
+
+struct RcclCtx
+{
+   ncclComm_t comm = nullptr;
+   int rank = 0, size = 1;
+   // device staging for host-buffer traffic (setup-time metadata, tiny vectors)
+   char  *d_stage = nullptr;
+   size_t d_stage_len = 0;
+   char *stage(size_t n)
+   {
+      if (d_stage_len < n)
+      {
+         if (d_stage) { (void) hipFree(d_stage); }
+         size_t len = n < (1u << 20) ? (1u << 20) : n;
+         if (hipMalloc((void **) &d_stage, len) != hipSuccess) { return nullptr; }
+         d_stage_len = len;
+      }
+      return d_stage;
+   }
+};
+
+int rccl_exchange(void *vctx, int ns, const int *dest, void *const *sbuf, const size_t *sbytes,
+                  int nr, const int *src, void *const *rbuf, const size_t *rbytes, int on_device, void *vstream)
+{
+   RcclCtx *c = (RcclCtx *) vctx;
+   hipStream_t s = (hipStream_t) vstream;
+   if (!s) { s = hamd::handle().comm_stream; }
+   if (on_device)
+   {
+      NCCL_CHECK(ncclGroupStart());
+      for (int i = 0; i < nr; i++) { if (rbytes[i]) NCCL_CHECK(ncclRecv(rbuf[i], rbytes[i], ncclChar, src[i], c->comm, s)); }
+      for (int i = 0; i < ns; i++) { if (sbytes[i]) NCCL_CHECK(ncclSend(sbuf[i], sbytes[i], ncclChar, dest[i], c->comm, s)); }
+      NCCL_CHECK(ncclGroupEnd());
+      return 0;
+   }
+   // host buffers: stage through device memory
+   size_t tot_s = 0, tot_r = 0;
+   for (int i = 0; i < ns; i++) { tot_s += (sbytes[i] + 15) & ~(size_t) 15; }
+   for (int i = 0; i < nr; i++) { tot_r += (rbytes[i] + 15) & ~(size_t) 15; }
+   char *st = c->stage(tot_s + tot_r + 16);
+   if (!st) { hypre_error_w_msg(HYPRE_ERROR_MEMORY, "RCCL staging allocation failed"); return 1; }
+   size_t off = 0;
+   std::vector<char *> ds((size_t) ns), dr((size_t) nr);
+   for (int i = 0; i < ns; i++)
+   {
+      ds[(size_t) i] = st + off;
+      if (sbytes[i]) { HIP_CHECK(hipMemcpyAsync(st + off, sbuf[i], sbytes[i], hipMemcpyHostToDevice, s)); }
+      off += (sbytes[i] + 15) & ~(size_t) 15;
+   }
+   for (int i = 0; i < nr; i++) { dr[(size_t) i] = st + off; off += (rbytes[i] + 15) & ~(size_t) 15; }
+   NCCL_CHECK(ncclGroupStart());
+   for (int i = 0; i < nr; i++) { if (rbytes[i]) NCCL_CHECK(ncclRecv(dr[(size_t) i], rbytes[i], ncclChar, src[i], c->comm, s)); }
+   for (int i = 0; i < ns; i++) { if (sbytes[i]) NCCL_CHECK(ncclSend(ds[(size_t) i], sbytes[i], ncclChar, dest[i], c->comm, s)); }
+   NCCL_CHECK(ncclGroupEnd());
+   for (int i = 0; i < nr; i++)
+   {
+      if (rbytes[i]) { HIP_CHECK(hipMemcpyAsync(rbuf[i], dr[(size_t) i], rbytes[i], hipMemcpyDeviceToHost, s)); }
+   }
+   HIP_CHECK(hipStreamSynchronize(s));
+   return 0;
+}
+
+int rccl_allreduce(void *vctx, double *buf, int count, int on_device, void *vstream)
+{
+   RcclCtx *c = (RcclCtx *) vctx;
+   hipStream_t s = (hipStream_t) vstream;
+   if (!s) { s = hamd::handle().comm_stream; }
+   if (on_device)
+   {
+      NCCL_CHECK(ncclAllReduce(buf, buf, (size_t) count, ncclDouble, ncclSum, c->comm, s));
+      return 0;
+   }
+   char *st = c->stage(sizeof(double) * (size_t) count);
+   if (!st) { return 1; }
+   HIP_CHECK(hipMemcpyAsync(st, buf, sizeof(double) * (size_t) count, hipMemcpyHostToDevice, s));
+   NCCL_CHECK(ncclAllReduce(st, st, (size_t) count, ncclDouble, ncclSum, c->comm, s));
+   HIP_CHECK(hipMemcpyAsync(buf, st, sizeof(double) * (size_t) count, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   return 0;
+}
+
+int rccl_allgather(void *vctx, const void *sbuf, void *rbuf, size_t bytes)
+{
+   RcclCtx *c = (RcclCtx *) vctx;
+   hipStream_t s = hamd::handle().comm_stream;
+   const size_t pad = (bytes + 15) & ~(size_t) 15;
+   char *st = c->stage(pad * (size_t) (c->size + 1));
+   if (!st) { return 1; }
+   char *d_send = st, *d_recv = st + pad;
+   HIP_CHECK(hipMemcpyAsync(d_send, sbuf, bytes, hipMemcpyHostToDevice, s));
+   NCCL_CHECK(ncclAllGather(d_send, d_recv, pad, ncclChar, c->comm, s));
+   std::vector<char> tmp(pad * (size_t) c->size);
+   HIP_CHECK(hipMemcpyAsync(tmp.data(), d_recv, pad * (size_t) c->size, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   for (int r = 0; r < c->size; r++) { memcpy((char *) rbuf + bytes * (size_t) r, tmp.data() + pad * (size_t) r, bytes); }
+   return 0;
+}
+
+int rccl_barrier(void *vctx)
+{
+   double one = 1.0;
+   return rccl_allreduce(vctx, &one, 1, 0, nullptr);
+}
+
+void rccl_destroy(void *vctx)
+{
+   RcclCtx *c = (RcclCtx *) vctx;
+   if (c->comm) { ncclCommDestroy(c->comm); }
+   if (c->d_stage) { (void) hipFree(c->d_stage); }
+   delete c;
+}
+
+}  // namespace
+
+namespace hamd {
+const hypre_amd_CommOps *comm_ops(MPI_Comm comm)
+{
+   auto &t = table();
+   if (comm < 0 || (size_t) comm >= t.size() || !t[(size_t) comm].live) { return nullptr; }
+   return &t[(size_t) comm].ops;
+}
+}  // namespace hamd
+
+extern "C" {
+
+MPI_Comm hypre_amd_CommCreate(const hypre_amd_CommOps *ops)
+{
+   auto &t = table();
+   CommObj o;
+   o.live = true;
+   o.ops = *ops;
+   for (size_t k = 1; k < t.size(); k++)
+   {
+      if (!t[k].live) { t[k] = o; return (MPI_Comm) k; }
+   }
+   t.push_back(o);
+   return (MPI_Comm) (t.size() - 1);
+}
+
+HYPRE_Int hypre_amd_CommDestroy(MPI_Comm comm)
+{
+   auto &t = table();
+   if (comm <= 0 || (size_t) comm >= t.size() || !t[(size_t) comm].live) { return hypre_error_flag; }
+   if (t[(size_t) comm].ops.destroy) { t[(size_t) comm].ops.destroy(t[(size_t) comm].ops.ctx); }
+   t[(size_t) comm] = CommObj();
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_amd_RCCLGetUniqueId(void *id_out)
+{
+   static_assert(sizeof(ncclUniqueId) == HYPRE_AMD_RCCL_ID_BYTES, "RCCL id size");
+   ncclUniqueId id;
+   if (ncclGetUniqueId(&id) != ncclSuccess)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "ncclGetUniqueId failed");
+      return hypre_error_flag;
+   }
+   memcpy(id_out, &id, sizeof(id));
+   return hypre_error_flag;
+}
+
+MPI_Comm hypre_amd_CommCreateRCCL(const void *id_bytes, int rank, int size)
+{
+   if (!hamd::ensure_device())
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_amd_CommCreateRCCL: no HIP device");
+      return hypre_MPI_COMM_NULL;
+   }
+   ncclUniqueId id;
+   memcpy(&id, id_bytes, sizeof(id));
+   RcclCtx *c = new RcclCtx();
+   c->rank = rank; c->size = size;
+   if (ncclCommInitRank(&c->comm, size, id, rank) != ncclSuccess)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "ncclCommInitRank failed");
+      delete c;
+      return hypre_MPI_COMM_NULL;
+   }
+   hypre_amd_CommOps ops{};
+   ops.ctx = c; ops.rank = rank; ops.size = size;
+   ops.exchange = rccl_exchange;
+   ops.allreduce_sum = rccl_allreduce;
+   ops.allgather = rccl_allgather;
+   ops.barrier = rccl_barrier;
+   ops.destroy = rccl_destroy;
+   ops.device_buffers = 1;
+   return hypre_amd_CommCreate(&ops);
+}
+
+HYPRE_Int hypre_MPI_Comm_rank(MPI_Comm comm, HYPRE_Int *rank)
+{
+   const hypre_amd_CommOps *o = hamd::comm_ops(comm);
+   *rank = o ? o->rank : 0;
+   return 0;
+}
+HYPRE_Int hypre_MPI_Comm_size(MPI_Comm comm, HYPRE_Int *size)
+{
+   const hypre_amd_CommOps *o = hamd::comm_ops(comm);
+   *size = o ? o->size : 1;
+   return 0;
+}
+HYPRE_Int hypre_MPI_Barrier(MPI_Comm comm)
+{
+   const hypre_amd_CommOps *o = hamd::comm_ops(comm);
+   if (o && o->size > 1 && o->barrier) { return o->barrier(o->ctx); }
+   return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// hypre_amd — synthetic problem generators: the inputs of the benchmark
+// configurations.  Each rank (p,q,r) of a P x Q x R box
+// decomposition assembles its own block in host memory; rows are numbered
+// lexicographically inside the rank's box (x fastest) and boxes are
+// concatenated in rank order, exactly as the reference driver does so that
+// matrices, partitions and hence AMG hierarchies are comparable.
+//
+// Reference: parcsr_ls/par_laplace.c:15-375 (7-point), par_laplace_27pt.c,
+// par_difconv.c; seq_mv/genpart.c:18-40 (partitioning).
+#include "internal.hpp"
+#include <algorithm>
+
+namespace {
+
+std::vector<HYPRE_BigInt> gen_part(HYPRE_BigInt length, HYPRE_Int nprocs)
+{
+   std::vector<HYPRE_BigInt> part((size_t) nprocs + 1, 0);
+   const HYPRE_BigInt size = length / nprocs;
+   const HYPRE_BigInt rest = length - size * nprocs;
+   for (HYPRE_Int i = 0; i < nprocs; i++) { part[(size_t) i + 1] = part[(size_t) i] + size + (i < rest ? 1 : 0); }
+   return part;
+}
+
+struct Box
+{
+   HYPRE_BigInt nx, ny, nz;
+   std::vector<HYPRE_BigInt> xp, yp, zp;
+   // global index of grid point (ix,iy,iz) that lives in the box of rank (p,q,r)
+   HYPRE_BigInt map(HYPRE_BigInt ix, HYPRE_BigInt iy, HYPRE_BigInt iz, HYPRE_Int p, HYPRE_Int q, HYPRE_Int r) const
+   {
+      const HYPRE_BigInt nxl = xp[(size_t) p + 1] - xp[(size_t) p];
+      const HYPRE_BigInt nyl = yp[(size_t) q + 1] - yp[(size_t) q];
+      const HYPRE_BigInt nzl = zp[(size_t) r + 1] - zp[(size_t) r];
+      HYPRE_BigInt g = zp[(size_t) r] * nx * ny + yp[(size_t) q] * nx * nzl + xp[(size_t) p] * (nyl * nzl);
+      g += ((iz - zp[(size_t) r]) * nyl + (iy - yp[(size_t) q])) * nxl + (ix - xp[(size_t) p]);
+      return g;
+   }
+};
+
+// Generic stencil assembler.  `stencil` lists (dx,dy,dz,value-index) in the
+// order entries are stored in each row; entry 0 must be the centre.
+struct StencilPt { int dx, dy, dz, vi; };
+
+HYPRE_ParCSRMatrix assemble(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
+                            HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int ip, HYPRE_Int iq, HYPRE_Int ir,
+                            const std::vector<StencilPt> &stencil, const HYPRE_Real *value)
+{
+   Box bx;
+   bx.nx = nx; bx.ny = ny; bx.nz = nz;
+   bx.xp = gen_part(nx, P); bx.yp = gen_part(ny, Q); bx.zp = gen_part(nz, R);
+   const HYPRE_BigInt x0 = bx.xp[(size_t) ip], x1 = bx.xp[(size_t) ip + 1];
+   const HYPRE_BigInt y0 = bx.yp[(size_t) iq], y1 = bx.yp[(size_t) iq + 1];
+   const HYPRE_BigInt z0 = bx.zp[(size_t) ir], z1 = bx.zp[(size_t) ir + 1];
+   const HYPRE_Int nxl = (HYPRE_Int) (x1 - x0), nyl = (HYPRE_Int) (y1 - y0), nzl = (HYPRE_Int) (z1 - z0);
+   const HYPRE_Int nloc = nxl * nyl * nzl;
+   HYPRE_BigInt part[2];
+   part[0] = z0 * nx * ny + (y0 * nx + x0 * nyl) * nzl;
+   part[1] = part[0] + nloc;
+
+   std::vector<HYPRE_Int> di((size_t) nloc + 1, 0), oi((size_t) nloc + 1, 0);
+   std::vector<HYPRE_Int> dj;
+   std::vector<HYPRE_Real> da, oa;
+   std::vector<HYPRE_BigInt> obig;
+   dj.reserve((size_t) nloc * stencil.size());
+   da.reserve((size_t) nloc * stencil.size());
+
+   HYPRE_Int row = 0;
+   for (HYPRE_BigInt iz = z0; iz < z1; iz++)
+      for (HYPRE_BigInt iy = y0; iy < y1; iy++)
+         for (HYPRE_BigInt ix = x0; ix < x1; ix++)
+         {
+            for (const StencilPt &s : stencil)
+            {
+               const HYPRE_BigInt jx = ix + s.dx, jy = iy + s.dy, jz = iz + s.dz;
+               if (jx < 0 || jx >= nx || jy < 0 || jy >= ny || jz < 0 || jz >= nz) { continue; }
+               const bool in = jx >= x0 && jx < x1 && jy >= y0 && jy < y1 && jz >= z0 && jz < z1;
+               if (in)
+               {
+                  dj.push_back(row + s.dx + nxl * (s.dy + nyl * s.dz));
+                  da.push_back(value[s.vi]);
+               }
+               else
+               {
+                  const HYPRE_Int jp = ip + (jx < x0 ? -1 : (jx >= x1 ? 1 : 0));
+                  const HYPRE_Int jq = iq + (jy < y0 ? -1 : (jy >= y1 ? 1 : 0));
+                  const HYPRE_Int jr = ir + (jz < z0 ? -1 : (jz >= z1 ? 1 : 0));
+                  obig.push_back(bx.map(jx, jy, jz, jp, jq, jr));
+                  oa.push_back(value[s.vi]);
+               }
+            }
+            row++;
+            di[(size_t) row] = (HYPRE_Int) dj.size();
+            oi[(size_t) row] = (HYPRE_Int) obig.size();
+         }
+
+   // ghost columns: ascending global ids, compressed
+   std::vector<HYPRE_BigInt> cmap(obig);
+   std::sort(cmap.begin(), cmap.end());
+   cmap.erase(std::unique(cmap.begin(), cmap.end()), cmap.end());
+   std::vector<HYPRE_Int> oj(obig.size());
+   for (size_t k = 0; k < obig.size(); k++)
+   {
+      oj[k] = (HYPRE_Int) (std::lower_bound(cmap.begin(), cmap.end(), obig[k]) - cmap.begin());
+   }
+   const HYPRE_BigInt gsize = nx * ny * nz;
+   return hypre_amd_ParCSRMatrixFromArrays(comm, gsize, gsize, part, part, (HYPRE_Int) cmap.size(), cmap.data(),
+                                           di.data(), dj.data(), da.data(), oi.data(), oj.data(), oa.data(),
+                                           HYPRE_MEMORY_HOST);
+}
+
+}  // namespace
+
+extern "C" {
+
+// 7-point stencil; stored order per row = [centre, -z, -y, -x, +x, +y, +z]
+// (par_laplace.c:199-300); value = {centre, x-coupling, y-coupling, z-coupling}
+HYPRE_ParCSRMatrix GenerateLaplacian(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
+                                     HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
+                                     HYPRE_Int r, HYPRE_Real *value)
+{
+   static const std::vector<StencilPt> st = {
+      {0, 0, 0, 0}, {0, 0, -1, 3}, {0, -1, 0, 2}, {-1, 0, 0, 1}, {1, 0, 0, 1}, {0, 1, 0, 2}, {0, 0, 1, 3}};
+   return assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value);
+}
+
+// 27-point stencil; stored order = centre first, then the remaining 26 points
+// in lexicographic (z, y, x) order (par_laplace_27pt.c); value = {centre, off}
+HYPRE_ParCSRMatrix GenerateLaplacian27pt(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
+                                         HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
+                                         HYPRE_Int r, HYPRE_Real *value)
+{
+   std::vector<StencilPt> st;
+   st.push_back({0, 0, 0, 0});
+   for (int dz = -1; dz <= 1; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+         for (int dx = -1; dx <= 1; dx++)
+         {
+            if (dx || dy || dz) { st.push_back({dx, dy, dz, 1}); }
+         }
+   return assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value);
+}
+
+// convection-diffusion 7-point operator; value = {centre, -x, -y, -z, +x, +y, +z}
+// (par_difconv.c:203-285; values prepared by the driver as in test/ij.c:10184-10215)
+HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
+                                   HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
+                                   HYPRE_Int r, HYPRE_Real *value)
+{
+   static const std::vector<StencilPt> st = {
+      {0, 0, 0, 0}, {0, 0, -1, 3}, {0, -1, 0, 2}, {-1, 0, 0, 1}, {1, 0, 0, 4}, {0, 1, 0, 5}, {0, 0, 1, 6}};
+   return assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value);
+}
+
+}  // extern "C"

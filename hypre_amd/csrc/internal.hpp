@@ -1,0 +1,145 @@
+// hypre_amd internal declarations shared by the host-side translation units
+// and the HIP kernel file.  Nothing here is part of the C ABI (see include/).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <vector>
+
+#include "HYPRE_amd_utilities.h"
+#include "hypre_amd_seq_mv.h"
+#include "hypre_amd_comm.h"
+#include "hypre_amd_parcsr_mv.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+#define HIP_CHECK(call)                                                          \
+   do {                                                                          \
+      hipError_t e_ = (call);                                                    \
+      if (e_ != hipSuccess) {                                                    \
+         char msg_[512];                                                         \
+         snprintf(msg_, sizeof(msg_), "HIP error %d (%s) in %s", (int) e_,       \
+                  hipGetErrorString(e_), #call);                                 \
+         hypre_error_handler(__FILE__, __LINE__, HYPRE_ERROR_GENERIC, msg_);     \
+      }                                                                          \
+   } while (0)
+
+// The compute entry points exist only for device-resident operands.
+#define HYPRE_AMD_REQUIRE_DEVICE(loc, what)                                      \
+   do {                                                                          \
+      if ((loc) != HYPRE_MEMORY_DEVICE) {                                        \
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC,                                  \
+                           what ": operand is not in device memory; host "       \
+                           "execution is not part of this library");             \
+         return hypre_error_flag;                                                \
+      }                                                                          \
+   } while (0)
+
+namespace hamd {
+
+// ---------------------------------------------------------------------------
+// library handle (utilities/handle.h:34-81 in the reference)
+// ---------------------------------------------------------------------------
+struct Handle
+{
+   bool                  device_ok      = false;
+   bool                  device_probed  = false;
+   hipStream_t           compute_stream = nullptr;
+   hipStream_t           comm_stream    = nullptr;
+   int                   sync_compute   = 1;       // sync at the end of public ops
+   HYPRE_MemoryLocation  memory_location = HYPRE_MEMORY_DEVICE;
+   HYPRE_ExecutionPolicy exec_policy     = HYPRE_EXEC_DEVICE;
+   // scratch for reductions: device partials + pinned host landing zone
+   double               *d_reduce      = nullptr;
+   size_t                d_reduce_len  = 0;
+   double               *h_reduce      = nullptr;  // pinned, 16 doubles
+   int                   num_cus       = 256;
+};
+Handle &handle();
+const hypre_amd_CommOps *comm_ops(MPI_Comm comm);   // nullptr for an invalid handle
+bool    ensure_device();                 // lazily creates streams; false if no GPU
+hipStream_t stream();                    // compute stream
+void    maybe_sync();                    // honours hypre_SetSyncCudaCompute
+double *reduce_scratch(size_t n);        // >= n doubles of device scratch
+
+// ---------------------------------------------------------------------------
+// SpMV plan: rows are binned into fixed-nnz tiles ("row blocks").  Tile b owns
+// the rows whose first stored entry lies in [b*TILE, (b+1)*TILE).
+// ---------------------------------------------------------------------------
+constexpr int SPMV_TILE    = 2048;   // nnz per tile
+constexpr int SPMV_MAXROW  = 1024;   // longest row the tiled path accepts
+constexpr int SPMV_THREADS = 256;
+
+struct SpmvPlan
+{
+   // identity of the matrix arrays the plan was built for
+   const HYPRE_Int     *i = nullptr;
+   const HYPRE_Int     *j = nullptr;
+   const HYPRE_Complex *a = nullptr;
+   int   num_rows = 0, num_cols = 0, nnz = 0;
+   int   max_row_nnz = 0;
+   int   num_tiles = 0;
+   int  *d_tile_row = nullptr;       // [num_tiles+1] first row of every tile
+   bool  tiled = false;              // false -> wave-per-row kernel (long rows)
+   // cached explicit transpose (built on first MatvecT)
+   hypre_CSRMatrix *AT = nullptr;
+   // fp32 copy of the values for the mixed-precision path (lazily built)
+   float *a32 = nullptr;
+};
+SpmvPlan *get_plan(hypre_CSRMatrix *A);
+void      drop_plan(hypre_CSRMatrix *A);
+
+// epilogue selector of the tiled SpMV family
+enum SpmvOp
+{
+   OP_AXPBY   = 0,  // y = alpha*(A x) + beta*b
+   OP_JACOBI  = 1,  // y = x + w*(b - A x)./d          (b=f, d=l1 or diag vector)
+   OP_JACOBI_CF = 2 // same, rows with marker!=pts copy x
+};
+
+struct SpmvArgs
+{
+   const HYPRE_Int     *Ai;
+   const HYPRE_Int     *Aj;
+   const HYPRE_Complex *Aa;
+   const float         *Aa32;     // non-null selects fp32 matrix values
+   const HYPRE_Complex *x;
+   const HYPRE_Complex *b;        // may be null when beta == 0
+   HYPRE_Complex       *y;
+   const HYPRE_Complex *d;        // diagonal / l1 norms for the relax epilogues
+   const HYPRE_Int     *marker;   // CF marker or null
+   int                  marker_val;
+   HYPRE_Complex        alpha, beta;
+   int                  fill;     // HYPRE_SPMV_FILL_*
+   int                  row_offset;
+};
+
+void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
+void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);
+void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
+                        hipStream_t s);
+int  device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s);
+
+// BLAS-1 kernels
+void launch_set(double *y, double v, size_t n, hipStream_t s);
+void launch_copy(double *y, const double *x, size_t n, hipStream_t s);
+void launch_scale(double *y, double a, size_t n, hipStream_t s);
+void launch_axpy(double a, const double *x, double *y, size_t n, hipStream_t s);
+void launch_axpyz(double a, const double *x, double b, const double *y, double *z, size_t n, hipStream_t s);
+void launch_elmdivpy(const double *x, const double *d, double *y, const int *marker, int mval,
+                     size_t n, hipStream_t s);
+void launch_scaled_div(double w, const double *f, const double *d, double *u, const int *marker,
+                       int mval, size_t n, hipStream_t s);   // u = w*f./d (zero-guess Jacobi)
+void launch_diagscale2(const double *diag, const double *x, double beta, double *y, double *z,
+                       int computeY, size_t n, hipStream_t s);
+void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipStream_t s);
+void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s);
+void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s);
+void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
+void launch_scale_copy(double b, const double *x, double *y, size_t n, hipStream_t s);   // y = b*x
+
+}  // namespace hamd

@@ -1,0 +1,790 @@
+// hypre_amd — distributed CSR matrix / vector objects, the halo-exchange
+// package, and the ParCSR matrix-vector products (one rank per GPU).
+//
+// Reference counterparts:
+//   parcsr_mv/par_csr_matrix.c:37-330          object life cycle, migrate
+//   parcsr_mv/par_vector.c:28-575              ParVector + BLAS-1 wrappers
+//   parcsr_mv/par_csr_communication.c:358-699  CommHandleCreate_v2 / Destroy
+//   parcsr_mv/par_csr_communication.c:713-943  CommPkgCreate_core
+//   parcsr_mv/par_csr_matvec.c:21-546          Matvec / MatvecT (host flow)
+//   parcsr_mv/par_csr_matvec_device.c:25-591   Matvec / MatvecT (device flow)
+//
+// Device flow of y = alpha*A*x + beta*b (halo overlapped with the interior
+// product; no host synchronisation inside):
+//   compute stream : pack x[send_map] -> buf            ; record ev_pack
+//   comm stream    : wait ev_pack ; grouped send/recv   ; record ev_halo
+//   compute stream : y = alpha*diag*x + beta*b          (interior, overlaps)
+//   compute stream : wait ev_halo ; y += alpha*offd*x_ghost
+#include "internal.hpp"
+#include <algorithm>
+
+using namespace hamd;
+
+namespace {
+
+// events used to order the two streams; created once
+struct HaloEvents
+{
+   hipEvent_t pack = nullptr, halo = nullptr;
+   bool ok = false;
+};
+HaloEvents &halo_events()
+{
+   static HaloEvents e;
+   if (!e.ok && ensure_device())
+   {
+      HIP_CHECK(hipEventCreateWithFlags(&e.pack, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&e.halo, hipEventDisableTiming));
+      e.ok = true;
+   }
+   return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ===========================================================================
+// ParCSR matrix object
+// ===========================================================================
+static void local_partition(HYPRE_BigInt length, HYPRE_Int num_procs, HYPRE_Int myid, HYPRE_BigInt *part)
+{
+   // seq_mv/genpart.c:50-75: even split, the first `rest` ranks get one extra
+   const HYPRE_BigInt size = length / num_procs;
+   const HYPRE_BigInt rest = length - size * num_procs;
+   part[0] = size * myid + std::min<HYPRE_BigInt>(myid, rest);
+   part[1] = size * (myid + 1) + std::min<HYPRE_BigInt>(myid + 1, rest);
+}
+
+hypre_ParCSRMatrix *hypre_ParCSRMatrixCreate(MPI_Comm comm, HYPRE_BigInt global_num_rows,
+                                             HYPRE_BigInt global_num_cols, HYPRE_BigInt *row_starts_in,
+                                             HYPRE_BigInt *col_starts_in, HYPRE_Int num_cols_offd,
+                                             HYPRE_Int num_nonzeros_diag, HYPRE_Int num_nonzeros_offd)
+{
+   hypre_ParCSRMatrix *m = (hypre_ParCSRMatrix *) calloc(1, sizeof(hypre_ParCSRMatrix));
+   HYPRE_Int num_procs, my_id;
+   hypre_MPI_Comm_rank(comm, &my_id);
+   hypre_MPI_Comm_size(comm, &num_procs);
+   HYPRE_BigInt rs[2], cs[2];
+   if (row_starts_in) { rs[0] = row_starts_in[0]; rs[1] = row_starts_in[1]; }
+   else { local_partition(global_num_rows, num_procs, my_id, rs); }
+   if (col_starts_in) { cs[0] = col_starts_in[0]; cs[1] = col_starts_in[1]; }
+   else { local_partition(global_num_cols, num_procs, my_id, cs); }
+   const HYPRE_Int nr = (HYPRE_Int) (rs[1] - rs[0]);
+   const HYPRE_Int nc = (HYPRE_Int) (cs[1] - cs[0]);
+   m->comm = comm;
+   m->diag = hypre_CSRMatrixCreate(nr, nc, num_nonzeros_diag);
+   m->offd = hypre_CSRMatrixCreate(nr, num_cols_offd, num_nonzeros_offd);
+   m->global_num_rows = global_num_rows;
+   m->global_num_cols = global_num_cols;
+   m->global_num_rownnz = global_num_rows;
+   m->num_nonzeros = -1;
+   m->d_num_nonzeros = -1.0;
+   m->first_row_index = rs[0];
+   m->first_col_diag = cs[0];
+   m->last_row_index = rs[0] + nr - 1;
+   m->last_col_diag = cs[0] + nc - 1;
+   m->row_starts[0] = rs[0]; m->row_starts[1] = rs[1];
+   m->col_starts[0] = cs[0]; m->col_starts[1] = cs[1];
+   m->owns_data = 1;
+   m->owns_assumed_partition = 1;
+   m->bdiag_size = -1;
+   return m;
+}
+
+HYPRE_Int hypre_ParCSRMatrixInitialize_v2(hypre_ParCSRMatrix *m, HYPRE_MemoryLocation loc)
+{
+   hypre_CSRMatrixInitialize_v2(m->diag, 0, loc);
+   hypre_CSRMatrixInitialize_v2(m->offd, 0, loc);
+   if (!m->col_map_offd && m->offd->num_cols)
+   {
+      m->col_map_offd = hypre_CTAlloc(HYPRE_BigInt, m->offd->num_cols, HYPRE_MEMORY_HOST);
+   }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_ParCSRMatrixDestroy(hypre_ParCSRMatrix *m)
+{
+   if (!m) { return hypre_error_flag; }
+   if (m->owns_data)
+   {
+      hypre_CSRMatrixDestroy(m->diag);
+      hypre_CSRMatrixDestroy(m->offd);
+      hypre_Free(m->col_map_offd, HYPRE_MEMORY_HOST);
+      hypre_Free(m->device_col_map_offd, HYPRE_MEMORY_DEVICE);
+      if (m->comm_pkg) { hypre_MatvecCommPkgDestroy(m->comm_pkg); }
+      if (m->comm_pkgT) { hypre_MatvecCommPkgDestroy(m->comm_pkgT); }
+   }
+   if (m->diagT) { hypre_CSRMatrixDestroy(m->diagT); }
+   if (m->offdT) { hypre_CSRMatrixDestroy(m->offdT); }
+   free(m);
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_ParCSRMatrixMigrate(hypre_ParCSRMatrix *A, HYPRE_MemoryLocation loc)
+{
+   if (!A) { return hypre_error_flag; }
+   hypre_CSRMatrixMigrate(A->diag, loc);
+   hypre_CSRMatrixMigrate(A->offd, loc);
+   if (A->diagT) { hypre_CSRMatrixMigrate(A->diagT, loc); }
+   if (A->offdT) { hypre_CSRMatrixMigrate(A->offdT, loc); }
+   return hypre_error_flag;
+}
+
+hypre_ParCSRMatrix *hypre_ParCSRMatrixClone_v2(hypre_ParCSRMatrix *A, HYPRE_Int copy_data,
+                                               HYPRE_MemoryLocation loc)
+{
+   hypre_ParCSRMatrix *B = hypre_ParCSRMatrixCreate(A->comm, A->global_num_rows, A->global_num_cols,
+                                                    A->row_starts, A->col_starts, A->offd->num_cols,
+                                                    A->diag->num_nonzeros, A->offd->num_nonzeros);
+   hypre_CSRMatrixDestroy(B->diag);
+   hypre_CSRMatrixDestroy(B->offd);
+   B->diag = hypre_CSRMatrixClone_v2(A->diag, copy_data, loc);
+   B->offd = hypre_CSRMatrixClone_v2(A->offd, copy_data, loc);
+   B->num_nonzeros = A->num_nonzeros;
+   B->d_num_nonzeros = A->d_num_nonzeros;
+   if (A->offd->num_cols)
+   {
+      B->col_map_offd = hypre_TAlloc(HYPRE_BigInt, A->offd->num_cols, HYPRE_MEMORY_HOST);
+      memcpy(B->col_map_offd, A->col_map_offd, sizeof(HYPRE_BigInt) * (size_t) A->offd->num_cols);
+   }
+   return B;
+}
+
+static double global_sum(MPI_Comm comm, double v)
+{
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   if (o && o->size > 1 && o->allreduce_sum) { o->allreduce_sum(o->ctx, &v, 1, 0, nullptr); }
+   return v;
+}
+
+HYPRE_Int hypre_ParCSRMatrixSetDNumNonzeros(hypre_ParCSRMatrix *m)
+{
+   const double local = (double) m->diag->num_nonzeros + (double) m->offd->num_nonzeros;
+   m->d_num_nonzeros = global_sum(m->comm, local);
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_ParCSRMatrixSetNumNonzeros(hypre_ParCSRMatrix *m)
+{
+   const double local = (double) m->diag->num_nonzeros + (double) m->offd->num_nonzeros;
+   m->num_nonzeros = (HYPRE_BigInt) global_sum(m->comm, local);
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_amd_ParCSRMatrixKeepTranspose(hypre_ParCSRMatrix *A)
+{
+   if (!A->diagT) { hypre_CSRMatrixTranspose(A->diag, &A->diagT, 1); }
+   if (!A->offdT && A->offd->num_cols) { hypre_CSRMatrixTranspose(A->offd, &A->offdT, 1); }
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// ParVector object
+// ===========================================================================
+hypre_ParVector *hypre_ParVectorCreate(MPI_Comm comm, HYPRE_BigInt global_size, HYPRE_BigInt *partitioning_in)
+{
+   hypre_ParVector *v = (hypre_ParVector *) calloc(1, sizeof(hypre_ParVector));
+   HYPRE_Int num_procs, my_id;
+   hypre_MPI_Comm_rank(comm, &my_id);
+   hypre_MPI_Comm_size(comm, &num_procs);
+   HYPRE_BigInt part[2];
+   if (partitioning_in) { part[0] = partitioning_in[0]; part[1] = partitioning_in[1]; }
+   else { local_partition(global_size, num_procs, my_id, part); }
+   const HYPRE_Int local_size = (HYPRE_Int) (part[1] - part[0]);
+   v->comm = comm;
+   v->global_size = global_size;
+   v->partitioning[0] = part[0];
+   v->partitioning[1] = part[1];
+   v->first_index = part[0];
+   v->last_index = part[1] - 1;
+   v->local_vector = hypre_SeqVectorCreate(local_size);
+   v->actual_local_size = 0;
+   v->owns_data = 1;
+   v->all_zeros = 0;
+   return v;
+}
+
+HYPRE_Int hypre_ParVectorInitialize_v2(hypre_ParVector *v, HYPRE_MemoryLocation loc)
+{
+   hypre_SeqVectorInitialize_v2(v->local_vector, loc);
+   v->actual_local_size = v->local_vector->size;
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_ParVectorInitialize(hypre_ParVector *v)
+{
+   return hypre_ParVectorInitialize_v2(v, v->local_vector->memory_location);
+}
+
+HYPRE_Int hypre_ParVectorDestroy(hypre_ParVector *v)
+{
+   if (!v) { return hypre_error_flag; }
+   if (v->owns_data) { hypre_SeqVectorDestroy(v->local_vector); }
+   free(v);
+   return hypre_error_flag;
+}
+
+// Work vectors are allocated at fine-grid size and re-sized in place per level
+// (parcsr_ls/par_cycle.c:290-291); only the logical size changes.
+HYPRE_Int hypre_ParVectorSetLocalSize(hypre_ParVector *v, HYPRE_Int local_size)
+{
+   hypre_Vector *l = v->local_vector;
+   l->size = local_size;
+   if (l->multivec_storage_method == 0) { l->vecstride = local_size; }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_ParVectorMigrate(hypre_ParVector *x, HYPRE_MemoryLocation loc)
+{
+   if (!x) { return hypre_error_flag; }
+   // migrate the whole allocation, not just the logical size
+   hypre_Vector *l = x->local_vector;
+   const HYPRE_Int logical = l->size;
+   if (x->actual_local_size > logical) { l->size = x->actual_local_size; }
+   hypre_SeqVectorMigrate(l, loc);
+   l->size = logical;
+   return hypre_error_flag;
+}
+
+// ---- BLAS-1 wrappers (par_vector.c:322-575) ----
+HYPRE_Int hypre_ParVectorSetConstantValues(hypre_ParVector *v, HYPRE_Complex value)
+{
+   return hypre_SeqVectorSetConstantValues(v->local_vector, value);
+}
+HYPRE_Int hypre_ParVectorSetZeros(hypre_ParVector *v)
+{
+   v->all_zeros = 1;
+   return hypre_SeqVectorSetConstantValues(v->local_vector, 0.0);
+}
+HYPRE_Int hypre_ParVectorCopy(hypre_ParVector *x, hypre_ParVector *y)
+{
+   return hypre_SeqVectorCopy(x->local_vector, y->local_vector);
+}
+HYPRE_Int hypre_ParVectorScale(HYPRE_Complex alpha, hypre_ParVector *y)
+{
+   return hypre_SeqVectorScale(alpha, y->local_vector);
+}
+HYPRE_Int hypre_ParVectorAxpy(HYPRE_Complex alpha, hypre_ParVector *x, hypre_ParVector *y)
+{
+   return hypre_SeqVectorAxpy(alpha, x->local_vector, y->local_vector);
+}
+HYPRE_Int hypre_ParVectorAxpyz(HYPRE_Complex alpha, hypre_ParVector *x, HYPRE_Complex beta,
+                               hypre_ParVector *y, hypre_ParVector *z)
+{
+   return hypre_SeqVectorAxpyz(alpha, x->local_vector, beta, y->local_vector, z->local_vector);
+}
+HYPRE_Real hypre_ParVectorInnerProd(hypre_ParVector *x, hypre_ParVector *y)
+{
+   // local dot + one scalar all-reduce (par_vector.c:513-533)
+   double local = hypre_SeqVectorInnerProd(x->local_vector, y->local_vector);
+   return global_sum(x->comm, local);
+}
+HYPRE_Int hypre_ParVectorElmdivpy(hypre_ParVector *x, hypre_ParVector *b, hypre_ParVector *y)
+{
+   return hypre_SeqVectorElmdivpy(x->local_vector, b->local_vector, y->local_vector);
+}
+HYPRE_Int hypre_ParVectorElmdivpyMarked(hypre_ParVector *x, hypre_ParVector *b, hypre_ParVector *y,
+                                        HYPRE_Int *marker, HYPRE_Int marker_val)
+{
+   return hypre_SeqVectorElmdivpyMarked(x->local_vector, b->local_vector, y->local_vector, marker, marker_val);
+}
+
+// ===========================================================================
+// halo-exchange package
+// ===========================================================================
+// Build the neighbour lists from the (ascending) ghost-column map.  Because
+// col_map_offd is sorted and ownership ranges are contiguous, the ghosts owned
+// by one neighbour form one contiguous run (par_csr_communication.c:765-801).
+HYPRE_Int hypre_ParCSRCommPkgCreate_core(MPI_Comm comm, HYPRE_BigInt *col_map_offd,
+                                         HYPRE_BigInt first_col_diag, HYPRE_BigInt *col_starts,
+                                         HYPRE_Int num_cols_diag, HYPRE_Int num_cols_offd,
+                                         HYPRE_Int *p_num_recvs, HYPRE_Int **p_recv_procs,
+                                         HYPRE_Int **p_recv_vec_starts, HYPRE_Int *p_num_sends,
+                                         HYPRE_Int **p_send_procs, HYPRE_Int **p_send_map_starts,
+                                         HYPRE_Int **p_send_map_elmts)
+{
+   (void) num_cols_diag;
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   const int size = o ? o->size : 1;
+   const int rank = o ? o->rank : 0;
+
+   // every rank's first owned column (+ global end)
+   std::vector<HYPRE_BigInt> starts((size_t) size + 1, 0);
+   if (size > 1)
+   {
+      HYPRE_BigInt mine[2] = {col_starts[0], col_starts[1]};
+      std::vector<HYPRE_BigInt> all((size_t) 2 * size);
+      o->allgather(o->ctx, mine, all.data(), sizeof(mine));
+      for (int r = 0; r < size; r++) { starts[(size_t) r] = all[(size_t) 2 * r]; }
+      starts[(size_t) size] = all[(size_t) 2 * size - 1];
+   }
+   else
+   {
+      starts[0] = col_starts[0]; starts[1] = col_starts[1];
+   }
+   (void) first_col_diag;
+
+   // receive side: runs of ghosts per owner
+   std::vector<HYPRE_Int> recv_procs, recv_vec_starts;
+   {
+      HYPRE_Int k = 0;
+      while (k < num_cols_offd)
+      {
+         const HYPRE_BigInt g = col_map_offd[k];
+         const int owner = (int) (std::upper_bound(starts.begin(), starts.end(), g) - starts.begin()) - 1;
+         recv_procs.push_back(owner);
+         recv_vec_starts.push_back(k);
+         const HYPRE_BigInt end = starts[(size_t) owner + 1];
+         while (k < num_cols_offd && col_map_offd[k] < end) { k++; }
+      }
+      recv_vec_starts.push_back(num_cols_offd);
+   }
+   const HYPRE_Int num_recvs = (HYPRE_Int) recv_procs.size();
+
+   // tell every owner how many of its entries we need: one row of a size x size table
+   std::vector<HYPRE_Int> want((size_t) size, 0), table((size_t) size * size, 0);
+   for (HYPRE_Int i = 0; i < num_recvs; i++)
+   {
+      want[(size_t) recv_procs[(size_t) i]] = recv_vec_starts[(size_t) i + 1] - recv_vec_starts[(size_t) i];
+   }
+   if (size > 1) { o->allgather(o->ctx, want.data(), table.data(), sizeof(HYPRE_Int) * (size_t) size); }
+
+   std::vector<HYPRE_Int> send_procs, send_map_starts(1, 0);
+   for (int r = 0; r < size; r++)
+   {
+      const HYPRE_Int cnt = (size > 1) ? table[(size_t) r * size + rank] : 0;
+      if (cnt > 0)
+      {
+         send_procs.push_back(r);
+         send_map_starts.push_back(send_map_starts.back() + cnt);
+      }
+   }
+   const HYPRE_Int num_sends = (HYPRE_Int) send_procs.size();
+   const HYPRE_Int tot_send = send_map_starts.back();
+
+   // ship the wanted global ids to their owners; they become local gather ids
+   std::vector<HYPRE_BigInt> req((size_t) std::max(tot_send, 1));
+   if (size > 1 && (num_sends || num_recvs))
+   {
+      std::vector<void *> sb((size_t) num_recvs), rb((size_t) num_sends);
+      std::vector<size_t> sbytes((size_t) num_recvs), rbytes((size_t) num_sends);
+      for (HYPRE_Int i = 0; i < num_recvs; i++)
+      {
+         sb[(size_t) i] = (void *) (col_map_offd + recv_vec_starts[(size_t) i]);
+         sbytes[(size_t) i] = sizeof(HYPRE_BigInt) * (size_t) (recv_vec_starts[(size_t) i + 1] - recv_vec_starts[(size_t) i]);
+      }
+      for (HYPRE_Int i = 0; i < num_sends; i++)
+      {
+         rb[(size_t) i] = (void *) (req.data() + send_map_starts[(size_t) i]);
+         rbytes[(size_t) i] = sizeof(HYPRE_BigInt) * (size_t) (send_map_starts[(size_t) i + 1] - send_map_starts[(size_t) i]);
+      }
+      o->exchange(o->ctx, num_recvs, recv_procs.data(), sb.data(), sbytes.data(),
+                  num_sends, send_procs.data(), rb.data(), rbytes.data(), 0, nullptr);
+   }
+
+   *p_num_recvs = num_recvs;
+   *p_recv_procs = hypre_CTAlloc(HYPRE_Int, std::max(num_recvs, 1), HYPRE_MEMORY_HOST);
+   *p_recv_vec_starts = hypre_CTAlloc(HYPRE_Int, num_recvs + 1, HYPRE_MEMORY_HOST);
+   for (HYPRE_Int i = 0; i < num_recvs; i++) { (*p_recv_procs)[i] = recv_procs[(size_t) i]; }
+   for (HYPRE_Int i = 0; i <= num_recvs; i++) { (*p_recv_vec_starts)[i] = recv_vec_starts[(size_t) i]; }
+   *p_num_sends = num_sends;
+   *p_send_procs = hypre_CTAlloc(HYPRE_Int, std::max(num_sends, 1), HYPRE_MEMORY_HOST);
+   *p_send_map_starts = hypre_CTAlloc(HYPRE_Int, num_sends + 1, HYPRE_MEMORY_HOST);
+   *p_send_map_elmts = hypre_CTAlloc(HYPRE_Int, std::max(tot_send, 1), HYPRE_MEMORY_HOST);
+   for (HYPRE_Int i = 0; i < num_sends; i++) { (*p_send_procs)[i] = send_procs[(size_t) i]; }
+   for (HYPRE_Int i = 0; i <= num_sends; i++) { (*p_send_map_starts)[i] = send_map_starts[(size_t) i]; }
+   for (HYPRE_Int i = 0; i < tot_send; i++) { (*p_send_map_elmts)[i] = (HYPRE_Int) (req[(size_t) i] - col_starts[0]); }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_MatvecCommPkgCreate(hypre_ParCSRMatrix *A)
+{
+   if (A->comm_pkg) { return hypre_error_flag; }
+   hypre_ParCSRCommPkg *pkg = (hypre_ParCSRCommPkg *) calloc(1, sizeof(hypre_ParCSRCommPkg));
+   pkg->comm = A->comm;
+   pkg->num_components = 1;
+   hypre_ParCSRCommPkgCreate_core(A->comm, A->col_map_offd, A->first_col_diag, A->col_starts,
+                                  A->diag->num_cols, A->offd->num_cols,
+                                  &pkg->num_recvs, &pkg->recv_procs, &pkg->recv_vec_starts,
+                                  &pkg->num_sends, &pkg->send_procs, &pkg->send_map_starts,
+                                  &pkg->send_map_elmts);
+   A->comm_pkg = pkg;
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_MatvecCommPkgDestroy(hypre_ParCSRCommPkg *pkg)
+{
+   if (!pkg) { return hypre_error_flag; }
+   hypre_Free(pkg->send_procs, HYPRE_MEMORY_HOST);
+   hypre_Free(pkg->send_map_starts, HYPRE_MEMORY_HOST);
+   hypre_Free(pkg->send_map_elmts, HYPRE_MEMORY_HOST);
+   hypre_Free(pkg->recv_procs, HYPRE_MEMORY_HOST);
+   hypre_Free(pkg->recv_vec_starts, HYPRE_MEMORY_HOST);
+   hypre_Free(pkg->device_send_map_elmts, HYPRE_MEMORY_DEVICE);
+   hypre_Free(pkg->tmp_data, HYPRE_MEMORY_DEVICE);
+   hypre_Free(pkg->buf_data, HYPRE_MEMORY_DEVICE);
+   free(pkg);
+   return hypre_error_flag;
+}
+
+// Start a neighbour exchange.  job 1/11: owner -> ghost; job 2/12: ghost -> owner.
+// Device buffers: the transfers are enqueued on the communication stream behind
+// everything already queued on the compute stream; Destroy makes the compute
+// stream wait for them (no host synchronisation).  Host buffers: blocking.
+hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate_v2(HYPRE_Int job, hypre_ParCSRCommPkg *pkg,
+                                                        HYPRE_MemoryLocation send_loc, void *send_data,
+                                                        HYPRE_MemoryLocation recv_loc, void *recv_data)
+{
+   hypre_ParCSRCommHandle *h = (hypre_ParCSRCommHandle *) calloc(1, sizeof(hypre_ParCSRCommHandle));
+   h->comm_pkg = pkg;
+   h->send_memory_location = send_loc;
+   h->recv_memory_location = recv_loc;
+   h->send_data = send_data;
+   h->recv_data = recv_data;
+   const hypre_amd_CommOps *o = comm_ops(pkg->comm);
+   if (!o || o->size <= 1) { return h; }
+
+   const size_t esz = (job == 11 || job == 12) ? sizeof(HYPRE_Int) : sizeof(HYPRE_Complex);
+   const bool forward = (job == 1 || job == 11);
+   const HYPRE_Int ns = forward ? pkg->num_sends : pkg->num_recvs;
+   const HYPRE_Int nr = forward ? pkg->num_recvs : pkg->num_sends;
+   const HYPRE_Int *sprocs  = forward ? pkg->send_procs : pkg->recv_procs;
+   const HYPRE_Int *rprocs  = forward ? pkg->recv_procs : pkg->send_procs;
+   const HYPRE_Int *sstarts = forward ? pkg->send_map_starts : pkg->recv_vec_starts;
+   const HYPRE_Int *rstarts = forward ? pkg->recv_vec_starts : pkg->send_map_starts;
+
+   const bool dev = (send_loc == HYPRE_MEMORY_DEVICE) || (recv_loc == HYPRE_MEMORY_DEVICE);
+   char *sbase = (char *) send_data, *rbase = (char *) recv_data;
+   std::vector<char> hs, hr;
+   const size_t stot = esz * (size_t) sstarts[ns], rtot = esz * (size_t) rstarts[nr];
+   const bool stage = dev && !o->device_buffers;
+   if (stage)
+   {
+      // provider cannot take device pointers: bounce through host memory
+      hs.resize(stot ? stot : 1); hr.resize(rtot ? rtot : 1);
+      if (send_loc == HYPRE_MEMORY_DEVICE) { hypre_Memcpy(hs.data(), send_data, stot, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE); sbase = hs.data(); }
+      if (recv_loc == HYPRE_MEMORY_DEVICE) { rbase = hr.data(); }
+   }
+   std::vector<void *> sb((size_t) ns), rb((size_t) nr);
+   std::vector<size_t> sbytes((size_t) ns), rbytes((size_t) nr);
+   for (HYPRE_Int i = 0; i < ns; i++)
+   {
+      sb[(size_t) i] = sbase + esz * (size_t) sstarts[i];
+      sbytes[(size_t) i] = esz * (size_t) (sstarts[i + 1] - sstarts[i]);
+   }
+   for (HYPRE_Int i = 0; i < nr; i++)
+   {
+      rb[(size_t) i] = rbase + esz * (size_t) rstarts[i];
+      rbytes[(size_t) i] = esz * (size_t) (rstarts[i + 1] - rstarts[i]);
+   }
+   if (dev && !stage)
+   {
+      HaloEvents &ev = halo_events();
+      Handle &hd = handle();
+      HIP_CHECK(hipEventRecord(ev.pack, hd.compute_stream));
+      HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, ev.pack, 0));
+      o->exchange(o->ctx, ns, sprocs, sb.data(), sbytes.data(), nr, rprocs, rb.data(), rbytes.data(), 1,
+                  (void *) hd.comm_stream);
+      HIP_CHECK(hipEventRecord(ev.halo, hd.comm_stream));
+      h->num_requests = 1;   // marks "device exchange in flight"
+   }
+   else
+   {
+      o->exchange(o->ctx, ns, sprocs, sb.data(), sbytes.data(), nr, rprocs, rb.data(), rbytes.data(), 0, nullptr);
+      if (stage && recv_loc == HYPRE_MEMORY_DEVICE)
+      {
+         hypre_Memcpy(recv_data, hr.data(), rtot, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      }
+   }
+   return h;
+}
+
+hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate(HYPRE_Int job, hypre_ParCSRCommPkg *pkg,
+                                                     void *send_data, void *recv_data)
+{
+   return hypre_ParCSRCommHandleCreate_v2(job, pkg, HYPRE_MEMORY_HOST, send_data, HYPRE_MEMORY_HOST, recv_data);
+}
+
+HYPRE_Int hypre_ParCSRCommHandleDestroy(hypre_ParCSRCommHandle *h)
+{
+   if (!h) { return hypre_error_flag; }
+   if (h->num_requests)
+   {
+      HaloEvents &ev = halo_events();
+      HIP_CHECK(hipStreamWaitEvent(handle().compute_stream, ev.halo, 0));
+   }
+   free(h);
+   return hypre_error_flag;
+}
+
+// device work space of a package (allocated on first use, never in the hot loop)
+static void ensure_pkg_device(hypre_ParCSRCommPkg *pkg, HYPRE_Int num_cols_offd)
+{
+   const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
+   if (!pkg->device_send_map_elmts && tot_send)
+   {
+      pkg->device_send_map_elmts = hypre_TAlloc(HYPRE_Int, tot_send, HYPRE_MEMORY_DEVICE);
+      hypre_TMemcpy(pkg->device_send_map_elmts, pkg->send_map_elmts, HYPRE_Int, tot_send,
+                    HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   }
+   if (!pkg->buf_data && tot_send) { pkg->buf_data = hypre_TAlloc(HYPRE_Complex, tot_send, HYPRE_MEMORY_DEVICE); }
+   if (!pkg->tmp_data && num_cols_offd) { pkg->tmp_data = hypre_TAlloc(HYPRE_Complex, num_cols_offd, HYPRE_MEMORY_DEVICE); }
+}
+
+// ===========================================================================
+// ParCSR SpMV
+// ===========================================================================
+HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlaceDevice(HYPRE_Complex alpha, hypre_ParCSRMatrix *A,
+                                                   hypre_ParVector *x, HYPRE_Complex beta,
+                                                   hypre_ParVector *b, hypre_ParVector *y)
+{
+   hypre_CSRMatrix *diag = A->diag, *offd = A->offd;
+   hypre_Vector *xl = x->local_vector, *bl = b->local_vector, *yl = y->local_vector;
+   HYPRE_AMD_REQUIRE_DEVICE(diag->memory_location, "hypre_ParCSRMatrixMatvec(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(xl->memory_location, "hypre_ParCSRMatrixMatvec(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(yl->memory_location, "hypre_ParCSRMatrixMatvec(y)");
+   HYPRE_AMD_REQUIRE_DEVICE(bl->memory_location, "hypre_ParCSRMatrixMatvec(b)");
+   if (xl->num_vectors != 1 || yl->num_vectors != 1)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRMatrixMatvec: multivectors are not supported by the distributed product");
+      return hypre_error_flag;
+   }
+   const HYPRE_Int num_cols_offd = offd->num_cols;
+   HYPRE_Int nprocs;
+   hypre_MPI_Comm_size(A->comm, &nprocs);
+
+   const int saved_sync = handle().sync_compute;
+   handle().sync_compute = 0;
+
+   hypre_ParCSRCommHandle *ch = nullptr;
+   hypre_Vector x_ghost{};
+   if (nprocs > 1 && num_cols_offd > 0)
+   {
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      hypre_ParCSRCommPkg *pkg = A->comm_pkg;
+      ensure_pkg_device(pkg, num_cols_offd);
+      const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
+      launch_gather(xl->data, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
+      ch = hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data,
+                                           HYPRE_MEMORY_DEVICE, pkg->tmp_data);
+      x_ghost.data = pkg->tmp_data;
+      x_ghost.size = num_cols_offd;
+      x_ghost.num_vectors = 1; x_ghost.vecstride = num_cols_offd; x_ghost.idxstride = 1;
+      x_ghost.memory_location = HYPRE_MEMORY_DEVICE;
+   }
+   else if (nprocs > 1)
+   {
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }   // collective: every rank takes part
+      if (A->comm_pkg->num_sends)
+      {
+         hypre_ParCSRCommPkg *pkg = A->comm_pkg;
+         ensure_pkg_device(pkg, 0);
+         const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
+         launch_gather(xl->data, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
+         ch = hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data,
+                                              HYPRE_MEMORY_DEVICE, pkg->tmp_data);
+      }
+   }
+
+   // interior product, overlapped with the exchange
+   hypre_CSRMatrixMatvecDevice(0, alpha, diag, xl, beta, bl, yl, 0);
+
+   if (ch) { hypre_ParCSRCommHandleDestroy(ch); }
+   if (num_cols_offd > 0 && x_ghost.data)
+   {
+      hypre_CSRMatrixMatvecDevice(0, alpha, offd, &x_ghost, 1.0, yl, yl, 0);
+   }
+   handle().sync_compute = saved_sync;
+   maybe_sync();
+   return hypre_error_flag;
+}
+
+static HYPRE_Int par_ierr(HYPRE_BigInt nrows, HYPRE_BigInt ncols, hypre_ParVector *x, hypre_ParVector *b,
+                          hypre_ParVector *y)
+{
+   // par_csr_matvec.c:57-82 — informational only
+   HYPRE_Int ierr = 0;
+   const bool badx = ncols != x->global_size;
+   const bool bady = nrows != y->global_size || nrows != b->global_size;
+   if (badx) { ierr = 11; }
+   if (bady) { ierr = 12; }
+   if (badx && bady) { ierr = 13; }
+   return ierr;
+}
+
+HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlace(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, hypre_ParVector *x,
+                                             HYPRE_Complex beta, hypre_ParVector *b, hypre_ParVector *y)
+{
+   const HYPRE_Int ierr = par_ierr(A->global_num_rows, A->global_num_cols, x, b, y);
+   hypre_ParCSRMatrixMatvecOutOfPlaceDevice(alpha, A, x, beta, b, y);
+   return ierr;
+}
+
+HYPRE_Int hypre_ParCSRMatrixMatvec(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, hypre_ParVector *x,
+                                   HYPRE_Complex beta, hypre_ParVector *y)
+{
+   return hypre_ParCSRMatrixMatvecOutOfPlace(alpha, A, x, beta, y, y);
+}
+
+HYPRE_Int HYPRE_ParCSRMatrixMatvec(HYPRE_Complex alpha, HYPRE_ParCSRMatrix A, HYPRE_ParVector x,
+                                   HYPRE_Complex beta, HYPRE_ParVector y)
+{
+   return hypre_ParCSRMatrixMatvec(alpha, A, x, beta, y);
+}
+
+// y = alpha*A^T*x + beta*y : ghost-row contributions travel back to their owners
+HYPRE_Int hypre_ParCSRMatrixMatvecTDevice(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, hypre_ParVector *x,
+                                          HYPRE_Complex beta, hypre_ParVector *y)
+{
+   hypre_CSRMatrix *diag = A->diag, *offd = A->offd;
+   hypre_Vector *xl = x->local_vector, *yl = y->local_vector;
+   HYPRE_AMD_REQUIRE_DEVICE(diag->memory_location, "hypre_ParCSRMatrixMatvecT(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(xl->memory_location, "hypre_ParCSRMatrixMatvecT(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(yl->memory_location, "hypre_ParCSRMatrixMatvecT(y)");
+   const HYPRE_Int num_cols_offd = offd->num_cols;
+   HYPRE_Int nprocs;
+   hypre_MPI_Comm_size(A->comm, &nprocs);
+
+   const int saved_sync = handle().sync_compute;
+   handle().sync_compute = 0;
+
+   hypre_ParCSRCommHandle *ch = nullptr;
+   hypre_ParCSRCommPkg *pkg = nullptr;
+   if (nprocs > 1)
+   {
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      pkg = A->comm_pkg;
+      ensure_pkg_device(pkg, num_cols_offd);
+      if (num_cols_offd > 0)
+      {
+         hypre_Vector y_ghost{};
+         y_ghost.data = pkg->tmp_data; y_ghost.size = num_cols_offd; y_ghost.num_vectors = 1;
+         y_ghost.vecstride = num_cols_offd; y_ghost.idxstride = 1; y_ghost.memory_location = HYPRE_MEMORY_DEVICE;
+         if (A->offdT) { hypre_CSRMatrixMatvecDevice(0, alpha, A->offdT, xl, 0.0, &y_ghost, &y_ghost, 0); }
+         else          { hypre_CSRMatrixMatvecDevice(1, alpha, offd, xl, 0.0, &y_ghost, &y_ghost, 0); }
+      }
+      if (pkg->num_sends || pkg->num_recvs)
+      {
+         ch = hypre_ParCSRCommHandleCreate_v2(2, pkg, HYPRE_MEMORY_DEVICE, pkg->tmp_data,
+                                              HYPRE_MEMORY_DEVICE, pkg->buf_data);
+      }
+   }
+   if (A->diagT) { hypre_CSRMatrixMatvecDevice(0, alpha, A->diagT, xl, beta, yl, yl, 0); }
+   else          { hypre_CSRMatrixMatvecDevice(1, alpha, diag, xl, beta, yl, yl, 0); }
+   if (ch)
+   {
+      hypre_ParCSRCommHandleDestroy(ch);
+      const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
+      launch_scatter_add(pkg->buf_data, pkg->device_send_map_elmts, yl->data, (size_t) tot_send, stream());
+   }
+   handle().sync_compute = saved_sync;
+   maybe_sync();
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_ParCSRMatrixMatvecT(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, hypre_ParVector *x,
+                                    HYPRE_Complex beta, hypre_ParVector *y)
+{
+   HYPRE_Int ierr = 0;
+   const bool badx = A->global_num_rows != x->global_size;
+   const bool bady = A->global_num_cols != y->global_size;
+   if (badx) { ierr = 1; }
+   if (bady) { ierr = 2; }
+   if (badx && bady) { ierr = 3; }
+   hypre_ParCSRMatrixMatvecTDevice(alpha, A, x, beta, y);
+   return ierr;
+}
+
+// ===========================================================================
+// binding conveniences
+// ===========================================================================
+hypre_CSRMatrix *hypre_amd_CSRMatrixFromArrays(HYPRE_Int num_rows, HYPRE_Int num_cols, HYPRE_Int nnz,
+                                               const HYPRE_Int *i, const HYPRE_Int *j,
+                                               const HYPRE_Complex *data, HYPRE_MemoryLocation loc)
+{
+   hypre_CSRMatrix *m = hypre_CSRMatrixCreate(num_rows, num_cols, nnz);
+   hypre_CSRMatrixInitialize_v2(m, 0, loc);
+   hypre_TMemcpy(m->i, i, HYPRE_Int, num_rows + 1, loc, HYPRE_MEMORY_HOST);
+   if (nnz)
+   {
+      hypre_TMemcpy(m->j, j, HYPRE_Int, nnz, loc, HYPRE_MEMORY_HOST);
+      if (data) { hypre_TMemcpy(m->data, data, HYPRE_Complex, nnz, loc, HYPRE_MEMORY_HOST); }
+   }
+   return m;
+}
+
+hypre_Vector *hypre_amd_SeqVectorFromArray(HYPRE_Int size, const HYPRE_Complex *data, HYPRE_MemoryLocation loc)
+{
+   hypre_Vector *v = hypre_SeqVectorCreate(size);
+   hypre_SeqVectorInitialize_v2(v, loc);
+   if (data && size) { hypre_TMemcpy(v->data, data, HYPRE_Complex, size, loc, HYPRE_MEMORY_HOST); }
+   return v;
+}
+
+HYPRE_Int hypre_amd_SeqVectorToArray(hypre_Vector *v, HYPRE_Complex *out)
+{
+   hypre_TMemcpy(out, v->data, HYPRE_Complex, (size_t) v->size * v->num_vectors, HYPRE_MEMORY_HOST, v->memory_location);
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_amd_CopyToHost(void *dst, const void *src, size_t bytes, HYPRE_MemoryLocation loc)
+{
+   hypre_Memcpy(dst, src, bytes, HYPRE_MEMORY_HOST, loc);
+   return hypre_error_flag;
+}
+
+hypre_ParCSRMatrix *hypre_amd_ParCSRMatrixFromArrays(MPI_Comm comm, HYPRE_BigInt global_num_rows,
+                                                     HYPRE_BigInt global_num_cols,
+                                                     const HYPRE_BigInt *row_starts,
+                                                     const HYPRE_BigInt *col_starts,
+                                                     HYPRE_Int num_cols_offd, const HYPRE_BigInt *col_map_offd,
+                                                     const HYPRE_Int *diag_i, const HYPRE_Int *diag_j,
+                                                     const HYPRE_Complex *diag_data,
+                                                     const HYPRE_Int *offd_i, const HYPRE_Int *offd_j,
+                                                     const HYPRE_Complex *offd_data, HYPRE_MemoryLocation loc)
+{
+   HYPRE_BigInt rs[2] = {row_starts[0], row_starts[1]}, cs[2] = {col_starts[0], col_starts[1]};
+   const HYPRE_Int nr = (HYPRE_Int) (rs[1] - rs[0]);
+   const HYPRE_Int nnz_d = diag_i[nr];
+   const HYPRE_Int nnz_o = offd_i ? offd_i[nr] : 0;
+   hypre_ParCSRMatrix *A = hypre_ParCSRMatrixCreate(comm, global_num_rows, global_num_cols, rs, cs,
+                                                    num_cols_offd, nnz_d, nnz_o);
+   hypre_ParCSRMatrixInitialize_v2(A, loc);
+   hypre_TMemcpy(A->diag->i, diag_i, HYPRE_Int, nr + 1, loc, HYPRE_MEMORY_HOST);
+   if (nnz_d)
+   {
+      hypre_TMemcpy(A->diag->j, diag_j, HYPRE_Int, nnz_d, loc, HYPRE_MEMORY_HOST);
+      hypre_TMemcpy(A->diag->data, diag_data, HYPRE_Complex, nnz_d, loc, HYPRE_MEMORY_HOST);
+   }
+   if (offd_i) { hypre_TMemcpy(A->offd->i, offd_i, HYPRE_Int, nr + 1, loc, HYPRE_MEMORY_HOST); }
+   if (nnz_o)
+   {
+      hypre_TMemcpy(A->offd->j, offd_j, HYPRE_Int, nnz_o, loc, HYPRE_MEMORY_HOST);
+      hypre_TMemcpy(A->offd->data, offd_data, HYPRE_Complex, nnz_o, loc, HYPRE_MEMORY_HOST);
+   }
+   for (HYPRE_Int k = 0; k < num_cols_offd; k++) { A->col_map_offd[k] = col_map_offd[k]; }
+   hypre_CSRMatrixSetRownnz(A->offd);
+   hypre_ParCSRMatrixSetNumNonzeros(A);
+   hypre_ParCSRMatrixSetDNumNonzeros(A);
+   return A;
+}
+
+hypre_ParVector *hypre_amd_ParVectorFromArray(MPI_Comm comm, HYPRE_BigInt global_size,
+                                              const HYPRE_BigInt *partitioning, const HYPRE_Complex *data,
+                                              HYPRE_MemoryLocation loc)
+{
+   HYPRE_BigInt part[2] = {partitioning[0], partitioning[1]};
+   hypre_ParVector *v = hypre_ParVectorCreate(comm, global_size, part);
+   hypre_ParVectorInitialize_v2(v, loc);
+   const HYPRE_Int n = v->local_vector->size;
+   if (data && n) { hypre_TMemcpy(v->local_vector->data, data, HYPRE_Complex, n, loc, HYPRE_MEMORY_HOST); }
+   return v;
+}
+
+HYPRE_Int hypre_amd_ParVectorToArray(hypre_ParVector *v, HYPRE_Complex *out)
+{
+   return hypre_amd_SeqVectorToArray(v->local_vector, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+// hypre_amd runtime: error word, library handle (streams, scratch), memory model.
+// Reference counterparts: utilities/error.c, utilities/handle.h:34-81,
+// utilities/memory.c (hypre_MAlloc/hypre_Free/hypre_Memcpy), utilities/general.c
+// (HYPRE_Initialize, HYPRE_SetMemoryLocation, hypre_SetSyncCudaCompute).
+#include "internal.hpp"
+#include <string>
+
+extern "C" {
+hypre_Error hypre__global_error = {0, 0, 0, 1, nullptr, 0, 0};
+}
+
+static std::string g_last_msg;
+
+extern "C" void hypre_error_handler(const char *filename, HYPRE_Int line, HYPRE_Int ierr, const char *msg)
+{
+   hypre__global_error.error_flag |= ierr;
+   if (msg)
+   {
+      g_last_msg = msg;
+      if (hypre__global_error.verbosity)
+      {
+         fprintf(stderr, "hypre_amd error 0x%x at %s:%d: %s\n", ierr, filename, line, msg);
+      }
+   }
+}
+
+extern "C" const char *hypre_amd_LastErrorMessage(void) { return g_last_msg.c_str(); }
+extern "C" HYPRE_Int HYPRE_GetError(void) { return hypre_error_flag; }
+extern "C" HYPRE_Int HYPRE_ClearAllErrors(void) { hypre_error_flag = 0; g_last_msg.clear(); return 0; }
+extern "C" HYPRE_Int HYPRE_GetErrorArg(void) { return (hypre_error_flag >> 3) & 31; }
+
+namespace hamd {
+
+Handle &handle()
+{
+   static Handle h;
+   return h;
+}
+
+bool ensure_device()
+{
+   Handle &h = handle();
+   if (h.device_probed) { return h.device_ok; }
+   h.device_probed = true;
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+   {
+      (void) hipGetLastError();
+      h.device_ok = false;
+      return false;
+   }
+   // one process per GPU: honour the launcher's LOCAL_RANK unless the caller
+   // already chose a device with hipSetDevice / torch.cuda.set_device
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess) { dev = 0; }
+   hipDeviceProp_t prop;
+   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) { h.num_cus = prop.multiProcessorCount; }
+   if (hipStreamCreateWithFlags(&h.compute_stream, hipStreamNonBlocking) != hipSuccess ||
+       hipStreamCreateWithFlags(&h.comm_stream, hipStreamNonBlocking) != hipSuccess)
+   {
+      h.device_ok = false;
+      return false;
+   }
+   if (hipHostMalloc((void **) &h.h_reduce, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess)
+   {
+      h.device_ok = false;
+      return false;
+   }
+   h.device_ok = true;
+   return true;
+}
+
+hipStream_t stream()
+{
+   ensure_device();
+   return handle().compute_stream;
+}
+
+void maybe_sync()
+{
+   Handle &h = handle();
+   if (h.device_ok && h.sync_compute) { HIP_CHECK(hipStreamSynchronize(h.compute_stream)); }
+}
+
+double *reduce_scratch(size_t n)
+{
+   Handle &h = handle();
+   if (h.d_reduce_len < n)
+   {
+      if (h.d_reduce) { HIP_CHECK(hipFree(h.d_reduce)); }
+      size_t len = n < 4096 ? 4096 : n;
+      HIP_CHECK(hipMalloc((void **) &h.d_reduce, len * sizeof(double)));
+      h.d_reduce_len = len;
+   }
+   return h.d_reduce;
+}
+
+}  // namespace hamd
+
+using namespace hamd;
+
+extern "C" {
+
+HYPRE_Int HYPRE_Initialize(void) { ensure_device(); return hypre_error_flag; }
+HYPRE_Int HYPRE_Finalize(void) { return hypre_error_flag; }
+HYPRE_Int hypre_amd_DeviceAvailable(void) { return ensure_device() ? 1 : 0; }
+
+HYPRE_Int HYPRE_SetMemoryLocation(HYPRE_MemoryLocation loc) { handle().memory_location = loc; return hypre_error_flag; }
+HYPRE_Int HYPRE_GetMemoryLocation(HYPRE_MemoryLocation *loc) { *loc = handle().memory_location; return hypre_error_flag; }
+HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy p) { handle().exec_policy = p; return hypre_error_flag; }
+HYPRE_Int HYPRE_GetExecutionPolicy(HYPRE_ExecutionPolicy *p) { *p = handle().exec_policy; return hypre_error_flag; }
+
+HYPRE_Int hypre_SetSyncCudaCompute(HYPRE_Int action) { handle().sync_compute = action; return hypre_error_flag; }
+HYPRE_Int hypre_GetSyncCudaCompute(HYPRE_Int *p) { *p = handle().sync_compute; return hypre_error_flag; }
+HYPRE_Int hypre_SyncComputeStream(void)
+{
+   Handle &h = handle();
+   if (h.device_ok) { HIP_CHECK(hipStreamSynchronize(h.compute_stream)); }
+   return hypre_error_flag;
+}
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+HYPRE_Int hypre_amd_EventTimerStart(void)
+{
+   if (!ensure_device()) { hypre_error_w_msg(HYPRE_ERROR_GENERIC, "no HIP device"); return hypre_error_flag; }
+   if (!g_ev0) { HIP_CHECK(hipEventCreate(&g_ev0)); HIP_CHECK(hipEventCreate(&g_ev1)); }
+   HIP_CHECK(hipEventRecord(g_ev0, handle().compute_stream));
+   return hypre_error_flag;
+}
+HYPRE_Real hypre_amd_EventTimerStopMs(void)
+{
+   float ms = 0.f;
+   if (!g_ev0) { return 0.0; }
+   HIP_CHECK(hipEventRecord(g_ev1, handle().compute_stream));
+   HIP_CHECK(hipEventSynchronize(g_ev1));
+   HIP_CHECK(hipEventElapsedTime(&ms, g_ev0, g_ev1));
+   return (HYPRE_Real) ms;
+}
+void *hypre_amd_ComputeStream(void) { ensure_device(); return (void *) handle().compute_stream; }
+void *hypre_amd_CommStream(void) { ensure_device(); return (void *) handle().comm_stream; }
+
+HYPRE_ExecutionPolicy hypre_GetExecPolicy1(HYPRE_MemoryLocation location)
+{
+   // utilities/memory.c:1070 — host memory runs on the host, device memory on the device
+   return location == HYPRE_MEMORY_DEVICE ? HYPRE_EXEC_DEVICE : HYPRE_EXEC_HOST;
+}
+HYPRE_ExecutionPolicy hypre_GetExecPolicy2(HYPRE_MemoryLocation l1, HYPRE_MemoryLocation l2)
+{
+   if (l1 == HYPRE_MEMORY_DEVICE && l2 == HYPRE_MEMORY_DEVICE) { return HYPRE_EXEC_DEVICE; }
+   if (l1 == HYPRE_MEMORY_HOST && l2 == HYPRE_MEMORY_HOST) { return HYPRE_EXEC_HOST; }
+   return HYPRE_EXEC_UNDEFINED;
+}
+
+void *hypre_MAlloc(size_t size, HYPRE_MemoryLocation location)
+{
+   if (size == 0) { return nullptr; }
+   void *p = nullptr;
+   if (location == HYPRE_MEMORY_DEVICE)
+   {
+      if (!ensure_device())
+      {
+         hypre_error_w_msg(HYPRE_ERROR_MEMORY, "device allocation requested but no HIP device is available");
+         return nullptr;
+      }
+      if (hipMalloc(&p, size) != hipSuccess)
+      {
+         (void) hipGetLastError();
+         hypre_error_w_msg(HYPRE_ERROR_MEMORY, "hipMalloc failed");
+         return nullptr;
+      }
+   }
+   else
+   {
+      // 64-byte alignment keeps host buffers friendly to pinned/async copies
+      if (posix_memalign(&p, 64, size) != 0) { p = nullptr; }
+      if (!p) { hypre_error_w_msg(HYPRE_ERROR_MEMORY, "host allocation failed"); }
+   }
+   return p;
+}
+
+void *hypre_CAlloc(size_t count, size_t elt_size, HYPRE_MemoryLocation location)
+{
+   const size_t size = count * elt_size;
+   void *p = hypre_MAlloc(size, location);
+   if (p) { hypre_Memset(p, 0, size, location); }
+   return p;
+}
+
+void hypre_Free(void *ptr, HYPRE_MemoryLocation location)
+{
+   if (!ptr) { return; }
+   if (location == HYPRE_MEMORY_DEVICE) { HIP_CHECK(hipFree(ptr)); }
+   else { free(ptr); }
+}
+
+void hypre_Memset(void *ptr, HYPRE_Int value, size_t num, HYPRE_MemoryLocation location)
+{
+   if (!ptr || !num) { return; }
+   if (location == HYPRE_MEMORY_DEVICE)
+   {
+      HIP_CHECK(hipMemsetAsync(ptr, value, num, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+   }
+   else { memset(ptr, value, num); }
+}
+
+void hypre_Memcpy(void *dst, const void *src, size_t size, HYPRE_MemoryLocation loc_dst, HYPRE_MemoryLocation loc_src)
+{
+   if (!size || dst == src) { return; }
+   if (loc_dst == HYPRE_MEMORY_HOST && loc_src == HYPRE_MEMORY_HOST) { memcpy(dst, src, size); return; }
+   hipMemcpyKind kind = hipMemcpyDeviceToDevice;
+   if (loc_dst == HYPRE_MEMORY_HOST) { kind = hipMemcpyDeviceToHost; }
+   else if (loc_src == HYPRE_MEMORY_HOST) { kind = hipMemcpyHostToDevice; }
+   // ordered after everything already queued on the compute stream
+   HIP_CHECK(hipMemcpyAsync(dst, src, size, kind, stream()));
+   HIP_CHECK(hipStreamSynchronize(stream()));
+}
+
+hypre_IntArray *hypre_IntArrayCreate(HYPRE_Int size)
+{
+   hypre_IntArray *a = (hypre_IntArray *) calloc(1, sizeof(hypre_IntArray));
+   a->size = size;
+   a->memory_location = handle().memory_location;
+   return a;
+}
+HYPRE_Int hypre_IntArrayInitialize_v2(hypre_IntArray *a, HYPRE_MemoryLocation loc)
+{
+   a->memory_location = loc;
+   if (!a->data) { a->data = hypre_CTAlloc(HYPRE_Int, a->size, loc); }
+   return hypre_error_flag;
+}
+HYPRE_Int hypre_IntArrayDestroy(hypre_IntArray *a)
+{
+   if (a) { hypre_Free(a->data, a->memory_location); free(a); }
+   return hypre_error_flag;
+}
+
+}  // extern "C"

@@ -1,0 +1,649 @@
+// hypre_amd — local CSR matrix / dense vector objects and the sequential
+// (per-rank) matrix-vector and BLAS-1 entry points.
+//
+// Reference counterparts:
+//   seq_mv/csr_matrix.c:25-160,350-420,917-1040   object life cycle, rownnz, migrate, clone
+//   seq_mv/csr_matop.c:1043-1300,1537-1604        transpose, diagonal-first reorder
+//   seq_mv/csr_matvec.c:860-901,1142-1171         Matvec dispatchers
+//   seq_mv/csr_matvec_device.c:37-172             device wrapper
+//   seq_mv/csr_spmv_device.c:381-557              SpMV with triangular fill modes
+//   seq_mv/vector.c / vector_device.c             BLAS-1
+#include "internal.hpp"
+#include <unordered_map>
+#include <algorithm>
+
+using namespace hamd;
+
+// ===========================================================================
+// plan cache
+// ===========================================================================
+namespace hamd {
+
+static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> &plan_table()
+{
+   static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> t;
+   return t;
+}
+
+static void free_plan(SpmvPlan *p)
+{
+   if (!p) { return; }
+   if (p->d_tile_row) { HIP_CHECK(hipFree(p->d_tile_row)); }
+   if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
+   if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
+   delete p;
+}
+
+void drop_plan(hypre_CSRMatrix *A)
+{
+   auto &t = plan_table();
+   auto it = t.find(A);
+   if (it != t.end())
+   {
+      free_plan(it->second);
+      t.erase(it);
+   }
+}
+
+SpmvPlan *get_plan(hypre_CSRMatrix *A)
+{
+   auto &t = plan_table();
+   auto it = t.find(A);
+   if (it != t.end())
+   {
+      SpmvPlan *p = it->second;
+      if (p->i == A->i && p->j == A->j && p->a == A->data && p->nnz == A->num_nonzeros &&
+          p->num_rows == A->num_rows && p->num_cols == A->num_cols)
+      {
+         return p;
+      }
+      free_plan(p);
+      t.erase(it);
+   }
+   SpmvPlan *p = new SpmvPlan();
+   p->i = A->i; p->j = A->j; p->a = A->data;
+   p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->num_nonzeros;
+   hipStream_t s = stream();
+   if (A->num_rows > 0 && A->num_nonzeros > 0)
+   {
+      p->max_row_nnz = device_max_row_nnz(A->i, A->num_rows, s);
+      const bool aligned = (((uintptr_t) A->j) & 15) == 0 && (((uintptr_t) A->data) & 15) == 0;
+      p->tiled = aligned && p->max_row_nnz <= SPMV_MAXROW;
+      if (p->tiled)
+      {
+         p->num_tiles = (int) (((long long) A->num_nonzeros + SPMV_TILE - 1) / SPMV_TILE);
+         HIP_CHECK(hipMalloc((void **) &p->d_tile_row, sizeof(int) * (size_t) (p->num_tiles + 1)));
+         launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, s);
+      }
+   }
+   t[A] = p;
+   return p;
+}
+
+}  // namespace hamd
+
+extern "C" HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A)
+{
+   drop_plan(A);
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// CSR matrix object
+// ===========================================================================
+extern "C" {
+
+hypre_CSRMatrix *hypre_CSRMatrixCreate(HYPRE_Int num_rows, HYPRE_Int num_cols, HYPRE_Int num_nonzeros)
+{
+   hypre_CSRMatrix *m = (hypre_CSRMatrix *) calloc(1, sizeof(hypre_CSRMatrix));
+   m->num_rows = num_rows;
+   m->num_cols = num_cols;
+   m->num_nonzeros = num_nonzeros;
+   m->num_rownnz = num_rows;
+   m->owns_data = 1;
+   m->memory_location = handle().memory_location;
+   return m;
+}
+
+HYPRE_Int hypre_CSRMatrixInitialize_v2(hypre_CSRMatrix *m, HYPRE_Int bigInit, HYPRE_MemoryLocation loc)
+{
+   m->memory_location = loc;
+   if (!m->data && m->num_nonzeros) { m->data = hypre_CTAlloc(HYPRE_Complex, m->num_nonzeros, loc); }
+   if (!m->i) { m->i = hypre_CTAlloc(HYPRE_Int, m->num_rows + 1, loc); }
+   if (bigInit)
+   {
+      if (!m->big_j && m->num_nonzeros) { m->big_j = hypre_CTAlloc(HYPRE_BigInt, m->num_nonzeros, loc); }
+   }
+   else
+   {
+      if (!m->j && m->num_nonzeros) { m->j = hypre_CTAlloc(HYPRE_Int, m->num_nonzeros, loc); }
+   }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_CSRMatrixInitialize(hypre_CSRMatrix *m)
+{
+   return hypre_CSRMatrixInitialize_v2(m, 0, m->memory_location);
+}
+
+HYPRE_Int hypre_CSRMatrixDestroy(hypre_CSRMatrix *m)
+{
+   if (!m) { return hypre_error_flag; }
+   drop_plan(m);
+   const HYPRE_MemoryLocation loc = m->memory_location;
+   hypre_Free(m->rownnz, loc);
+   if (m->owns_data)
+   {
+      hypre_Free(m->data, loc);
+      hypre_Free(m->i, loc);
+      hypre_Free(m->j, loc);
+      hypre_Free(m->big_j, loc);
+   }
+   free(m);
+   return hypre_error_flag;
+}
+
+// List the rows that hold at least one entry (seq_mv/csr_matrix.c:350-400).
+HYPRE_Int hypre_CSRMatrixSetRownnz(hypre_CSRMatrix *m)
+{
+   const HYPRE_MemoryLocation loc = m->memory_location;
+   const HYPRE_Int n = m->num_rows;
+   std::vector<HYPRE_Int> hi;
+   const HYPRE_Int *Ai = m->i;
+   if (loc == HYPRE_MEMORY_DEVICE)
+   {
+      hi.resize((size_t) n + 1);
+      hypre_TMemcpy(hi.data(), m->i, HYPRE_Int, n + 1, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      Ai = hi.data();
+   }
+   HYPRE_Int cnt = 0;
+   for (HYPRE_Int r = 0; r < n; r++) { if (Ai[r + 1] > Ai[r]) { cnt++; } }
+   hypre_Free(m->rownnz, loc);
+   m->rownnz = nullptr;
+   m->num_rownnz = cnt;
+   if (cnt == 0 || cnt == n) { return hypre_error_flag; }
+   std::vector<HYPRE_Int> list((size_t) cnt);
+   cnt = 0;
+   for (HYPRE_Int r = 0; r < n; r++) { if (Ai[r + 1] > Ai[r]) { list[(size_t) cnt++] = r; } }
+   m->rownnz = hypre_TAlloc(HYPRE_Int, cnt, loc);
+   hypre_TMemcpy(m->rownnz, list.data(), HYPRE_Int, cnt, loc, HYPRE_MEMORY_HOST);
+   return hypre_error_flag;
+}
+
+static void migrate_array(void **p, size_t bytes, HYPRE_MemoryLocation from, HYPRE_MemoryLocation to)
+{
+   if (!*p || !bytes) { return; }
+   void *q = hypre_MAlloc(bytes, to);
+   hypre_Memcpy(q, *p, bytes, to, from);
+   hypre_Free(*p, from);
+   *p = q;
+}
+
+HYPRE_Int hypre_CSRMatrixMigrate(hypre_CSRMatrix *A, HYPRE_MemoryLocation to)
+{
+   const HYPRE_MemoryLocation from = A->memory_location;
+   if (from == to) { return hypre_error_flag; }
+   drop_plan(A);
+   migrate_array((void **) &A->i, sizeof(HYPRE_Int) * (size_t) (A->num_rows + 1), from, to);
+   migrate_array((void **) &A->j, sizeof(HYPRE_Int) * (size_t) A->num_nonzeros, from, to);
+   migrate_array((void **) &A->big_j, sizeof(HYPRE_BigInt) * (size_t) A->num_nonzeros, from, to);
+   migrate_array((void **) &A->data, sizeof(HYPRE_Complex) * (size_t) A->num_nonzeros, from, to);
+   if (A->rownnz) { migrate_array((void **) &A->rownnz, sizeof(HYPRE_Int) * (size_t) A->num_rownnz, from, to); }
+   A->memory_location = to;
+   return hypre_error_flag;
+}
+
+hypre_CSRMatrix *hypre_CSRMatrixClone_v2(hypre_CSRMatrix *A, HYPRE_Int copy_data, HYPRE_MemoryLocation loc)
+{
+   hypre_CSRMatrix *B = hypre_CSRMatrixCreate(A->num_rows, A->num_cols, A->num_nonzeros);
+   hypre_CSRMatrixInitialize_v2(B, A->big_j != nullptr && A->j == nullptr, loc);
+   const HYPRE_MemoryLocation src = A->memory_location;
+   hypre_TMemcpy(B->i, A->i, HYPRE_Int, A->num_rows + 1, loc, src);
+   if (A->j) { hypre_TMemcpy(B->j, A->j, HYPRE_Int, A->num_nonzeros, loc, src); }
+   if (A->big_j && B->big_j) { hypre_TMemcpy(B->big_j, A->big_j, HYPRE_BigInt, A->num_nonzeros, loc, src); }
+   if (copy_data && A->data) { hypre_TMemcpy(B->data, A->data, HYPRE_Complex, A->num_nonzeros, loc, src); }
+   B->num_rownnz = A->num_rownnz;
+   if (A->rownnz)
+   {
+      B->rownnz = hypre_TAlloc(HYPRE_Int, A->num_rownnz, loc);
+      hypre_TMemcpy(B->rownnz, A->rownnz, HYPRE_Int, A->num_rownnz, loc, src);
+   }
+   return B;
+}
+
+// Explicit transpose (setup-time utility; counting sort on the host).
+// Column order inside each row of AT is ascending source row, as produced by
+// the reference's host transpose (seq_mv/csr_matop.c:1043-1270).
+HYPRE_Int hypre_CSRMatrixTranspose(hypre_CSRMatrix *A, hypre_CSRMatrix **AT_ptr, HYPRE_Int data)
+{
+   const HYPRE_MemoryLocation loc = A->memory_location;
+   const HYPRE_Int nr = A->num_rows, nc = A->num_cols, nnz = A->num_nonzeros;
+   std::vector<HYPRE_Int> hi, hj;
+   std::vector<HYPRE_Complex> ha;
+   const HYPRE_Int *Ai = A->i, *Aj = A->j;
+   const HYPRE_Complex *Aa = A->data;
+   if (loc == HYPRE_MEMORY_DEVICE)
+   {
+      hi.resize((size_t) nr + 1); hj.resize((size_t) nnz);
+      hypre_TMemcpy(hi.data(), A->i, HYPRE_Int, nr + 1, HYPRE_MEMORY_HOST, loc);
+      if (nnz) { hypre_TMemcpy(hj.data(), A->j, HYPRE_Int, nnz, HYPRE_MEMORY_HOST, loc); }
+      Ai = hi.data(); Aj = hj.data();
+      if (data && A->data)
+      {
+         ha.resize((size_t) nnz);
+         if (nnz) { hypre_TMemcpy(ha.data(), A->data, HYPRE_Complex, nnz, HYPRE_MEMORY_HOST, loc); }
+         Aa = ha.data();
+      }
+   }
+   const bool with_data = data && A->data;
+   std::vector<HYPRE_Int> ti((size_t) nc + 1, 0), tj((size_t) nnz);
+   std::vector<HYPRE_Complex> ta(with_data ? (size_t) nnz : 0);
+   for (HYPRE_Int k = 0; k < nnz; k++) { ti[(size_t) Aj[k] + 1]++; }
+   for (HYPRE_Int c = 0; c < nc; c++) { ti[(size_t) c + 1] += ti[(size_t) c]; }
+   std::vector<HYPRE_Int> pos(ti.begin(), ti.end() - 1);
+   for (HYPRE_Int r = 0; r < nr; r++)
+   {
+      for (HYPRE_Int k = Ai[r]; k < Ai[r + 1]; k++)
+      {
+         const HYPRE_Int q = pos[(size_t) Aj[k]]++;
+         tj[(size_t) q] = r;
+         if (with_data) { ta[(size_t) q] = Aa[k]; }
+      }
+   }
+   hypre_CSRMatrix *AT = hypre_CSRMatrixCreate(nc, nr, nnz);
+   hypre_CSRMatrixInitialize_v2(AT, 0, loc);
+   hypre_TMemcpy(AT->i, ti.data(), HYPRE_Int, nc + 1, loc, HYPRE_MEMORY_HOST);
+   if (nnz)
+   {
+      hypre_TMemcpy(AT->j, tj.data(), HYPRE_Int, nnz, loc, HYPRE_MEMORY_HOST);
+      if (with_data) { hypre_TMemcpy(AT->data, ta.data(), HYPRE_Complex, nnz, loc, HYPRE_MEMORY_HOST); }
+   }
+   *AT_ptr = AT;
+   return hypre_error_flag;
+}
+
+// Move the diagonal entry of every row of a square host matrix to the front
+// (seq_mv/csr_matop.c:1537-1584); the relaxation kernels rely on it.
+HYPRE_Int hypre_CSRMatrixReorder(hypre_CSRMatrix *A)
+{
+   if (A->num_rows != A->num_cols) { return -1; }
+   if (A->memory_location != HYPRE_MEMORY_HOST)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_CSRMatrixReorder: host matrices only (setup-time utility)");
+      return hypre_error_flag;
+   }
+   for (HYPRE_Int r = 0; r < A->num_rows; r++)
+   {
+      const HYPRE_Int s = A->i[r], e = A->i[r + 1];
+      for (HYPRE_Int k = s; k < e; k++)
+      {
+         if (A->j[k] == r)
+         {
+            if (k != s)
+            {
+               std::swap(A->j[s], A->j[k]);
+               std::swap(A->data[s], A->data[k]);
+            }
+            break;
+         }
+      }
+   }
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// dense vector object
+// ===========================================================================
+hypre_Vector *hypre_SeqMultiVectorCreate(HYPRE_Int size, HYPRE_Int num_vectors)
+{
+   hypre_Vector *v = (hypre_Vector *) calloc(1, sizeof(hypre_Vector));
+   v->size = size;
+   v->num_vectors = num_vectors;
+   v->owns_data = 1;
+   v->multivec_storage_method = 0;
+   v->vecstride = size;
+   v->idxstride = 1;
+   v->memory_location = handle().memory_location;
+   return v;
+}
+
+hypre_Vector *hypre_SeqVectorCreate(HYPRE_Int size) { return hypre_SeqMultiVectorCreate(size, 1); }
+
+HYPRE_Int hypre_SeqVectorInitialize_v2(hypre_Vector *v, HYPRE_MemoryLocation loc)
+{
+   v->memory_location = loc;
+   if (!v->data) { v->data = hypre_CTAlloc(HYPRE_Complex, (size_t) v->size * v->num_vectors, loc); }
+   if (v->multivec_storage_method == 0) { v->vecstride = v->size; v->idxstride = 1; }
+   else { v->vecstride = 1; v->idxstride = v->num_vectors; }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_SeqVectorInitialize(hypre_Vector *v) { return hypre_SeqVectorInitialize_v2(v, v->memory_location); }
+
+HYPRE_Int hypre_SeqVectorDestroy(hypre_Vector *v)
+{
+   if (!v) { return hypre_error_flag; }
+   if (v->owns_data) { hypre_Free(v->data, v->memory_location); }
+   free(v);
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_SeqVectorMigrate(hypre_Vector *x, HYPRE_MemoryLocation to)
+{
+   if (x->memory_location == to) { return hypre_error_flag; }
+   migrate_array((void **) &x->data, sizeof(HYPRE_Complex) * (size_t) x->size * x->num_vectors, x->memory_location, to);
+   x->memory_location = to;
+   return hypre_error_flag;
+}
+
+hypre_Vector *hypre_SeqVectorCloneDeep_v2(hypre_Vector *x, HYPRE_MemoryLocation loc)
+{
+   hypre_Vector *y = hypre_SeqMultiVectorCreate(x->size, x->num_vectors);
+   y->multivec_storage_method = x->multivec_storage_method;
+   hypre_SeqVectorInitialize_v2(y, loc);
+   hypre_TMemcpy(y->data, x->data, HYPRE_Complex, (size_t) x->size * x->num_vectors, loc, x->memory_location);
+   return y;
+}
+
+hypre_Vector *hypre_SeqVectorCloneDeep(hypre_Vector *x) { return hypre_SeqVectorCloneDeep_v2(x, x->memory_location); }
+
+// ===========================================================================
+// SpMV
+// ===========================================================================
+static HYPRE_Int matvec_ierr(HYPRE_Int num_rows, HYPRE_Int num_cols, hypre_Vector *x, hypre_Vector *b,
+                             hypre_Vector *y)
+{
+   // informational only; the product is still formed (seq_mv/csr_matvec.c:57-86)
+   HYPRE_Int ierr = 0;
+   const bool badx = num_cols != x->size;
+   const bool bady = num_rows != y->size || num_rows != b->size;
+   if (badx) { ierr = 1; }
+   if (bady) { ierr = 2; }
+   if (badx && bady) { ierr = 3; }
+   return ierr;
+}
+
+// y(:,v) = alpha * A * x(:,v) + beta * b(:,v) on the compute stream, no sync.
+static void spmv_device_core(HYPRE_Complex alpha, hypre_CSRMatrix *A, const HYPRE_Complex *x,
+                             HYPRE_Complex beta, const HYPRE_Complex *b, HYPRE_Complex *y, HYPRE_Int fill)
+{
+   hipStream_t s = stream();
+   const HYPRE_Int nr = A->num_rows;
+   if (nr <= 0) { return; }
+   if (A->num_nonzeros <= 0 || alpha == 0.0)
+   {
+      // y = beta*b
+      if (beta == 0.0) { launch_set(y, 0.0, (size_t) nr, s); }
+      else if (b == y) { if (beta != 1.0) { launch_scale(y, beta, (size_t) nr, s); } }
+      else { launch_scale_copy(beta, b, y, (size_t) nr, s); }
+      return;
+   }
+   SpmvArgs a{};
+   a.Ai = A->i; a.Aj = A->j; a.Aa = A->data; a.Aa32 = nullptr;
+   a.x = x; a.b = b; a.y = y; a.d = nullptr; a.marker = nullptr; a.marker_val = 0;
+   a.alpha = alpha; a.beta = beta; a.fill = fill; a.row_offset = 0;
+
+   // sparse-row path: only a few rows hold entries (off-diagonal blocks)
+   if (fill == HYPRE_SPMV_FILL_WHOLE && A->rownnz && (double) A->num_rownnz < 0.7 * (double) nr)
+   {
+      if (beta == 0.0) { launch_set(y, 0.0, (size_t) nr, s); }
+      else if (b == y) { if (beta != 1.0) { launch_scale(y, beta, (size_t) nr, s); } }
+      else { launch_scale_copy(beta, b, y, (size_t) nr, s); }
+      launch_spmv_rownnz(A->rownnz, A->num_rownnz, a, s);
+      return;
+   }
+   SpmvPlan *plan = get_plan(A);
+   launch_spmv(plan, a, OP_AXPBY, s);
+}
+
+HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_CSRMatrix *A,
+                                      hypre_Vector *x, HYPRE_Complex beta, hypre_Vector *b,
+                                      hypre_Vector *y, HYPRE_Int offset)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(A->memory_location, "hypre_CSRMatrixMatvecDevice(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_CSRMatrixMatvecDevice(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_CSRMatrixMatvecDevice(y)");
+   HYPRE_AMD_REQUIRE_DEVICE(b->memory_location, "hypre_CSRMatrixMatvecDevice(b)");
+   if (offset != 0)
+   {
+      // the reference's device path asserts offset == 0 (csr_matvec_device.c:121)
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_CSRMatrixMatvecDevice: offset != 0 is not supported on the device");
+      return hypre_error_flag;
+   }
+   if (x->num_vectors != y->num_vectors || x->num_vectors != b->num_vectors)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_CSRMatrixMatvecDevice: num_vectors mismatch");
+      return hypre_error_flag;
+   }
+   hypre_CSRMatrix *M = A;
+   if (trans)
+   {
+      SpmvPlan *plan = get_plan(A);
+      if (!plan->AT) { hypre_CSRMatrixTranspose(A, &plan->AT, 1); }
+      M = plan->AT;
+   }
+   hypre_Vector *x_tmp = nullptr;
+   const HYPRE_Complex *xd = x->data;
+   if (x->data == y->data)
+   {
+      // aliasing: the host reference deep-clones x (csr_matvec.c:109-113)
+      x_tmp = hypre_SeqVectorCloneDeep(x);
+      xd = x_tmp->data;
+   }
+   for (HYPRE_Int v = 0; v < x->num_vectors; v++)
+   {
+      if (x->idxstride != 1 || y->idxstride != 1 || b->idxstride != 1)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_CSRMatrixMatvecDevice: row-wise multivector storage is not supported");
+         break;
+      }
+      spmv_device_core(alpha, M, xd + (size_t) v * x->vecstride, beta, b->data + (size_t) v * b->vecstride,
+                       y->data + (size_t) v * y->vecstride, HYPRE_SPMV_FILL_WHOLE);
+   }
+   if (x_tmp) { HIP_CHECK(hipStreamSynchronize(stream())); hypre_SeqVectorDestroy(x_tmp); }
+   maybe_sync();
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_CSRMatrixMatvecOutOfPlace(HYPRE_Complex alpha, hypre_CSRMatrix *A, hypre_Vector *x,
+                                          HYPRE_Complex beta, hypre_Vector *b, hypre_Vector *y,
+                                          HYPRE_Int offset)
+{
+   const HYPRE_Int ierr = matvec_ierr(A->num_rows - offset, A->num_cols, x, b, y);
+   hypre_CSRMatrixMatvecDevice(0, alpha, A, x, beta, b, y, offset);
+   return ierr;
+}
+
+HYPRE_Int hypre_CSRMatrixMatvec(HYPRE_Complex alpha, hypre_CSRMatrix *A, hypre_Vector *x,
+                                HYPRE_Complex beta, hypre_Vector *y)
+{
+   return hypre_CSRMatrixMatvecOutOfPlace(alpha, A, x, beta, y, y, 0);
+}
+
+HYPRE_Int hypre_CSRMatrixMatvecT(HYPRE_Complex alpha, hypre_CSRMatrix *A, hypre_Vector *x,
+                                 HYPRE_Complex beta, hypre_Vector *y)
+{
+   // ierr as seq_mv/csr_matvec.c:952-966 (roles of rows/cols swapped)
+   HYPRE_Int ierr = 0;
+   const bool badx = A->num_rows != x->size;
+   const bool bady = A->num_cols != y->size;
+   if (badx) { ierr = 1; }
+   if (bady) { ierr = 2; }
+   if (badx && bady) { ierr = 3; }
+   hypre_CSRMatrixMatvecDevice(1, alpha, A, x, beta, y, y, 0);
+   return ierr;
+}
+
+HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_CSRMatrix *B,
+                                    hypre_Vector *x, HYPRE_Complex beta, hypre_Vector *y, HYPRE_Int fill)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(B->memory_location, "hypre_CSRMatrixSpMVDevice(B)");
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_CSRMatrixSpMVDevice(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_CSRMatrixSpMVDevice(y)");
+   if (x->num_vectors != y->num_vectors)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "num_vectors_x != num_vectors_y");
+      return hypre_error_flag;
+   }
+   hypre_CSRMatrix *M = B;
+   if (trans)
+   {
+      SpmvPlan *plan = get_plan(B);
+      if (!plan->AT) { hypre_CSRMatrixTranspose(B, &plan->AT, 1); }
+      M = plan->AT;
+   }
+   for (HYPRE_Int v = 0; v < x->num_vectors; v++)
+   {
+      spmv_device_core(alpha, M, x->data + (size_t) v * x->vecstride, beta,
+                       y->data + (size_t) v * y->vecstride, y->data + (size_t) v * y->vecstride, fill);
+   }
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// BLAS-1
+// ===========================================================================
+static inline size_t vlen(hypre_Vector *v) { return (size_t) v->size * (size_t) v->num_vectors; }
+
+HYPRE_Int hypre_SeqVectorSetConstantValuesDevice(hypre_Vector *v, HYPRE_Complex value)
+{
+   launch_set(v->data, value, vlen(v), stream());
+   maybe_sync();
+   return hypre_error_flag;
+}
+HYPRE_Int hypre_SeqVectorSetConstantValues(hypre_Vector *v, HYPRE_Complex value)
+{
+   if (v->memory_location == HYPRE_MEMORY_HOST)
+   {
+      // vectors are filled on the host while problems are assembled; this is
+      // data preparation, not part of the solve path
+      for (size_t i = 0; i < vlen(v); i++) { v->data[i] = value; }
+      return hypre_error_flag;
+   }
+   return hypre_SeqVectorSetConstantValuesDevice(v, value);
+}
+
+HYPRE_Int hypre_SeqVectorCopy(hypre_Vector *x, hypre_Vector *y)
+{
+   const size_t n = std::min(vlen(x), vlen(y));
+   if (x->memory_location == HYPRE_MEMORY_DEVICE && y->memory_location == HYPRE_MEMORY_DEVICE)
+   {
+      launch_copy(y->data, x->data, n, stream());
+      maybe_sync();
+   }
+   else
+   {
+      hypre_TMemcpy(y->data, x->data, HYPRE_Complex, n, y->memory_location, x->memory_location);
+   }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_SeqVectorScaleDevice(HYPRE_Complex alpha, hypre_Vector *y)
+{
+   launch_scale(y->data, alpha, vlen(y), stream());
+   maybe_sync();
+   return hypre_error_flag;
+}
+HYPRE_Int hypre_SeqVectorScale(HYPRE_Complex alpha, hypre_Vector *y)
+{
+   // shortcuts of seq_mv/vector.c:661-669
+   if (alpha == 1.0) { return hypre_error_flag; }
+   if (alpha == 0.0) { return hypre_SeqVectorSetConstantValues(y, 0.0); }
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_SeqVectorScale");
+   return hypre_SeqVectorScaleDevice(alpha, y);
+}
+
+HYPRE_Int hypre_SeqVectorAxpyDevice(HYPRE_Complex alpha, hypre_Vector *x, hypre_Vector *y)
+{
+   launch_axpy(alpha, x->data, y->data, vlen(x), stream());
+   maybe_sync();
+   return hypre_error_flag;
+}
+HYPRE_Int hypre_SeqVectorAxpy(HYPRE_Complex alpha, hypre_Vector *x, hypre_Vector *y)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_SeqVectorAxpy(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_SeqVectorAxpy(y)");
+   return hypre_SeqVectorAxpyDevice(alpha, x, y);
+}
+
+HYPRE_Int hypre_SeqVectorAxpyzDevice(HYPRE_Complex alpha, hypre_Vector *x, HYPRE_Complex beta,
+                                     hypre_Vector *y, hypre_Vector *z)
+{
+   launch_axpyz(alpha, x->data, beta, y->data, z->data, vlen(x), stream());
+   maybe_sync();
+   return hypre_error_flag;
+}
+HYPRE_Int hypre_SeqVectorAxpyz(HYPRE_Complex alpha, hypre_Vector *x, HYPRE_Complex beta,
+                               hypre_Vector *y, hypre_Vector *z)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_SeqVectorAxpyz(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_SeqVectorAxpyz(y)");
+   HYPRE_AMD_REQUIRE_DEVICE(z->memory_location, "hypre_SeqVectorAxpyz(z)");
+   return hypre_SeqVectorAxpyzDevice(alpha, x, beta, y, z);
+}
+
+HYPRE_Real hypre_SeqVectorInnerProdDevice(hypre_Vector *x, hypre_Vector *y)
+{
+   hipStream_t s = stream();
+   double *d_out = reduce_scratch(2048);
+   launch_dot(x->data, y->data, vlen(x), d_out, s);
+   double *h = handle().h_reduce;
+   HIP_CHECK(hipMemcpyAsync(h, d_out, sizeof(double), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   return h[0];
+}
+HYPRE_Real hypre_SeqVectorInnerProd(hypre_Vector *x, hypre_Vector *y)
+{
+   if (x->memory_location != HYPRE_MEMORY_DEVICE || y->memory_location != HYPRE_MEMORY_DEVICE)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_SeqVectorInnerProd: operand is not in device memory; host execution is not part of this library");
+      return 0.0;
+   }
+   return hypre_SeqVectorInnerProdDevice(x, y);
+}
+
+HYPRE_Int hypre_SeqVectorElmdivpyDevice(hypre_Vector *x, hypre_Vector *b, hypre_Vector *y,
+                                        HYPRE_Int *marker, HYPRE_Int marker_val)
+{
+   launch_elmdivpy(x->data, b->data, y->data, marker, marker_val, (size_t) b->size, stream());
+   maybe_sync();
+   return hypre_error_flag;
+}
+HYPRE_Int hypre_SeqVectorElmdivpy(hypre_Vector *x, hypre_Vector *b, hypre_Vector *y)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_SeqVectorElmdivpy(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_SeqVectorElmdivpy(y)");
+   return hypre_SeqVectorElmdivpyDevice(x, b, y, nullptr, -1);
+}
+HYPRE_Int hypre_SeqVectorElmdivpyMarked(hypre_Vector *x, hypre_Vector *b, hypre_Vector *y,
+                                        HYPRE_Int *marker, HYPRE_Int marker_val)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_SeqVectorElmdivpyMarked(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_SeqVectorElmdivpyMarked(y)");
+   return hypre_SeqVectorElmdivpyDevice(x, b, y, marker, marker_val);
+}
+
+HYPRE_Int hypreDevice_IVAXPY(HYPRE_Int n, HYPRE_Complex *a, HYPRE_Complex *x, HYPRE_Complex *y)
+{
+   if (n > 0) { launch_elmdivpy(x, a, y, nullptr, 0, (size_t) n, stream()); }
+   return hypre_error_flag;
+}
+HYPRE_Int hypreDevice_IVAXPYMarked(HYPRE_Int n, HYPRE_Complex *a, HYPRE_Complex *x, HYPRE_Complex *y,
+                                   HYPRE_Int *marker, HYPRE_Int marker_val)
+{
+   if (n > 0) { launch_elmdivpy(x, a, y, marker, marker_val, (size_t) n, stream()); }
+   return hypre_error_flag;
+}
+HYPRE_Int hypreDevice_DiagScaleVector2(HYPRE_Int num_vectors, HYPRE_Int num_rows, HYPRE_Complex *diag,
+                                       HYPRE_Complex *x, HYPRE_Complex beta, HYPRE_Complex *y,
+                                       HYPRE_Complex *z, HYPRE_Int computeY)
+{
+   for (HYPRE_Int v = 0; v < num_vectors; v++)
+   {
+      const size_t o = (size_t) v * (size_t) num_rows;
+      launch_diagscale2(diag, x + o, beta, y ? y + o : nullptr, z + o, computeY, (size_t) num_rows, stream());
+   }
+   return hypre_error_flag;
+}
+
+}  // extern "C"

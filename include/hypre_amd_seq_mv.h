@@ -1,0 +1,165 @@
+/*
+ * hypre_amd — local (per-rank) CSR matrix and dense vector, and the
+ * sequential matrix-vector / BLAS-1 entry points of the hot path.
+ *
+ * Struct layouts follow the reference in the configuration fixed in
+ * HYPRE_amd_utilities.h (no vendor sparse library => the four trailing
+ * vendor members of hypre_CSRMatrix are absent):
+ *   seq_mv/csr_matrix.h:33-58   hypre_CSRMatrix
+ *   seq_mv/vector.h:22-40       hypre_Vector
+ * Functions replace:
+ *   seq_mv/csr_matvec.c:860,894,1142      Matvec / MatvecOutOfPlace / MatvecT
+ *   seq_mv/csr_matvec_device.c:109        hypre_CSRMatrixMatvecDevice
+ *   seq_mv/csr_spmv_device.c:381          hypre_CSRMatrixSpMVDevice
+ *   seq_mv/vector.c:351,436,653,723,789,953,1030,1070  BLAS-1 dispatchers
+ *   seq_mv/vector_device.c:26-316         their *Device bodies
+ *   utilities/device_utils.c:667,713,2481 IVAXPY / IVAXPYMarked / DiagScaleVector2
+ *
+ * Execution: the compute functions run on the GPU only.  Operands whose
+ * memory_location is HYPRE_MEMORY_HOST make them raise HYPRE_ERROR_GENERIC
+ * ("host execution is not part of this library") — there is no CPU path.
+ */
+#ifndef HYPRE_AMD_SEQ_MV_H
+#define HYPRE_AMD_SEQ_MV_H
+
+#include "HYPRE_amd_utilities.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct
+{
+   HYPRE_Int            *i;
+   HYPRE_Int            *j;
+   HYPRE_BigInt         *big_j;
+   HYPRE_Int             num_rows;
+   HYPRE_Int             num_cols;
+   HYPRE_Int             num_nonzeros;
+   hypre_int            *i_short;
+   hypre_int            *j_short;
+   HYPRE_Int             owns_data;
+   HYPRE_Int             pattern_only;
+   HYPRE_Complex        *data;
+   HYPRE_Int            *rownnz;      /* ids of the non-empty rows (offd blocks) */
+   HYPRE_Int             num_rownnz;
+   HYPRE_MemoryLocation  memory_location;
+} hypre_CSRMatrix;
+
+#define hypre_CSRMatrixData(matrix)            ((matrix) -> data)
+#define hypre_CSRMatrixI(matrix)               ((matrix) -> i)
+#define hypre_CSRMatrixJ(matrix)               ((matrix) -> j)
+#define hypre_CSRMatrixBigJ(matrix)            ((matrix) -> big_j)
+#define hypre_CSRMatrixNumRows(matrix)         ((matrix) -> num_rows)
+#define hypre_CSRMatrixNumCols(matrix)         ((matrix) -> num_cols)
+#define hypre_CSRMatrixNumNonzeros(matrix)     ((matrix) -> num_nonzeros)
+#define hypre_CSRMatrixRownnz(matrix)          ((matrix) -> rownnz)
+#define hypre_CSRMatrixNumRownnz(matrix)       ((matrix) -> num_rownnz)
+#define hypre_CSRMatrixOwnsData(matrix)        ((matrix) -> owns_data)
+#define hypre_CSRMatrixPatternOnly(matrix)     ((matrix) -> pattern_only)
+#define hypre_CSRMatrixMemoryLocation(matrix)  ((matrix) -> memory_location)
+
+typedef struct
+{
+   HYPRE_Complex        *data;
+   HYPRE_Int             size;
+   HYPRE_Int             component;
+   HYPRE_Int             owns_data;
+   HYPRE_MemoryLocation  memory_location;
+   HYPRE_Int             num_vectors;
+   HYPRE_Int             multivec_storage_method;
+   HYPRE_Int             vecstride, idxstride;   /* v_j[i] = data[j*vecstride + i*idxstride] */
+} hypre_Vector;
+
+#define hypre_VectorData(vector)                  ((vector) -> data)
+#define hypre_VectorSize(vector)                  ((vector) -> size)
+#define hypre_VectorComponent(vector)             ((vector) -> component)
+#define hypre_VectorOwnsData(vector)              ((vector) -> owns_data)
+#define hypre_VectorMemoryLocation(vector)        ((vector) -> memory_location)
+#define hypre_VectorNumVectors(vector)            ((vector) -> num_vectors)
+#define hypre_VectorMultiVecStorageMethod(vector) ((vector) -> multivec_storage_method)
+#define hypre_VectorVectorStride(vector)          ((vector) -> vecstride)
+#define hypre_VectorIndexStride(vector)           ((vector) -> idxstride)
+
+/* triangular-part selectors of hypre_CSRMatrixSpMVDevice — seq_mv/csr_spmv_device.h:13-17 */
+#define HYPRE_SPMV_FILL_STRICT_LOWER -2
+#define HYPRE_SPMV_FILL_LOWER        -1
+#define HYPRE_SPMV_FILL_WHOLE         0
+#define HYPRE_SPMV_FILL_UPPER         1
+#define HYPRE_SPMV_FILL_STRICT_UPPER  2
+
+/* ---- objects (seq_mv/csr_matrix.c, seq_mv/vector.c) ---- */
+hypre_CSRMatrix *hypre_CSRMatrixCreate(HYPRE_Int num_rows, HYPRE_Int num_cols, HYPRE_Int num_nonzeros);
+HYPRE_Int hypre_CSRMatrixInitialize_v2(hypre_CSRMatrix *matrix, HYPRE_Int bigInit,
+                                       HYPRE_MemoryLocation memory_location);
+HYPRE_Int hypre_CSRMatrixInitialize(hypre_CSRMatrix *matrix);
+HYPRE_Int hypre_CSRMatrixDestroy(hypre_CSRMatrix *matrix);
+HYPRE_Int hypre_CSRMatrixSetRownnz(hypre_CSRMatrix *matrix);
+HYPRE_Int hypre_CSRMatrixMigrate(hypre_CSRMatrix *A, HYPRE_MemoryLocation memory_location);
+hypre_CSRMatrix *hypre_CSRMatrixClone_v2(hypre_CSRMatrix *A, HYPRE_Int copy_data,
+                                         HYPRE_MemoryLocation memory_location);
+HYPRE_Int hypre_CSRMatrixTranspose(hypre_CSRMatrix *A, hypre_CSRMatrix **AT, HYPRE_Int data);
+HYPRE_Int hypre_CSRMatrixReorder(hypre_CSRMatrix *A);   /* diagonal entry first; host matrices */
+
+hypre_Vector *hypre_SeqVectorCreate(HYPRE_Int size);
+hypre_Vector *hypre_SeqMultiVectorCreate(HYPRE_Int size, HYPRE_Int num_vectors);
+HYPRE_Int hypre_SeqVectorInitialize_v2(hypre_Vector *vector, HYPRE_MemoryLocation memory_location);
+HYPRE_Int hypre_SeqVectorInitialize(hypre_Vector *vector);
+HYPRE_Int hypre_SeqVectorDestroy(hypre_Vector *vector);
+HYPRE_Int hypre_SeqVectorMigrate(hypre_Vector *x, HYPRE_MemoryLocation memory_location);
+hypre_Vector *hypre_SeqVectorCloneDeep_v2(hypre_Vector *x, HYPRE_MemoryLocation memory_location);
+hypre_Vector *hypre_SeqVectorCloneDeep(hypre_Vector *x);
+
+/* ---- SpMV: y = alpha*A*x + beta*b  (b == y for the in-place forms) ----
+ * Return value: informational ierr 1/2/3 on dimension mismatch, exactly as
+ * seq_mv/csr_matvec.c:57-86 (the product is still formed). */
+HYPRE_Int hypre_CSRMatrixMatvecOutOfPlace(HYPRE_Complex alpha, hypre_CSRMatrix *A, hypre_Vector *x,
+                                          HYPRE_Complex beta, hypre_Vector *b, hypre_Vector *y,
+                                          HYPRE_Int offset);
+HYPRE_Int hypre_CSRMatrixMatvec(HYPRE_Complex alpha, hypre_CSRMatrix *A, hypre_Vector *x,
+                                HYPRE_Complex beta, hypre_Vector *y);
+HYPRE_Int hypre_CSRMatrixMatvecT(HYPRE_Complex alpha, hypre_CSRMatrix *A, hypre_Vector *x,
+                                 HYPRE_Complex beta, hypre_Vector *y);
+HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_CSRMatrix *A,
+                                      hypre_Vector *x, HYPRE_Complex beta, hypre_Vector *b,
+                                      hypre_Vector *y, HYPRE_Int offset);
+HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_CSRMatrix *B,
+                                    hypre_Vector *x, HYPRE_Complex beta, hypre_Vector *y,
+                                    HYPRE_Int fill);
+
+/* The row-binning plan and cached transpose the kernels use are kept in a
+ * side table keyed by the matrix address (the struct layout is untouched).
+ * Call after changing i/j/data in place or before freeing arrays that the
+ * library does not own. */
+HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A);
+
+/* ---- BLAS-1 (seq_mv/vector.c dispatchers + vector_device.c bodies) ---- */
+HYPRE_Int hypre_SeqVectorSetConstantValues(hypre_Vector *v, HYPRE_Complex value);
+HYPRE_Int hypre_SeqVectorCopy(hypre_Vector *x, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorScale(HYPRE_Complex alpha, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorAxpy(HYPRE_Complex alpha, hypre_Vector *x, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorAxpyz(HYPRE_Complex alpha, hypre_Vector *x, HYPRE_Complex beta,
+                               hypre_Vector *y, hypre_Vector *z);
+HYPRE_Real hypre_SeqVectorInnerProd(hypre_Vector *x, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorElmdivpy(hypre_Vector *x, hypre_Vector *b, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorElmdivpyMarked(hypre_Vector *x, hypre_Vector *b, hypre_Vector *y,
+                                        HYPRE_Int *marker, HYPRE_Int marker_val);
+HYPRE_Int hypre_SeqVectorSetConstantValuesDevice(hypre_Vector *v, HYPRE_Complex value);
+HYPRE_Int hypre_SeqVectorScaleDevice(HYPRE_Complex alpha, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorAxpyDevice(HYPRE_Complex alpha, hypre_Vector *x, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorAxpyzDevice(HYPRE_Complex alpha, hypre_Vector *x, HYPRE_Complex beta,
+                                     hypre_Vector *y, hypre_Vector *z);
+HYPRE_Real hypre_SeqVectorInnerProdDevice(hypre_Vector *x, hypre_Vector *y);
+HYPRE_Int hypre_SeqVectorElmdivpyDevice(hypre_Vector *x, hypre_Vector *b, hypre_Vector *y,
+                                        HYPRE_Int *marker, HYPRE_Int marker_val);
+HYPRE_Int hypreDevice_IVAXPY(HYPRE_Int n, HYPRE_Complex *a, HYPRE_Complex *x, HYPRE_Complex *y);
+HYPRE_Int hypreDevice_IVAXPYMarked(HYPRE_Int n, HYPRE_Complex *a, HYPRE_Complex *x, HYPRE_Complex *y,
+                                   HYPRE_Int *marker, HYPRE_Int marker_val);
+HYPRE_Int hypreDevice_DiagScaleVector2(HYPRE_Int num_vectors, HYPRE_Int num_rows,
+                                       HYPRE_Complex *diag, HYPRE_Complex *x, HYPRE_Complex beta,
+                                       HYPRE_Complex *y, HYPRE_Complex *z, HYPRE_Int computeY);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,70 @@
+/* oracle.h — data model of the CPU restatement (TEST INFRASTRUCTURE ONLY; see oracle.c). */
+#ifndef HYPRE_AMD_ORACLE_H
+#define HYPRE_AMD_ORACLE_H
+
+/* one CSR block (seq_mv/csr_matrix.h:33-58 reduced to what the loops read) */
+typedef struct
+{
+   int           nrows, ncols;
+   const int    *i, *j;
+   const double *a;
+   const int    *rownnz;      /* may be NULL */
+   int           num_rownnz;
+} ocsr;
+
+/* a distributed matrix as nranks virtual ranks (parcsr_mv/par_csr_matrix.h:27-86) */
+typedef struct
+{
+   int          nranks;
+   ocsr        *diag;            /* [nranks] */
+   ocsr        *offd;            /* [nranks] */
+   long long  **col_map_offd;    /* [nranks][offd.ncols] global column of each ghost */
+   long long   *row_starts;      /* [nranks+1] */
+   long long   *col_starts;      /* [nranks+1] */
+} opar;
+
+/* solve-relevant slice of hypre_ParAMGData (parcsr_ls/par_amg.h:70-116,191-197) */
+typedef struct
+{
+   int       num_levels, max_levels;
+   opar     *A;                  /* [num_levels] */
+   opar     *P;                  /* [num_levels-1]; restriction is P^T */
+   int     **cf_marker;          /* [num_levels] global arrays (NULL on the coarsest) */
+   double  **l1_norms;           /* [num_levels] or NULL entries */
+   double  **F, **U;             /* [num_levels] work vectors (level 0 slots are swapped in) */
+   double   *vtemp;              /* fine-grid sized */
+   int       num_grid_sweeps[4];
+   int       grid_relax_type[4];
+   int     **grid_relax_points;  /* NULL, or [4][sweeps] (old interface) */
+   int       relax_order;
+   int       user_relax_type;
+   double   *relax_weight;       /* [num_levels] */
+   double   *omega;              /* [num_levels] */
+   int       cycle_type, fcycle;
+   int       num_threads;        /* OpenMP thread count the hybrid smoothers emulate */
+} oamg;
+
+int    oracle_csr_matvec(double alpha, const ocsr *A, const double *x, int x_size, double beta,
+                         const double *b, int b_size, double *y, int y_size, int offset);
+int    oracle_csr_matvecT(double alpha, const ocsr *A, const double *x, int x_size, double beta,
+                          double *y, int y_size);
+double oracle_inner_prod(const double *x, const double *y, long long n);
+void   oracle_axpy(double alpha, const double *x, double *y, long long n);
+void   oracle_scale(double alpha, double *y, long long n);
+int    oracle_par_matvec(double alpha, const opar *A, const double *x, double beta, const double *b, double *y);
+int    oracle_par_matvecT(double alpha, const opar *A, const double *x, double beta, double *y);
+int    oracle_l1_norms(const opar *A, int option, const int *cf_marker, double *l1);
+int    oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax_type, int relax_points,
+                    double w, double omega, const double *l1, double *u, double *vtemp, int num_threads,
+                    int *all_zeros);
+int    oracle_relax_if(const opar *A, const double *f, const int *cf_marker, int relax_type, int relax_order,
+                       int cycle_param, double w, double omega, const double *l1, double *u, double *vtemp,
+                       int num_threads, int *all_zeros);
+int    oracle_gselim(double *A, double *x, int n);
+int    oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros);
+int    oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol, int min_iter, int max_iter,
+                        int converge_type, int u_all_zeros, double *rel_resid_out, int *conv_err,
+                        double *resid_hist);
+int    oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
+                      int two_norm, int precond_cycles, double *rel_resid_out, int *converged_out);
+#endif

@@ -1,0 +1,249 @@
+"""ctypes view of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the hypre_amd package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+IntP = C.POINTER(C.c_int)
+RealP = C.POINTER(C.c_double)
+LLP = C.POINTER(C.c_longlong)
+
+
+class OCSR(C.Structure):
+    _fields_ = [("nrows", C.c_int), ("ncols", C.c_int), ("i", IntP), ("j", IntP), ("a", RealP),
+                ("rownnz", IntP), ("num_rownnz", C.c_int)]
+
+
+class OPAR(C.Structure):
+    _fields_ = [("nranks", C.c_int), ("diag", C.POINTER(OCSR)), ("offd", C.POINTER(OCSR)),
+                ("col_map_offd", C.POINTER(LLP)), ("row_starts", LLP), ("col_starts", LLP)]
+
+
+class OAMG(C.Structure):
+    _fields_ = [("num_levels", C.c_int), ("max_levels", C.c_int), ("A", C.POINTER(OPAR)), ("P", C.POINTER(OPAR)),
+                ("cf_marker", C.POINTER(IntP)), ("l1_norms", C.POINTER(RealP)), ("F", C.POINTER(RealP)),
+                ("U", C.POINTER(RealP)), ("vtemp", RealP), ("num_grid_sweeps", C.c_int * 4),
+                ("grid_relax_type", C.c_int * 4), ("grid_relax_points", C.POINTER(IntP)),
+                ("relax_order", C.c_int), ("user_relax_type", C.c_int), ("relax_weight", RealP),
+                ("omega", RealP), ("cycle_type", C.c_int), ("fcycle", C.c_int), ("num_threads", C.c_int)]
+
+
+def build():
+    subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    return LIB
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "oracle.c")):
+        build()
+    L = C.CDLL(LIB)
+    P = C.POINTER
+    L.oracle_csr_matvec.restype = C.c_int
+    L.oracle_csr_matvec.argtypes = [C.c_double, P(OCSR), RealP, C.c_int, C.c_double, RealP, C.c_int, RealP,
+                                    C.c_int, C.c_int]
+    L.oracle_csr_matvecT.restype = C.c_int
+    L.oracle_csr_matvecT.argtypes = [C.c_double, P(OCSR), RealP, C.c_int, C.c_double, RealP, C.c_int]
+    L.oracle_inner_prod.restype = C.c_double
+    L.oracle_inner_prod.argtypes = [RealP, RealP, C.c_longlong]
+    L.oracle_axpy.restype = None
+    L.oracle_axpy.argtypes = [C.c_double, RealP, RealP, C.c_longlong]
+    L.oracle_par_matvec.restype = C.c_int
+    L.oracle_par_matvec.argtypes = [C.c_double, P(OPAR), RealP, C.c_double, RealP, RealP]
+    L.oracle_par_matvecT.restype = C.c_int
+    L.oracle_par_matvecT.argtypes = [C.c_double, P(OPAR), RealP, C.c_double, RealP]
+    L.oracle_l1_norms.restype = C.c_int
+    L.oracle_l1_norms.argtypes = [P(OPAR), C.c_int, IntP, RealP]
+    L.oracle_relax.restype = C.c_int
+    L.oracle_relax.argtypes = [P(OPAR), RealP, IntP, C.c_int, C.c_int, C.c_double, C.c_double, RealP, RealP,
+                               RealP, C.c_int, IntP]
+    L.oracle_relax_if.restype = C.c_int
+    L.oracle_relax_if.argtypes = [P(OPAR), RealP, IntP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                  RealP, RealP, RealP, C.c_int, IntP]
+    L.oracle_gselim.restype = C.c_int
+    L.oracle_gselim.argtypes = [RealP, RealP, C.c_int]
+    L.oracle_amg_cycle.restype = C.c_int
+    L.oracle_amg_cycle.argtypes = [P(OAMG), P(RealP), P(RealP), IntP]
+    L.oracle_amg_solve.restype = C.c_int
+    L.oracle_amg_solve.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   RealP, IntP, RealP]
+    L.oracle_pcg_amg.restype = C.c_int
+    L.oracle_pcg_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                 RealP, IntP]
+    _lib = L
+    return L
+
+
+def _ip(a):
+    return a.ctypes.data_as(IntP)
+
+
+def _rp(a):
+    return a.ctypes.data_as(RealP) if a is not None else None
+
+
+class Csr:
+    """Keeps the numpy arrays alive next to the C struct."""
+
+    def __init__(self, nrows, ncols, indptr, indices, data, rownnz=None):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.data = np.ascontiguousarray(data, dtype=np.float64)
+        self.rownnz = None if rownnz is None else np.ascontiguousarray(rownnz, dtype=np.int32)
+        self.c = OCSR(int(nrows), int(ncols), _ip(self.indptr), _ip(self.indices), _rp(self.data),
+                      _ip(self.rownnz) if self.rownnz is not None else None,
+                      int(len(self.rownnz)) if self.rownnz is not None else int(nrows))
+
+    @classmethod
+    def from_scipy(cls, A, with_rownnz=False):
+        A = A.tocsr()
+        rn = None
+        if with_rownnz:
+            rn = np.nonzero(np.diff(A.indptr))[0].astype(np.int32)
+            if len(rn) == A.shape[0] or len(rn) == 0:
+                rn = None
+        return cls(A.shape[0], A.shape[1], A.indptr, A.indices, A.data, rn)
+
+
+class Par:
+    """Distributed matrix as virtual ranks.  blocks = list of
+    (diag Csr, offd Csr, col_map_offd int64 array); row_starts/col_starts global."""
+
+    def __init__(self, blocks, row_starts, col_starts):
+        self.blocks = blocks
+        n = len(blocks)
+        self.row_starts = np.ascontiguousarray(row_starts, dtype=np.int64)
+        self.col_starts = np.ascontiguousarray(col_starts, dtype=np.int64)
+        self._diag = (OCSR * n)(*[b[0].c for b in blocks])
+        self._offd = (OCSR * n)(*[b[1].c for b in blocks])
+        self._cmaps = [np.ascontiguousarray(b[2], dtype=np.int64) for b in blocks]
+        self._cmap_ptrs = (LLP * n)(*[m.ctypes.data_as(LLP) for m in self._cmaps])
+        self.c = OPAR(n, self._diag, self._offd, self._cmap_ptrs, self.row_starts.ctypes.data_as(LLP),
+                      self.col_starts.ctypes.data_as(LLP))
+
+    @property
+    def nrows(self):
+        return int(self.row_starts[-1])
+
+    @property
+    def ncols(self):
+        return int(self.col_starts[-1])
+
+    @classmethod
+    def from_scipy_single(cls, A):
+        """One virtual rank holding the whole matrix (no ghost block)."""
+        import scipy.sparse as sp
+        A = A.tocsr()
+        offd = Csr(A.shape[0], 0, np.zeros(A.shape[0] + 1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+        return cls([(Csr.from_scipy(A), offd, np.zeros(0, np.int64))], [0, A.shape[0]], [0, A.shape[1]])
+
+
+class Amg:
+    """oamg built from python-side level lists."""
+
+    def __init__(self, A_levels, P_levels, cf_markers, l1_norms, num_grid_sweeps, grid_relax_type,
+                 relax_order=0, relax_weight=None, omega=None, cycle_type=1, fcycle=0, num_threads=1,
+                 max_levels=25, user_relax_type=-1, grid_relax_points=None):
+        L = len(A_levels)
+        self.A_levels, self.P_levels = A_levels, P_levels
+        self.cf = [None if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in cf_markers]
+        self.l1 = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in l1_norms]
+        sizes = [a.nrows for a in A_levels]
+        self.F = [np.zeros(max(n, 1)) for n in sizes]
+        self.U = [np.zeros(max(n, 1)) for n in sizes]
+        self.vtemp = np.zeros(max(sizes[0], 1))
+        self.rw = np.ascontiguousarray(relax_weight if relax_weight is not None else np.ones(L), dtype=np.float64)
+        self.om = np.ascontiguousarray(omega if omega is not None else np.ones(L), dtype=np.float64)
+        self._A = (OPAR * L)(*[a.c for a in A_levels])
+        self._P = (OPAR * max(L - 1, 1))(*[p.c for p in P_levels]) if L > 1 else (OPAR * 1)()
+        self._cf = (IntP * L)(*[_ip(c) if c is not None else None for c in self.cf])
+        self._l1 = (RealP * L)(*[_rp(v) if v is not None else None for v in self.l1])
+        self._F = (RealP * L)(*[_rp(v) for v in self.F])
+        self._U = (RealP * L)(*[_rp(v) for v in self.U])
+        self._grp = None
+        self._grp_rows = None
+        if grid_relax_points is not None:
+            self._grp_rows = [np.ascontiguousarray(r, dtype=np.int32) for r in grid_relax_points]
+            self._grp = (IntP * 4)(*[_ip(r) for r in self._grp_rows])
+        self.c = OAMG(L, max_levels, self._A, self._P, self._cf, self._l1, self._F, self._U, _rp(self.vtemp),
+                      (C.c_int * 4)(*num_grid_sweeps), (C.c_int * 4)(*grid_relax_type), self._grp, relax_order,
+                      user_relax_type, _rp(self.rw), _rp(self.om), cycle_type, fcycle, num_threads)
+
+    def cycle(self, f, u, u_all_zeros=False):
+        L = load()
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        self._F[0] = _rp(f)
+        self._U[0] = _rp(u)
+        az = C.c_int(1 if u_all_zeros else 0)
+        err = L.oracle_amg_cycle(C.byref(self.c), self._F, self._U, C.byref(az))
+        self._F[0] = _rp(self.F[0])
+        self._U[0] = _rp(self.U[0])
+        return err
+
+    def solve(self, f, u, tol=1e-8, min_iter=0, max_iter=20, converge_type=0, u_all_zeros=False):
+        L = load()
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        rel = C.c_double(0.0)
+        conv = C.c_int(0)
+        hist = np.zeros(max_iter + 2)
+        its = L.oracle_amg_solve(C.byref(self.c), _rp(f), _rp(u), tol, min_iter, max_iter, converge_type,
+                                 1 if u_all_zeros else 0, C.byref(rel), C.byref(conv), _rp(hist))
+        return its, rel.value, conv.value, hist[:its + 1]
+
+    def pcg(self, b, x, tol=1e-8, atol=0.0, max_iter=1000, two_norm=1, precond_cycles=1):
+        L = load()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        rel = C.c_double(0.0)
+        conv = C.c_int(0)
+        its = L.oracle_pcg_amg(C.byref(self.c), _rp(b), _rp(x), tol, atol, max_iter, two_norm, precond_cycles,
+                               C.byref(rel), C.byref(conv))
+        return its, rel.value, conv.value
+
+
+def csr_matvec(alpha, A, x, beta, b, y, offset=0):
+    L = load()
+    return L.oracle_csr_matvec(alpha, C.byref(A.c), _rp(x), len(x), beta, _rp(b), len(b), _rp(y), len(y), offset)
+
+
+def csr_matvecT(alpha, A, x, beta, y):
+    L = load()
+    return L.oracle_csr_matvecT(alpha, C.byref(A.c), _rp(x), len(x), beta, _rp(y), len(y))
+
+
+def par_matvec(alpha, A, x, beta, b, y):
+    return load().oracle_par_matvec(alpha, C.byref(A.c), _rp(x), beta, _rp(b), _rp(y))
+
+
+def par_matvecT(alpha, A, x, beta, y):
+    return load().oracle_par_matvecT(alpha, C.byref(A.c), _rp(x), beta, _rp(y))
+
+
+def l1_norms(A, option, cf_marker=None):
+    out = np.zeros(A.nrows)
+    cf = None if cf_marker is None else np.ascontiguousarray(cf_marker, dtype=np.int32)
+    bad = load().oracle_l1_norms(C.byref(A.c), option, _ip(cf) if cf is not None else None, _rp(out))
+    return out, bad
+
+
+def relax(A, f, cf_marker, relax_type, relax_points, w, omega, l1, u, num_threads=1, all_zeros=False):
+    cf = None if cf_marker is None else np.ascontiguousarray(cf_marker, dtype=np.int32)
+    vtemp = np.zeros(max(A.nrows, 1))
+    az = C.c_int(1 if all_zeros else 0)
+    f = np.ascontiguousarray(f, dtype=np.float64)
+    l1 = None if l1 is None else np.ascontiguousarray(l1, dtype=np.float64)
+    err = load().oracle_relax(C.byref(A.c), _rp(f), _ip(cf) if cf is not None else None, relax_type,
+                              relax_points, w, omega, _rp(l1), _rp(u), _rp(vtemp), num_threads, C.byref(az))
+    return err

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from hypre_amd import binding
+    return binding.load_library(build_if_missing=True)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib(lib):
+    if not lib.hypre_amd_DeviceAvailable():
+        pytest.fail("no HIP device: the gpu-marked tests must run on the GPU box")
+    return lib
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    pyoracle.load()
+    return pyoracle

@@ -1,0 +1,46 @@
+"""CPU: the oracle's products against scipy (sanity of the restatement itself)."""
+import numpy as np
+import pytest
+
+from util import laplace_3d, random_csr, rand_vector
+
+
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-1.0, 1.0), (2.0, -2.0), (2.0, 2.0), (0.5, 0.25), (0.0, 3.0)])
+def test_csr_matvec_matches_scipy(oracle, alpha, beta):
+    A = random_csr(300, 200, 0, 9, seed=4, empty_frac=0.1)
+    x, b = rand_vector(200, 1), rand_vector(300, 2)
+    for with_rownnz in (False, True):
+        y = np.zeros(300)
+        assert oracle.csr_matvec(alpha, oracle.Csr.from_scipy(A, with_rownnz), x, beta, b, y) == 0
+        assert np.allclose(y, alpha * (A @ x) + beta * b, rtol=1e-13, atol=1e-13)
+
+
+def test_csr_matvec_alias_and_ierr(oracle):
+    A = laplace_3d(4, 4, 4)
+    oA = oracle.Csr.from_scipy(A)
+    x = rand_vector(64, 1)
+    y = x.copy()
+    oracle.csr_matvec(1.0, oA, y, 0.0, y, y)          # x == y is deep-cloned
+    assert np.allclose(y, A @ x)
+    assert oracle.csr_matvec(1.0, oA, np.ones(70), 0.0, np.ones(70), np.zeros(70)) == 3
+    assert oracle.csr_matvec(1.0, oA, np.ones(70), 0.0, np.ones(64), np.zeros(64)) == 1
+    assert oracle.csr_matvec(1.0, oA, np.ones(64), 0.0, np.ones(70), np.zeros(70)) == 2
+
+
+def test_csr_matvecT(oracle):
+    A = random_csr(120, 80, 1, 5, seed=2)
+    x, y0 = rand_vector(120, 3), rand_vector(80, 4)
+    y = y0.copy()
+    oracle.csr_matvecT(-1.5, oracle.Csr.from_scipy(A), x, 0.5, y)
+    assert np.allclose(y, -1.5 * (A.T @ x) + 0.5 * y0, rtol=1e-13, atol=1e-13)
+
+
+def test_gselim(oracle):
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    M = rng.uniform(-1, 1, (7, 7)) + 7 * np.eye(7)
+    b = rng.uniform(-1, 1, 7)
+    Mc, x = M.copy().ravel(), b.copy()
+    L = oracle.load()
+    assert L.oracle_gselim(Mc.ctypes.data_as(oracle.RealP), x.ctypes.data_as(oracle.RealP), 7) == 0
+    assert np.allclose(x, np.linalg.solve(M, b), rtol=1e-12)

@@ -1,0 +1,152 @@
+"""Parity of the HIP sequential SpMV (hypre_CSRMatrixMatvec* through the C ABI)
+against the CPU oracle, on seeded inputs.  fp64; tolerance: the GPU sums each
+row in a different association than the reference's serial loop, so results
+agree to a few ulps of the row's absolute sum: |y_gpu - y_ref| <= 1e-13 * (|alpha| |A| |x| + |beta b|)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from util import laplace_3d, random_csr, rand_vector
+
+pytestmark = pytest.mark.gpu
+
+
+def _bound(A, x, alpha, beta, b):
+    return 1e-13 * (abs(alpha) * (abs(A) @ np.abs(x)) + abs(beta) * np.abs(b)) + 1e-300
+
+
+def _run(lib, oracle, A, alpha, beta, seed=0, inplace=False):
+    from hypre_amd import binding as B
+    x = rand_vector(A.shape[1], seed + 1)
+    b = rand_vector(A.shape[0], seed + 2)
+    y0 = rand_vector(A.shape[0], seed + 3)
+    dA = B.csr_from_scipy(A)
+    dx, db = B.vec_from_numpy(x), B.vec_from_numpy(b)
+    dy = B.vec_from_numpy(b if inplace else y0)
+    if inplace:
+        ierr = lib.hypre_CSRMatrixMatvec(alpha, dA, dx, beta, dy)
+    else:
+        ierr = lib.hypre_CSRMatrixMatvecOutOfPlace(alpha, dA, dx, beta, db, dy, 0)
+    B.check()
+    y = B.vec_to_numpy(dy)
+    oA = oracle.Csr.from_scipy(A)
+    yr = (b if inplace else y0).copy()
+    ierr_ref = oracle.csr_matvec(alpha, oA, x, beta, b, yr)
+    assert ierr == ierr_ref == 0
+    assert np.all(np.abs(y - yr) <= _bound(A, x, alpha, beta, b)), np.abs(y - yr).max()
+    for o in (dx, db, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
+
+
+@pytest.mark.parametrize("alpha,beta", [(1.0, 0.0), (-1.0, 1.0), (1.0, 1.0), (1.0, -1.0), (-1.0, -1.0),
+                                        (2.5, 0.0), (2.5, -2.5), (2.5, 2.5), (0.7, 0.3), (-1.0, 0.4),
+                                        (1.0, 0.4), (0.0, 0.5), (-1.0, 0.0)])
+def test_laplacian_all_branches(gpu_lib, oracle, alpha, beta):
+    _run(gpu_lib, oracle, laplace_3d(8, 8, 8), alpha, beta)
+
+
+def test_27pt_and_inplace(gpu_lib, oracle):
+    _run(gpu_lib, oracle, laplace_3d(6, 6, 6, 27), 1.0, 0.0)
+    _run(gpu_lib, oracle, laplace_3d(6, 6, 6, 27), -1.0, 1.0, inplace=True)
+
+
+@pytest.mark.parametrize("lo,hi", [(0, 4), (1, 12), (13, 48), (49, 160), (200, 900)])
+def test_row_length_bins(gpu_lib, oracle, lo, hi):
+    """Every reduction width of the tiled kernel (1, 8, 32 lanes per row) plus ragged tiles."""
+    A = random_csr(3000, 2500, lo, hi, seed=hi)
+    _run(gpu_lib, oracle, A, 1.0, 0.0, seed=hi)
+    _run(gpu_lib, oracle, A, -0.5, 2.0, seed=hi + 1)
+
+
+def test_rectangular_with_empty_rows(gpu_lib, oracle):
+    A = random_csr(5000, 700, 0, 4, seed=3, empty_frac=0.4)
+    _run(gpu_lib, oracle, A, 1.0, 1.0, seed=5)
+
+
+def test_long_rows_fall_back_to_wave_kernel(gpu_lib, oracle):
+    A = random_csr(40, 5000, 1500, 3000, seed=9)
+    _run(gpu_lib, oracle, A, 1.0, 0.0, seed=7)
+    _run(gpu_lib, oracle, A, 1.0, -1.0, seed=8)
+
+
+def test_empty_matrix_and_zero_rows(gpu_lib, oracle):
+    A = sp.csr_matrix((50, 30))
+    _run(gpu_lib, oracle, A, 1.0, 0.5)
+
+
+def test_rownnz_path(gpu_lib, oracle):
+    """Off-diagonal-like block: few non-empty rows, rownnz list set -> sparse-row kernel."""
+    from hypre_amd import binding as B
+    A = random_csr(4000, 300, 1, 3, seed=11, empty_frac=0.95)
+    x = rand_vector(300, 1); y0 = rand_vector(4000, 2)
+    dA = B.csr_from_scipy(A)
+    gpu_lib.hypre_CSRMatrixSetRownnz(dA)
+    assert dA.contents.num_rownnz < 0.7 * 4000 and bool(dA.contents.rownnz)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(y0)
+    gpu_lib.hypre_CSRMatrixMatvec(-1.0, dA, dx, 1.0, dy)
+    B.check()
+    y = B.vec_to_numpy(dy)
+    oA = oracle.Csr.from_scipy(A, with_rownnz=True)
+    yr = y0.copy()
+    oracle.csr_matvec(-1.0, oA, x, 1.0, y0.copy(), yr)
+    assert np.all(np.abs(y - yr) <= _bound(A, x, -1.0, 1.0, y0))
+
+
+def test_transpose(gpu_lib, oracle):
+    from hypre_amd import binding as B
+    A = random_csr(900, 400, 1, 6, seed=21)
+    x = rand_vector(900, 1); y0 = rand_vector(400, 2)
+    dA = B.csr_from_scipy(A)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(y0)
+    ierr = gpu_lib.hypre_CSRMatrixMatvecT(2.0, dA, dx, -1.0, dy)
+    B.check()
+    y = B.vec_to_numpy(dy)
+    yr = y0.copy()
+    assert oracle.csr_matvecT(2.0, oracle.Csr.from_scipy(A), x, -1.0, yr) == ierr == 0
+    assert np.all(np.abs(y - yr) <= 1e-13 * (2.0 * (abs(A).T @ np.abs(x)) + np.abs(y0)) + 1e-300)
+
+
+def test_size_mismatch_is_informational(gpu_lib, oracle):
+    """ierr 1/2/3 is returned and the product is still formed (csr_matvec.c:57-86)."""
+    from hypre_amd import binding as B
+    A = laplace_3d(4, 4, 4)
+    dA = B.csr_from_scipy(A)
+    dx = B.vec_from_numpy(np.ones(70)); dy = B.vec_from_numpy(np.zeros(70))
+    assert gpu_lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy) == 3
+    B.check()
+    y = B.vec_to_numpy(dy)[:64]
+    assert np.allclose(y, A @ np.ones(64))
+
+
+def test_host_operands_fail_loudly(gpu_lib):
+    from hypre_amd import binding as B
+    A = laplace_3d(4, 4, 4)
+    hA = B.csr_from_scipy(A, B.HYPRE_MEMORY_HOST)
+    hx = B.vec_from_numpy(np.ones(64), B.HYPRE_MEMORY_HOST)
+    hy = B.vec_from_numpy(np.zeros(64), B.HYPRE_MEMORY_HOST)
+    gpu_lib.hypre_CSRMatrixMatvec(1.0, hA, hx, 0.0, hy)
+    with pytest.raises(B.HypreAmdError, match="host execution is not part of this library"):
+        B.check()
+
+
+def test_blas1(gpu_lib, oracle):
+    from hypre_amd import binding as B
+    n = 100003
+    x, y = rand_vector(n, 1), rand_vector(n, 2)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(y)
+    dot = gpu_lib.hypre_SeqVectorInnerProd(dx, dy)
+    assert abs(dot - float(np.dot(x, y))) <= 1e-12 * float(np.dot(np.abs(x), np.abs(y)))
+    gpu_lib.hypre_SeqVectorAxpy(0.3, dx, dy)
+    assert np.allclose(B.vec_to_numpy(dy), y + 0.3 * x, rtol=0, atol=1e-15)
+    gpu_lib.hypre_SeqVectorScale(-2.0, dy)
+    assert np.allclose(B.vec_to_numpy(dy), -2.0 * (y + 0.3 * x), rtol=0, atol=1e-15)
+    dz = B.vec_from_numpy(np.zeros(n))
+    gpu_lib.hypre_SeqVectorAxpyz(2.0, dx, -1.0, dy, dz)
+    assert np.allclose(B.vec_to_numpy(dz), 2.0 * x + 2.0 * (y + 0.3 * x), rtol=0, atol=1e-14)
+    d = np.abs(rand_vector(n, 3)) + 0.5
+    dd = B.vec_from_numpy(d)
+    ybefore = B.vec_to_numpy(dy)
+    gpu_lib.hypre_SeqVectorElmdivpy(dx, dd, dy)
+    assert np.allclose(B.vec_to_numpy(dy), ybefore + x / d, rtol=0, atol=1e-14)
+    B.check()
