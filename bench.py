@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""BoomerAMG V-cycle benchmark on synthetic 7-point Laplacians (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one application of the hot path: one V(1,1) BoomerAMG cycle
+(PMIS / extended+i (4 per row) / l1-Jacobi, fp64) from a zero initial guess, as PCG applies it
+as a preconditioner, through HYPRE_BoomerAMGSolve of the C-ABI library.  Inputs
+(matrix hierarchy, right-hand side) are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=256, help="grid points per dimension PER GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cycles", type=int, default=2)
+    return ap.parse_args()
+
+
+def proc_grid(n):
+    """P x Q x R box decomposition used by the reference's benchmark jobs (1, 2x1x1, 2x2x1, 2x2x2)."""
+    P = Q = R = 1
+    k = 0
+    while P * Q * R < n:
+        if k % 3 == 0:
+            P *= 2
+        elif k % 3 == 1:
+            Q *= 2
+        else:
+            R *= 2
+        k += 1
+    if P * Q * R != n:
+        raise SystemExit("--gpus must be a power of two")
+    return P, Q, R
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from hypre_amd import binding as B, ij
+    L = B.load_library()          # raises when the HIP library is missing: no fallback exists
+    if not L.hypre_amd_DeviceAvailable():
+        raise SystemExit("bench.py needs a HIP device")
+
+    comm = 0
+    if world > 1:
+        from hypre_amd import distributed
+        comm = distributed.create_rccl_comm(dist, rank, world)
+
+    P, Q, R = proc_grid(world)
+    n1 = args.n
+    opt = ij.IJOptions(n=(n1 * P, n1 * Q, n1 * R), P=(P, Q, R), coarsen_type=8, interp_type=6, P_max_elmts=4,
+                       relax_type=18, num_sweeps=1)
+    t0 = time.time()
+    A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+    L.HYPRE_BoomerAMGSetup(s, A, None, None)
+    B.check()
+    L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+    setup_s = time.time() - t0
+    Am = A.contents
+    nloc = Am.diag.contents.num_rows
+    nglob = int(Am.global_num_rows)
+    b = B.parvec_from_numpy(np.ones(nloc), comm=comm, global_size=nglob, first=int(Am.row_starts[0]))
+    u = B.parvec_from_numpy(np.zeros(nloc), comm=comm, global_size=nglob, first=int(Am.row_starts[0]))
+    L.HYPRE_BoomerAMGSetTol(s, 0.0)
+    L.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    L.hypre_SetSyncCudaCompute(0)
+
+    def step():
+        L.hypre_ParVectorSetZeros(u)                 # PCG's ClearVector before each preconditioner call
+        L.HYPRE_BoomerAMGSolve(s, A, b, u)
+
+    def fence():
+        L.hypre_SyncComputeStream()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    B.check()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    B.check()
+    ms_per_step = 1e3 * elapsed / args.steps
+    dof_per_s = nglob / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel: fine-level CSR SpMV y = A x ------------------
+    diag = Am.diag
+    nnz = diag.contents.num_nonzeros
+    x = B.vec_from_numpy(np.random.default_rng(rank).uniform(-1, 1, nloc))
+    y = B.vec_from_numpy(np.zeros(nloc))
+    reps = 50
+    for _ in range(5):
+        L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
+    L.hypre_SyncComputeStream()
+    L.hypre_amd_EventTimerStart()
+    for _ in range(reps):
+        L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
+    spmv_ms = L.hypre_amd_EventTimerStopMs() / reps
+    spmv_bytes = nnz * 12 + (nloc + 1) * 4 + nloc * 8 + nloc * 8
+    spmv_gbs = spmv_bytes / spmv_ms / 1e6
+    cycle_bytes = L.hypre_amd_BoomerAMGCycleBytes(s)
+    B.check()
+
+    # ---- CPU baseline: the oracle's V-cycle on the same hierarchy, one core -------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle as O
+        amg = O.amg_from_solvers([s])
+        f = np.ones(nloc)
+        ur = np.zeros(nloc)
+        amg.cycle(f, ur, u_all_zeros=True)          # warm the caches / page in
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_cycles):
+            ur[:] = 0.0
+            amg.cycle(f, ur, u_all_zeros=True)
+        cpu_s = (time.perf_counter() - t0) / args.cpu_cycles
+        ug = B.parvec_to_numpy(u)
+        parity = float(np.max(np.abs(ug - ur)) / np.max(np.abs(ur)))
+        cpu = {"value": nglob / cpu_s, "unit": "DOF/s", "cores": 1, "kind": "port",
+               "sample": "%d full V(1,1) cycles of the same %d^3 hierarchy (oracle/oracle.c, 1 thread)" %
+                         (args.cpu_cycles, n1),
+               "gpu_vs_cpu_cycle_rel_max_diff": parity}
+
+    if rank == 0:
+        g, o = C.c_double(), C.c_double()
+        L.hypre_amd_BoomerAMGGetComplexities(s, C.byref(g), C.byref(o))
+        out = {
+            "metric": "BoomerAMG V-cycle DOF/s (256^3 7-pt Laplacian per GPU, l1-Jacobi V(1,1), fp64)",
+            "value": dof_per_s, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%dx%d 7-pt Laplacian, %d rank(s) %dx%dx%d, PMIS + ext+i(4) + l1-Jacobi V(1,1)"
+                                   % (n1 * P, n1 * Q, n1 * R, world, P, Q, R),
+                       "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
+                       "operator_complexity": o.value, "setup_seconds": setup_s},
+            "roofline": {"bound": "hbm", "kernel": "spmv_tiled_kernel<AXPBY> (fine-level y = A x)",
+                         "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},
+            "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
+                       "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

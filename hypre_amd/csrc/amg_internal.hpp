@@ -1,0 +1,54 @@
+// hypre_amd — internal declarations of the BoomerAMG translation units.
+#pragma once
+#include "internal.hpp"
+#include "hypre_amd_parcsr_ls.h"
+#include <vector>
+
+namespace hamd {
+
+// Device-side state that rides along with a hypre_ParAMGData (amd_private).
+struct AmgPrivate
+{
+   int  emulated_threads = 1;      // thread count the thread-partitioned host loops emulate
+   bool mixed_precision  = false;
+
+   // second solution buffer per level: Jacobi-type sweeps are out-of-place
+   // (u_new is written while u_old is gathered), so every level ping-pongs
+   // between its home vector and this one instead of copying back.
+   std::vector<double *> u_alt;     // [num_levels], device
+   std::vector<int>      u_alt_len;
+
+   // coarsest level: factors of the reference's pivot-free elimination
+   // (utilities/gselim.h), computed once on the host, applied on the device
+   double *d_coarse_lu = nullptr;   // n*n row-major: U on/above the diagonal, multipliers below
+   double *d_coarse_rhs = nullptr;  // n (gathered right-hand side)
+   int     coarse_n = 0;
+   int     coarse_first_row = 0;    // this rank's offset into the gathered system
+
+   // algorithmic byte count of one cycle (filled by setup, SURVEY §8d formula)
+   double cycle_bytes = 0.0;
+
+   void release_device();
+   ~AmgPrivate() { release_device(); }
+};
+
+}  // namespace hamd
+
+extern "C" void amg_free_hierarchy(hypre_ParAMGData *d);
+
+namespace hamd {
+
+// raw-pointer cores shared by the public entry points and the cycle
+void dev_par_matvec(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, const double *x, HYPRE_Complex beta,
+                    const double *b, double *y);
+void dev_par_matvecT(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, const double *x, HYPRE_Complex beta, double *y);
+// Jacobi-type sweep u_out = u_in + w*(f - A u_in)./d on marked rows, u_out = u_in elsewhere
+void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_marker, int relax_points,
+                      double w, const double *d, const double *u_in, double *u_out);
+
+void launch_jacobi_update(const double *u_in, const double *r, const double *d, const int *marker, int mval,
+                          double *u_out, size_t n, hipStream_t s);
+void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStream_t s);
+void launch_coarse_solve(const double *lu, double *x, int n, hipStream_t s);
+
+}  // namespace hamd

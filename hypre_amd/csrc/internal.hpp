@@ -98,7 +98,8 @@ enum SpmvOp
 {
    OP_AXPBY   = 0,  // y = alpha*(A x) + beta*b
    OP_JACOBI  = 1,  // y = x + w*(b - A x)./d          (b=f, d=l1 or diag vector)
-   OP_JACOBI_CF = 2 // same, rows with marker!=pts copy x
+   OP_JACOBI_CF = 2, // same, rows with marker!=pts copy x
+   OP_TSGS    = 3   // y = (A_fill x)./d ; aux += alpha*y   (two-stage GS inner step)
 };
 
 struct SpmvArgs
@@ -110,6 +111,7 @@ struct SpmvArgs
    const HYPRE_Complex *x;
    const HYPRE_Complex *b;        // may be null when beta == 0
    HYPRE_Complex       *y;
+   HYPRE_Complex       *aux;      // second output of the OP_TSGS epilogue
    const HYPRE_Complex *d;        // diagonal / l1 norms for the relax epilogues
    const HYPRE_Int     *marker;   // CF marker or null
    int                  marker_val;

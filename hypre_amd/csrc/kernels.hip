@@ -13,7 +13,7 @@
 //   utilities/device_utils.c:2422-2468  DiagScaleVector2
 //   seq_mv/vector_device.c              axpy / scale / dot via rocBLAS+thrust
 
-#include "internal.hpp"
+#include "amg_internal.hpp"
 
 namespace hamd {
 
@@ -57,6 +57,14 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double 
       double r = p.alpha * sum;
       if (p.beta != 0.0) { r += p.beta * p.b[row]; }
       p.y[row] = r;
+   }
+   else if (OP == OP_TSGS)
+   {
+      // inner step of the two-stage Gauss-Seidel sweep (par_relax_device.c:139-150):
+      //    z_out = (L_strict z_in) ./ D ;  u += mult * z_out
+      const double z = sum * (1.0 / p.d[row]);
+      p.y[row] = z;
+      p.aux[row] += p.alpha * z;
    }
    else
    {
@@ -358,6 +366,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, args, s); break;
       case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, args, s); break;
       case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, args, s); break;
+      case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, args, s); break;
    }
 }
 
@@ -465,6 +474,18 @@ __global__ void scaled_div_kernel(double w, const double *__restrict__ f, const 
    }
 }
 
+// u_out = u_in + r./d on marked rows, u_out = u_in elsewhere (r may alias u_out)
+__global__ void jacobi_update_kernel(const double *__restrict__ u_in, const double *r, const double *__restrict__ d,
+                                     const int *__restrict__ marker, int mval, double *u_out, size_t n)
+{
+   const size_t stride = (size_t) gridDim.x * blockDim.x;
+   for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+   {
+      const double ui = u_in[i];
+      u_out[i] = (marker == nullptr || mval == 0 || marker[i] == mval) ? ui + r[i] / d[i] : ui;
+   }
+}
+
 // y = x ./ diag ; z += beta * (x ./ diag)     (device_utils.c:2422-2468, NV = 1)
 __global__ void diagscale2_kernel(const double *__restrict__ diag, const double *__restrict__ x, double beta,
                                   double *__restrict__ y, double *__restrict__ z, int computeY, size_t n)
@@ -533,6 +554,47 @@ __global__ void f64_to_f32_kernel(const double *__restrict__ x, float *__restric
    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { y[i] = (float) x[i]; }
 }
 
+// d[i] = first stored entry of row i (the diagonal, by the diagonal-first invariant)
+__global__ void diag_first_kernel(const int *__restrict__ Ai, const double *__restrict__ Aa,
+                                  double *__restrict__ d, int n)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) { d[i] = (Ai[i + 1] > Ai[i]) ? Aa[Ai[i]] : 0.0; }
+}
+
+// Coarsest level (<= a few dozen unknowns): forward elimination / back
+// substitution with the factors of the reference's pivot-free elimination
+// (utilities/gselim.h), one lane, operations in the reference's order and
+// without fused multiply-adds so the result matches the host loop bit for bit.
+__global__ void coarse_solve_kernel(const double *__restrict__ lu, double *__restrict__ x, int n)
+{
+   if (threadIdx.x != 0 || blockIdx.x != 0) { return; }
+   if (n == 1) { if (lu[0] != 0.0) { x[0] = x[0] / lu[0]; } return; }
+   for (int k = 0; k < n - 1; k++)
+   {
+      if (lu[k * n + k] != 0.0)
+      {
+         for (int j = k + 1; j < n; j++)
+         {
+            const double factor = lu[j * n + k];        // multiplier stored below the diagonal
+            if (factor != 0.0) { x[j] = __dsub_rn(x[j], __dmul_rn(factor, x[k])); }
+         }
+      }
+   }
+   for (int k = n - 1; k > 0; --k)
+   {
+      if (lu[k * n + k] != 0.0)
+      {
+         x[k] = x[k] / lu[k * n + k];
+         for (int j = 0; j < k; j++)
+         {
+            if (lu[j * n + k] != 0.0) { x[j] = __dsub_rn(x[j], __dmul_rn(x[k], lu[j * n + k])); }
+         }
+      }
+   }
+   if (lu[0] != 0.0) { x[0] = x[0] / lu[0]; }
+}
+
 static inline int lin_grid(size_t n)
 {
    size_t g = (n + 255) / 256;
@@ -571,6 +633,13 @@ void launch_gather(const double *x, const int *idx, double *out, size_t n, hipSt
 { if (n) hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, out, n); }
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(scatter_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, idx, y, n); }
+void launch_jacobi_update(const double *u_in, const double *r, const double *d, const int *marker, int mval,
+                          double *u_out, size_t n, hipStream_t s)
+{ if (n) hipLaunchKernelGGL(jacobi_update_kernel, dim3(lin_grid(n)), dim3(256), 0, s, u_in, r, d, marker, mval, u_out, n); }
+void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStream_t s)
+{ if (n > 0) hipLaunchKernelGGL(diag_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aa, d, n); }
+void launch_coarse_solve(const double *lu, double *x, int n, hipStream_t s)
+{ if (n > 0) hipLaunchKernelGGL(coarse_solve_kernel, dim3(1), dim3(64), 0, s, lu, x, n); }
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(f64_to_f32_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, y, n); }
 

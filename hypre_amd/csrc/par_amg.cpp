@@ -1,0 +1,251 @@
+// hypre_amd — BoomerAMG solver object: creation, parameters, destruction.
+// Reference: parcsr_ls/par_amg.c:28-520 (defaults at :162-316), HYPRE_parcsr_amg.c.
+#include "amg_internal.hpp"
+
+using namespace hamd;
+
+extern "C" {
+
+static HYPRE_Int amg_setup_thunk(HYPRE_Solver s, void *A, void *b, void *x)
+{
+   return HYPRE_BoomerAMGSetup(s, (HYPRE_ParCSRMatrix) A, (HYPRE_ParVector) b, (HYPRE_ParVector) x);
+}
+static HYPRE_Int amg_solve_thunk(HYPRE_Solver s, void *A, void *b, void *x)
+{
+   return HYPRE_BoomerAMGSolve(s, (HYPRE_ParCSRMatrix) A, (HYPRE_ParVector) b, (HYPRE_ParVector) x);
+}
+
+HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver)
+{
+   if (!solver) { hypre_error_in_arg(1); return hypre_error_flag; }
+   hypre_ParAMGData *d = (hypre_ParAMGData *) calloc(1, sizeof(hypre_ParAMGData));
+   d->base.setup = amg_setup_thunk;
+   d->base.solve = amg_solve_thunk;
+   d->base.destroy = HYPRE_BoomerAMGDestroy;
+   d->memory_location = handle().memory_location;
+   // defaults of par_amg.c:162-316 (host flavour; the driver overrides what it needs)
+   d->max_levels = 25;
+   d->strong_threshold = 0.25;
+   d->max_row_sum = 0.9;
+   d->trunc_factor = 0.0;
+   d->measure_type = 0;
+   d->coarsen_type = 10;
+   d->P_max_elmts = 4;
+   d->interp_type = 6;
+   d->agg_num_levels = 0;
+   d->max_coarse_size = 9;
+   d->min_coarse_size = 0;
+   d->keepTranspose = 1;           // stored P^T: the restriction SpMV never re-transposes
+   d->num_functions = 1;
+   d->max_iter = 20;
+   d->min_iter = 0;
+   d->fcycle = 0;
+   d->cycle_type = 1;
+   d->converge_type = 0;
+   d->tol = 1.0e-6;
+   d->relax_order = 0;
+   d->user_coarse_relax_type = 9;
+   d->user_relax_type = -1;
+   d->user_num_sweeps = -1;
+   d->user_relax_weight = 1.0;
+   d->outer_wt = 1.0;
+   d->num_grid_sweeps = (HYPRE_Int *) calloc(4, sizeof(HYPRE_Int));
+   d->grid_relax_type = (HYPRE_Int *) calloc(4, sizeof(HYPRE_Int));
+   for (int k = 0; k < 4; k++) { d->num_grid_sweeps[k] = 1; }
+   // SetCycleRelaxType(13,1), (14,2), (9,3) on a fresh array initialised to {3,3,3,9}
+   d->grid_relax_type[0] = 3; d->grid_relax_type[1] = 13; d->grid_relax_type[2] = 14; d->grid_relax_type[3] = 9;
+   d->amd_private = new AmgPrivate();
+   *solver = (HYPRE_Solver) d;
+   return hypre_error_flag;
+}
+
+void amg_free_hierarchy(hypre_ParAMGData *d)
+{
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   if (pv) { pv->release_device(); }
+   const int L = d->num_levels;
+   if (d->A_array)
+   {
+      for (int l = 1; l < L; l++) { hypre_ParCSRMatrixDestroy(d->A_array[l]); }
+      free(d->A_array); d->A_array = nullptr;
+   }
+   if (d->P_array)
+   {
+      for (int l = 0; l < L - 1; l++) { hypre_ParCSRMatrixDestroy(d->P_array[l]); }
+      free(d->P_array); d->P_array = nullptr; d->R_array = nullptr;
+   }
+   if (d->F_array)
+   {
+      for (int l = 1; l < L; l++) { hypre_ParVectorDestroy(d->F_array[l]); hypre_ParVectorDestroy(d->U_array[l]); }
+      free(d->F_array); free(d->U_array); d->F_array = d->U_array = nullptr;
+   }
+   if (d->CF_marker_array)
+   {
+      for (int l = 0; l < L; l++) { hypre_IntArrayDestroy(d->CF_marker_array[l]); }
+      free(d->CF_marker_array); d->CF_marker_array = nullptr;
+   }
+   if (d->l1_norms)
+   {
+      for (int l = 0; l < L; l++) { hypre_SeqVectorDestroy(d->l1_norms[l]); }
+      free(d->l1_norms); d->l1_norms = nullptr;
+   }
+   hypre_ParVectorDestroy(d->Vtemp); d->Vtemp = nullptr;
+   hypre_ParVectorDestroy(d->Ztemp); d->Ztemp = nullptr;
+   hypre_ParVectorDestroy(d->Rtemp); d->Rtemp = nullptr;
+   hypre_ParVectorDestroy(d->Ptemp); d->Ptemp = nullptr;
+   free(d->A_mat); d->A_mat = nullptr;
+   free(d->b_vec); d->b_vec = nullptr;
+   free(d->relax_weight); d->relax_weight = nullptr;
+   free(d->omega); d->omega = nullptr;
+   d->num_levels = 0;
+   d->gs_setup = 0;
+}
+
+HYPRE_Int HYPRE_BoomerAMGDestroy(HYPRE_Solver solver)
+{
+   hypre_ParAMGData *d = (hypre_ParAMGData *) solver;
+   if (!d) { return hypre_error_flag; }
+   amg_free_hierarchy(d);
+   delete (AmgPrivate *) d->amd_private;
+   free(d->num_grid_sweeps);
+   free(d->grid_relax_type);
+   if (d->grid_relax_points)
+   {
+      for (int k = 0; k < 4; k++) { free(d->grid_relax_points[k]); }
+      free(d->grid_relax_points);
+   }
+   free(d);
+   return hypre_error_flag;
+}
+
+#define AMG_DATA(solver, d)                                              \
+   hypre_ParAMGData *d = (hypre_ParAMGData *) (solver);                  \
+   if (!d) { hypre_error_in_arg(1); return hypre_error_flag; }
+
+HYPRE_Int HYPRE_BoomerAMGSetMaxLevels(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->max_levels = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetMaxCoarseSize(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->max_coarse_size = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetMinCoarseSize(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; } d->min_coarse_size = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetStrongThreshold(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); if (v < 0 || v > 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->strong_threshold = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetMaxRowSum(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); if (v <= 0 || v > 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->max_row_sum = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetCoarsenType(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->coarsen_type = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetInterpType(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->interp_type = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetTruncFactor(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); if (v < 0 || v >= 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->trunc_factor = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetPMaxElmts(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; } d->P_max_elmts = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->keepTranspose = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetTol(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); if (v < 0 || v > 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->tol = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetMaxIter(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; } d->max_iter = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetMinIter(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->min_iter = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetConvergeType(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->converge_type = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetCycleType(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 1 || v > 2) { hypre_error_in_arg(2); return hypre_error_flag; } d->cycle_type = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetFCycle(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->fcycle = v != 0; return hypre_error_flag; }
+
+// par_amg.c SetNumSweeps: levels 0..2 get num_sweeps, the coarsest gets 1
+HYPRE_Int HYPRE_BoomerAMGSetNumSweeps(HYPRE_Solver s, HYPRE_Int v)
+{
+   AMG_DATA(s, d);
+   if (v < 1) { hypre_error_in_arg(2); return hypre_error_flag; }
+   for (int k = 0; k < 3; k++) { d->num_grid_sweeps[k] = v; }
+   d->num_grid_sweeps[3] = 1;
+   d->user_num_sweeps = v;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_BoomerAMGSetCycleNumSweeps(HYPRE_Solver s, HYPRE_Int v, HYPRE_Int k)
+{
+   AMG_DATA(s, d);
+   if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; }
+   if (k < 1 || k > 3) { hypre_error_in_arg(3); return hypre_error_flag; }
+   d->num_grid_sweeps[k] = v;
+   return hypre_error_flag;
+}
+// par_amg.c SetRelaxType: down/up/"fine" get relax_type, the coarsest is reset to 9
+HYPRE_Int HYPRE_BoomerAMGSetRelaxType(HYPRE_Solver s, HYPRE_Int v)
+{
+   AMG_DATA(s, d);
+   if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; }
+   for (int k = 0; k < 3; k++) { d->grid_relax_type[k] = v; }
+   d->grid_relax_type[3] = 9;
+   d->user_coarse_relax_type = 9;
+   d->user_relax_type = v;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver s, HYPRE_Int v, HYPRE_Int k)
+{
+   AMG_DATA(s, d);
+   if (k < 1 || k > 3) { hypre_error_in_arg(3); return hypre_error_flag; }
+   if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; }
+   d->grid_relax_type[k] = v;
+   if (k == 3) { d->user_coarse_relax_type = v; }
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_BoomerAMGSetRelaxOrder(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->relax_order = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetRelaxWt(HYPRE_Solver s, HYPRE_Real v) { AMG_DATA(s, d); d->user_relax_weight = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetOuterWt(HYPRE_Solver s, HYPRE_Real v) { AMG_DATA(s, d); d->outer_wt = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetPrintLevel(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->print_level = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetLogging(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->logging = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver s, HYPRE_Int *v)
+{ AMG_DATA(s, d); *v = d->num_iterations; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v)
+{ AMG_DATA(s, d); *v = d->rel_resid_norm; return hypre_error_flag; }
+
+HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver s, HYPRE_MemoryLocation loc)
+{ AMG_DATA(s, d); d->memory_location = loc; return hypre_error_flag; }
+HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver s, HYPRE_Int n)
+{ AMG_DATA(s, d); ((AmgPrivate *) d->amd_private)->emulated_threads = n < 1 ? 1 : n; return hypre_error_flag; }
+HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver s, HYPRE_Int on)
+{ AMG_DATA(s, d); ((AmgPrivate *) d->amd_private)->mixed_precision = on != 0; return hypre_error_flag; }
+
+HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver s, HYPRE_Real *grid, HYPRE_Real *op)
+{
+   AMG_DATA(s, d);
+   double rows = 0, nnz = 0;
+   for (int l = 0; l < d->num_levels; l++)
+   {
+      rows += (double) d->A_array[l]->global_num_rows;
+      nnz += d->A_array[l]->d_num_nonzeros;
+   }
+   if (d->num_levels > 0)
+   {
+      if (grid) { *grid = rows / (double) d->A_array[0]->global_num_rows; }
+      if (op) { *op = nnz / d->A_array[0]->d_num_nonzeros; }
+   }
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_amd_BoomerAMGGetNumLevels(HYPRE_Solver s) { return s ? ((hypre_ParAMGData *) s)->num_levels : 0; }
+hypre_ParCSRMatrix *hypre_amd_BoomerAMGGetA(HYPRE_Solver s, HYPRE_Int l)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && l >= 0 && l < d->num_levels) ? d->A_array[l] : nullptr; }
+hypre_ParCSRMatrix *hypre_amd_BoomerAMGGetP(HYPRE_Solver s, HYPRE_Int l)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && l >= 0 && l < d->num_levels - 1) ? d->P_array[l] : nullptr; }
+hypre_IntArray *hypre_amd_BoomerAMGGetCFMarker(HYPRE_Solver s, HYPRE_Int l)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && d->CF_marker_array && l >= 0 && l < d->num_levels) ? d->CF_marker_array[l] : nullptr; }
+hypre_Vector *hypre_amd_BoomerAMGGetL1Norms(HYPRE_Solver s, HYPRE_Int l)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && d->l1_norms && l >= 0 && l < d->num_levels) ? d->l1_norms[l] : nullptr; }
+HYPRE_Int hypre_amd_BoomerAMGGetGridRelaxType(HYPRE_Solver s, HYPRE_Int k) { return ((hypre_ParAMGData *) s)->grid_relax_type[k]; }
+HYPRE_Int hypre_amd_BoomerAMGGetNumGridSweeps(HYPRE_Solver s, HYPRE_Int k) { return ((hypre_ParAMGData *) s)->num_grid_sweeps[k]; }
+
+HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   if (!A) { hypre_error_in_arg(2); return hypre_error_flag; }
+   return hypre_BoomerAMGSetup((void *) solver, A, b, x);
+}
+
+// HYPRE_parcsr_amg.c:64-91
+HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   if (!A) { hypre_error_in_arg(2); return hypre_error_flag; }
+   if (!b) { hypre_error_in_arg(3); return hypre_error_flag; }
+   if (!x) { hypre_error_in_arg(4); return hypre_error_flag; }
+   return hypre_BoomerAMGSolve((void *) solver, A, b, x);
+}
+
+}  // extern "C"

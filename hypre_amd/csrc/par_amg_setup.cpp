@@ -1,0 +1,1381 @@
+// hypre_amd — BoomerAMG setup (hierarchy construction) on the host.
+//
+// The solve phase is the GPU hot path; this file is the step before it (scope
+// table row "next"): it exists so that a 256^3 hierarchy can be produced where
+// the benchmark runs.  Every algorithm follows the reference's host code in
+// loop order and tie-breaking so that hierarchies (and therefore iteration
+// counts and complexities) match the reference driver's on the same input:
+//   parcsr_ls/par_strength.c:75-530        classical strength of connection
+//   parcsr_ls/par_coarsen.c:2101-2810      PMIS (measures, independent sets)
+//   parcsr_ls/par_coarsen.c:911-1400       Ruge-Stueben first pass (HMIS = RS pass + PMIS)
+//   parcsr_ls/par_indepset.c               random tie-breakers (utilities/random.c LCG)
+//   parcsr_ls/par_coarse_parms.c           coarse numbering
+//   parcsr_ls/par_lr_interp.c:1024-1700    extended+i interpolation
+//   parcsr_mv/par_csr_matrix.c:2874-3400   truncation of P (max elements / threshold, rescaled)
+//   parcsr_ls/par_rap.c:30-2000            Galerkin product RAP
+//   parcsr_ls/ams.c:527-830                smoother diagonals
+//   parcsr_ls/par_gauss_elim.c:25-300      dense coarsest-level operator
+//   parcsr_ls/par_amg_setup.c:28-3560      level loop, stopping rules, work vectors
+//
+// Rows are processed in parallel with OpenMP where every row's result is
+// independent of the others (strength, interpolation, RAP); the per-row
+// arithmetic and entry order are those of the sequential reference loops.
+#include "amg_internal.hpp"
+#include <algorithm>
+#include <cmath>
+#include <omp.h>
+
+using namespace hamd;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// host halo helpers over a comm package
+// ---------------------------------------------------------------------------
+template <class T> struct HaloJob;
+template <> struct HaloJob<double>       { static const int fwd = 1,  rev = 2; };
+template <> struct HaloJob<HYPRE_Int>    { static const int fwd = 11, rev = 12; };
+template <> struct HaloJob<HYPRE_BigInt> { static const int fwd = 21, rev = 22; };
+
+// owner values -> ghost array (offd column order)
+template <class T>
+void halo_forward(hypre_ParCSRCommPkg *pkg, const T *local, T *ghost)
+{
+   if (!pkg) { return; }
+   const HYPRE_Int tot = pkg->send_map_starts[pkg->num_sends];
+   std::vector<T> buf((size_t) std::max(tot, 1));
+   for (HYPRE_Int k = 0; k < tot; k++) { buf[(size_t) k] = local[pkg->send_map_elmts[k]]; }
+   hypre_ParCSRCommHandle *h = hypre_ParCSRCommHandleCreate(HaloJob<T>::fwd, pkg, buf.data(), ghost);
+   hypre_ParCSRCommHandleDestroy(h);
+}
+// ghost values -> owners' buffer laid out like send_map_elmts
+template <class T>
+void halo_reverse(hypre_ParCSRCommPkg *pkg, const T *ghost, T *buf)
+{
+   if (!pkg) { return; }
+   hypre_ParCSRCommHandle *h = hypre_ParCSRCommHandleCreate(HaloJob<T>::rev, pkg, (void *) ghost, buf);
+   hypre_ParCSRCommHandleDestroy(h);
+}
+
+int comm_size(MPI_Comm c) { HYPRE_Int n; hypre_MPI_Comm_size(c, &n); return n; }
+int comm_rank(MPI_Comm c) { HYPRE_Int r; hypre_MPI_Comm_rank(c, &r); return r; }
+
+HYPRE_BigInt global_sum_big(MPI_Comm comm, HYPRE_BigInt v)
+{
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   if (o && o->size > 1)
+   {
+      double d = (double) v;
+      o->allreduce_sum(o->ctx, &d, 1, 0, nullptr);
+      return (HYPRE_BigInt) llround(d);
+   }
+   return v;
+}
+
+// utilities/random.c: Park-Miller minimal standard generator
+struct HypreRand
+{
+   HYPRE_Int seed = 13579;
+   void reseed(HYPRE_Int s)
+   {
+      const HYPRE_Int m = 2147483647;
+      if (s < 1) { s = 1; } else if (s >= m) { s = m - 1; }
+      seed = s;
+   }
+   double next()
+   {
+      const HYPRE_Int a = 16807, m = 2147483647, q = 127773, r = 2836;
+      const HYPRE_Int high = seed / q, low = seed % q;
+      const HYPRE_Int test = a * low - r * high;
+      seed = test > 0 ? test : test + m;
+      return (double) seed / (double) m;
+   }
+};
+
+inline int num_threads_avail() { return omp_get_max_threads(); }
+
+// contiguous row chunk of thread t out of T
+inline void chunk(int n, int T, int t, int *b, int *e)
+{
+   const long long per = n / T, rest = n % T;
+   *b = (int) (t * per + std::min<long long>(t, rest));
+   *e = (int) (*b + per + (t < rest ? 1 : 0));
+}
+
+}  // namespace
+
+extern "C" {
+
+// ===========================================================================
+// strength of connection (par_strength.c:75-530, num_functions == 1)
+// S keeps, per row and in A's stored order, the off-diagonal columns j with
+//   a_ij < theta * min_k a_ik   (a_ii >= 0)   or   a_ij > theta * max_k a_ik   (a_ii < 0);
+// rows whose |row sum| exceeds max_row_sum*|a_ii| keep nothing.
+// ===========================================================================
+HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_Real max_row_sum,
+                                 HYPRE_Int num_functions, HYPRE_Int *dof_func, hypre_ParCSRMatrix **S_ptr)
+{
+   (void) dof_func;
+   if (num_functions > 1)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCreateS: systems (num_functions > 1) are out of scope");
+      return hypre_error_flag;
+   }
+   hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
+   const HYPRE_Int n = Ad->num_rows;
+   const HYPRE_Int nco = Ao->num_cols;
+   const HYPRE_Int *Adi = Ad->i, *Adj = Ad->j, *Aoi = Ao->i, *Aoj = Ao->j;
+   const HYPRE_Real *Ada = Ad->data, *Aoa = Ao->data;
+
+   hypre_ParCSRMatrix *S = hypre_ParCSRMatrixCreate(A->comm, A->global_num_rows, A->global_num_rows,
+                                                    A->row_starts, A->row_starts, nco, 0, 0);
+   std::vector<HYPRE_Int> sdi((size_t) n + 1, 0), soi((size_t) n + 1, 0);
+   // pass 1: per-row counts, pass 2: fill (both row-parallel)
+   std::vector<char> keep_d((size_t) Adi[n]), keep_o((size_t) Aoi[n]);
+#pragma omp parallel for schedule(static)
+   for (HYPRE_Int i = 0; i < n; i++)
+   {
+      const HYPRE_Real diag = Ada[Adi[i]];
+      HYPRE_Real row_scale = 0.0, row_sum = diag;
+      if (diag < 0)
+      {
+         for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { row_scale = std::max(row_scale, Ada[k]); row_sum += Ada[k]; }
+         for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { row_scale = std::max(row_scale, Aoa[k]); row_sum += Aoa[k]; }
+      }
+      else
+      {
+         for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { row_scale = std::min(row_scale, Ada[k]); row_sum += Ada[k]; }
+         for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { row_scale = std::min(row_scale, Aoa[k]); row_sum += Aoa[k]; }
+      }
+      HYPRE_Int cd = 0, co = 0;
+      if (Adi[i + 1] > Adi[i]) { keep_d[(size_t) Adi[i]] = 0; }
+      const bool all_weak = (std::fabs(row_sum) > std::fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
+      for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++)
+      {
+         bool strong = false;
+         if (!all_weak) { strong = diag < 0 ? !(Ada[k] <= theta * row_scale) : !(Ada[k] >= theta * row_scale); }
+         keep_d[(size_t) k] = strong; cd += strong;
+      }
+      for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++)
+      {
+         bool strong = false;
+         if (!all_weak) { strong = diag < 0 ? !(Aoa[k] <= theta * row_scale) : !(Aoa[k] >= theta * row_scale); }
+         keep_o[(size_t) k] = strong; co += strong;
+      }
+      sdi[(size_t) i + 1] = cd; soi[(size_t) i + 1] = co;
+   }
+   for (HYPRE_Int i = 0; i < n; i++) { sdi[(size_t) i + 1] += sdi[(size_t) i]; soi[(size_t) i + 1] += soi[(size_t) i]; }
+   hypre_CSRMatrix *Sd = S->diag, *So = S->offd;
+   Sd->num_nonzeros = sdi[(size_t) n]; So->num_nonzeros = soi[(size_t) n];
+   Sd->memory_location = So->memory_location = HYPRE_MEMORY_HOST;
+   Sd->i = hypre_TAlloc(HYPRE_Int, n + 1, HYPRE_MEMORY_HOST);
+   So->i = hypre_TAlloc(HYPRE_Int, n + 1, HYPRE_MEMORY_HOST);
+   Sd->j = hypre_TAlloc(HYPRE_Int, std::max(Sd->num_nonzeros, 1), HYPRE_MEMORY_HOST);
+   So->j = hypre_TAlloc(HYPRE_Int, std::max(So->num_nonzeros, 1), HYPRE_MEMORY_HOST);
+   memcpy(Sd->i, sdi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+   memcpy(So->i, soi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+#pragma omp parallel for schedule(static)
+   for (HYPRE_Int i = 0; i < n; i++)
+   {
+      HYPRE_Int p = sdi[(size_t) i];
+      for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { if (keep_d[(size_t) k]) { Sd->j[p++] = Adj[k]; } }
+      p = soi[(size_t) i];
+      for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { if (keep_o[(size_t) k]) { So->j[p++] = Aoj[k]; } }
+   }
+   if (nco)
+   {
+      S->col_map_offd = hypre_TAlloc(HYPRE_BigInt, nco, HYPRE_MEMORY_HOST);
+      memcpy(S->col_map_offd, A->col_map_offd, sizeof(HYPRE_BigInt) * (size_t) nco);
+   }
+   *S_ptr = S;
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// PMIS (par_coarsen.c:2101-2810).  CF_init: 0 plain, 1 second stage of HMIS
+// (markers pre-set by the RS pass), 2 sequential random numbers ("pmis1").
+// ===========================================================================
+static const int C_PT = 1, F_PT = -1, SF_PT = -3, Z_PT = -2, SC_PT = 3, UNDECIDED = -9999;
+
+HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *A, HYPRE_Int CF_init,
+                                     HYPRE_Int debug_flag, hypre_IntArray **CF_marker_ptr)
+{
+   (void) debug_flag;
+   MPI_Comm comm = S->comm;
+   const int nprocs = comm_size(comm), my_id = comm_rank(comm);
+   hypre_CSRMatrix *Sd = S->diag, *So = S->offd;
+   const HYPRE_Int n = Sd->num_rows, nco = So->num_cols;
+   const HYPRE_Int *Sdi = Sd->i, *Sdj = Sd->j, *Soi = So->i, *Soj = So->j;
+   hypre_ParCSRCommPkg *pkg = nullptr;
+   if (nprocs > 1)
+   {
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      pkg = A->comm_pkg;
+   }
+   const HYPRE_Int tot_send = pkg ? pkg->send_map_starts[pkg->num_sends] : 0;
+   std::vector<HYPRE_Int> int_buf((size_t) std::max(tot_send, 1));
+   std::vector<double> buf((size_t) std::max(tot_send, 1));
+
+   // measure = number of points a point influences (column sums of S) + random in (0,1]
+   std::vector<double> measure((size_t) n + nco, 0.0);
+   for (HYPRE_Int k = 0; k < Soi[n]; k++) { measure[(size_t) n + Soj[k]] += 1.0; }
+   if (pkg) { halo_reverse<double>(pkg, measure.data() + n, buf.data()); }
+   for (HYPRE_Int k = 0; k < Sdi[n]; k++) { measure[(size_t) Sdj[k]] += 1.0; }
+   for (HYPRE_Int k = 0; k < tot_send; k++) { measure[(size_t) pkg->send_map_elmts[k]] += buf[(size_t) k]; }
+   for (HYPRE_Int k = n; k < n + nco; k++) { measure[(size_t) k] = 0; }
+   {
+      // par_indepset.c: seed 2747+rank, or one global stream when seq_rand
+      HypreRand rng;
+      const bool seq_rand = (CF_init == 2 || CF_init == 4);
+      rng.reseed(seq_rand ? 2747 : 2747 + my_id);
+      if (seq_rand) { for (HYPRE_BigInt q = 0; q < S->first_row_index; q++) { rng.next(); } }
+      for (HYPRE_Int i = 0; i < n; i++) { measure[(size_t) i] += rng.next(); }
+   }
+
+   std::vector<HYPRE_Int> graph((size_t) std::max(n, 1)), graph2((size_t) std::max(n, 1));
+   std::vector<HYPRE_Int> graph_offd((size_t) std::max(nco, 1)), graph_offd2((size_t) std::max(nco, 1));
+   for (HYPRE_Int k = 0; k < nco; k++) { graph_offd[(size_t) k] = k; }
+   HYPRE_Int graph_offd_size = nco;
+
+   if (*CF_marker_ptr == nullptr)
+   {
+      *CF_marker_ptr = hypre_IntArrayCreate(n);
+      hypre_IntArrayInitialize_v2(*CF_marker_ptr, HYPRE_MEMORY_HOST);
+   }
+   HYPRE_Int *CF = (*CF_marker_ptr)->data;
+   HYPRE_Int cnt = 0;
+   if (CF_init == 1)
+   {
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         if (CF[i] != SF_PT)
+         {
+            if (Soi[i + 1] - Soi[i] > 0 || CF[i] == -1) { CF[i] = 0; }
+            if (CF[i] == Z_PT)
+            {
+               if (measure[(size_t) i] >= 1.0 || Sdi[i + 1] - Sdi[i] > 0) { CF[i] = 0; graph[(size_t) cnt++] = i; }
+               else { CF[i] = F_PT; }
+            }
+            else { graph[(size_t) cnt++] = i; }
+         }
+         else { measure[(size_t) i] = 0; }
+      }
+   }
+   else
+   {
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         CF[i] = 0;
+         const HYPRE_Int nnzrow = (Sdi[i + 1] - Sdi[i]) + (Soi[i + 1] - Soi[i]);
+         if (nnzrow == 0)
+         {
+            CF[i] = SF_PT;
+            if (CF_init == 3 || CF_init == 4) { CF[i] = C_PT; }
+            measure[(size_t) i] = 0;
+         }
+         else { graph[(size_t) cnt++] = i; }
+      }
+   }
+   HYPRE_Int graph_size = cnt;
+   std::vector<HYPRE_Int> CF_offd((size_t) std::max(nco, 1), 0);
+   if (pkg) { halo_forward<double>(pkg, measure.data(), measure.data() + n); }
+
+   HYPRE_Int iter = 0;
+   while (true)
+   {
+      if (global_sum_big(comm, graph_size) == 0) { break; }
+      if (!CF_init || iter)
+      {
+         for (HYPRE_Int ig = 0; ig < graph_size; ig++)
+         {
+            const HYPRE_Int i = graph[(size_t) ig];
+            if (measure[(size_t) i] > 1) { CF[i] = 1; }
+         }
+         for (HYPRE_Int ig = 0; ig < graph_offd_size; ig++)
+         {
+            const HYPRE_Int i = graph_offd[(size_t) ig];
+            if (measure[(size_t) i + n] > 1) { CF_offd[(size_t) i] = 1; }
+         }
+         // knock the smaller of two strongly connected candidates out of the set
+         for (HYPRE_Int ig = 0; ig < graph_size; ig++)
+         {
+            const HYPRE_Int i = graph[(size_t) ig];
+            if (measure[(size_t) i] > 1)
+            {
+               for (HYPRE_Int jS = Sdi[i]; jS < Sdi[i + 1]; jS++)
+               {
+                  const HYPRE_Int j = Sdj[jS];
+                  if (measure[(size_t) j] > 1)
+                  {
+                     if (measure[(size_t) i] > measure[(size_t) j]) { CF[j] = 0; }
+                     else if (measure[(size_t) j] > measure[(size_t) i]) { CF[i] = 0; }
+                  }
+               }
+               for (HYPRE_Int jS = Soi[i]; jS < Soi[i + 1]; jS++)
+               {
+                  const HYPRE_Int jj = Soj[jS];
+                  const HYPRE_Int j = n + jj;
+                  if (measure[(size_t) j] > 1)
+                  {
+                     if (measure[(size_t) i] > measure[(size_t) j]) { CF_offd[(size_t) jj] = 0; }
+                     else if (measure[(size_t) j] > measure[(size_t) i]) { CF[i] = 0; }
+                  }
+               }
+            }
+         }
+         if (pkg)
+         {
+            halo_reverse<HYPRE_Int>(pkg, CF_offd.data(), int_buf.data());
+            for (HYPRE_Int k = 0; k < tot_send; k++)
+            {
+               const HYPRE_Int elmt = pkg->send_map_elmts[k];
+               if (!int_buf[(size_t) k] && CF[elmt] > 0) { CF[elmt] = 0; }
+               else { int_buf[(size_t) k] = CF[elmt]; }
+            }
+            hypre_ParCSRCommHandle *h = hypre_ParCSRCommHandleCreate(11, pkg, int_buf.data(), CF_offd.data());
+            hypre_ParCSRCommHandleDestroy(h);
+         }
+      }
+      iter++;
+      for (HYPRE_Int ig = 0; ig < graph_size; ig++)
+      {
+         const HYPRE_Int i = graph[(size_t) ig];
+         if (measure[(size_t) i] < 1) { CF[i] = F_PT; }
+         if (CF[i] > 0) { CF[i] = C_PT; }
+         else
+         {
+            for (HYPRE_Int jS = Sdi[i]; jS < Sdi[i + 1]; jS++) { if (CF[Sdj[jS]] > 0) { CF[i] = F_PT; } }
+            for (HYPRE_Int jS = Soi[i]; jS < Soi[i + 1]; jS++) { if (CF_offd[(size_t) Soj[jS]] > 0) { CF[i] = F_PT; } }
+         }
+      }
+      if (pkg) { halo_forward<HYPRE_Int>(pkg, CF, CF_offd.data()); }
+      HYPRE_Int g2 = 0, go2 = 0;
+      for (HYPRE_Int ig = 0; ig < graph_size; ig++)
+      {
+         const HYPRE_Int i = graph[(size_t) ig];
+         if (CF[i] != 0) { measure[(size_t) i] = 0; } else { graph2[(size_t) g2++] = i; }
+      }
+      for (HYPRE_Int ig = 0; ig < graph_offd_size; ig++)
+      {
+         const HYPRE_Int i = graph_offd[(size_t) ig];
+         if (CF_offd[(size_t) i] != 0) { measure[(size_t) i + n] = 0; } else { graph_offd2[(size_t) go2++] = i; }
+      }
+      graph.swap(graph2); graph_offd.swap(graph_offd2);
+      graph_size = g2; graph_offd_size = go2;
+   }
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// Ruge-Stueben first pass on the local graph (par_coarsen.c:911-1400 with
+// coarsen_type 10 -> 11, measure_type 0), then PMIS on what it leaves.
+// The bucket structure reproduces the reference's list-of-lists: one FIFO
+// per measure value; the head of the highest non-empty list is picked.
+// ===========================================================================
+namespace {
+struct Buckets
+{
+   std::vector<int> head, tail, next, prev, where_meas;
+   int max_meas = 0;
+   explicit Buckets(int n, int maxm) : head((size_t) maxm + 2, -1), tail((size_t) maxm + 2, -1),
+      next((size_t) std::max(n, 1), -1), prev((size_t) std::max(n, 1), -1), where_meas((size_t) std::max(n, 1), -1) {}
+   void grow(int m) { if ((size_t) m + 2 > head.size()) { head.resize((size_t) m + 2, -1); tail.resize((size_t) m + 2, -1); } }
+   void enter(int m, int i)
+   {
+      grow(m);
+      next[(size_t) i] = -1; prev[(size_t) i] = tail[(size_t) m];
+      if (tail[(size_t) m] >= 0) { next[(size_t) tail[(size_t) m]] = i; } else { head[(size_t) m] = i; }
+      tail[(size_t) m] = i;
+      where_meas[(size_t) i] = m;
+      if (m > max_meas) { max_meas = m; }
+   }
+   void remove(int m, int i)
+   {
+      const int p = prev[(size_t) i], q = next[(size_t) i];
+      if (p >= 0) { next[(size_t) p] = q; } else { head[(size_t) m] = q; }
+      if (q >= 0) { prev[(size_t) q] = p; } else { tail[(size_t) m] = p; }
+      where_meas[(size_t) i] = -1;
+   }
+   int top()
+   {
+      while (max_meas > 0 && head[(size_t) max_meas] < 0) { max_meas--; }
+      return head[(size_t) max_meas];
+   }
+};
+}  // namespace
+
+static void ruge_first_pass(hypre_ParCSRMatrix *S, HYPRE_Int *CF)
+{
+   hypre_CSRMatrix *Sd = S->diag, *So = S->offd;
+   const HYPRE_Int n = Sd->num_rows;
+   const HYPRE_Int *Si = Sd->i, *Sj = Sd->j, *Soi = So->i;
+   const HYPRE_Int nS = Si[n];
+   // S^T by counting sort (rows in ascending source order)
+   std::vector<HYPRE_Int> STi((size_t) n + 1, 0), STj((size_t) std::max(nS, 1));
+   for (HYPRE_Int k = 0; k < nS; k++) { STi[(size_t) Sj[k] + 1]++; }
+   for (HYPRE_Int i = 0; i < n; i++) { STi[(size_t) i + 1] += STi[(size_t) i]; }
+   {
+      std::vector<HYPRE_Int> pos(STi.begin(), STi.end() - 1);
+      for (HYPRE_Int i = 0; i < n; i++) { for (HYPRE_Int k = Si[i]; k < Si[i + 1]; k++) { STj[(size_t) pos[(size_t) Sj[k]]++] = i; } }
+   }
+   std::vector<HYPRE_Int> meas((size_t) std::max(n, 1));
+   HYPRE_Int maxm = 0;
+   for (HYPRE_Int i = 0; i < n; i++) { meas[(size_t) i] = STi[(size_t) i + 1] - STi[(size_t) i]; maxm = std::max(maxm, meas[(size_t) i]); }
+   const int f_pnt = Z_PT;
+   HYPRE_Int num_left = 0;
+   for (HYPRE_Int j = 0; j < n; j++)
+   {
+      if (CF[j] == 0)
+      {
+         const HYPRE_Int nnzrow = (Si[j + 1] - Si[j]) + (Soi[j + 1] - Soi[j]);
+         if (nnzrow == 0) { CF[j] = SF_PT; meas[(size_t) j] = 0; }
+         else { CF[j] = UNDECIDED; num_left++; }
+      }
+      else { meas[(size_t) j] = 0; }
+   }
+   Buckets B(n, 2 * maxm + 2);
+   for (HYPRE_Int j = 0; j < n; j++)
+   {
+      const HYPRE_Int measure = meas[(size_t) j];
+      if (CF[j] != SF_PT && CF[j] != SC_PT)
+      {
+         if (measure > 0) { B.enter(measure, j); }
+         else
+         {
+            CF[j] = f_pnt;
+            for (HYPRE_Int k = Si[j]; k < Si[j + 1]; k++)
+            {
+               const HYPRE_Int nabor = Sj[k];
+               if (CF[nabor] != SF_PT && CF[nabor] != SC_PT)
+               {
+                  if (nabor < j)
+                  {
+                     HYPRE_Int nm = meas[(size_t) nabor];
+                     if (nm > 0) { B.remove(nm, nabor); }
+                     nm = ++meas[(size_t) nabor];
+                     B.enter(nm, nabor);
+                  }
+                  else { ++meas[(size_t) nabor]; }
+               }
+            }
+            --num_left;
+         }
+      }
+   }
+   while (num_left > 0)
+   {
+      const HYPRE_Int index = B.top();
+      CF[index] = C_PT;
+      HYPRE_Int measure = meas[(size_t) index];
+      meas[(size_t) index] = 0;
+      --num_left;
+      B.remove(measure, index);
+      for (HYPRE_Int j = STi[(size_t) index]; j < STi[(size_t) index + 1]; j++)
+      {
+         const HYPRE_Int nabor = STj[(size_t) j];
+         if (CF[nabor] == UNDECIDED)
+         {
+            CF[nabor] = F_PT;
+            B.remove(meas[(size_t) nabor], nabor);
+            --num_left;
+            for (HYPRE_Int k = Si[nabor]; k < Si[nabor + 1]; k++)
+            {
+               const HYPRE_Int n2 = Sj[k];
+               if (CF[n2] == UNDECIDED)
+               {
+                  B.remove(meas[(size_t) n2], n2);
+                  const HYPRE_Int nm = ++meas[(size_t) n2];
+                  B.enter(nm, n2);
+               }
+            }
+         }
+      }
+      for (HYPRE_Int j = Si[index]; j < Si[index + 1]; j++)
+      {
+         const HYPRE_Int nabor = Sj[j];
+         if (CF[nabor] == UNDECIDED)
+         {
+            measure = meas[(size_t) nabor];
+            B.remove(measure, nabor);
+            meas[(size_t) nabor] = --measure;
+            if (measure > 0) { B.enter(measure, nabor); }
+            else
+            {
+               CF[nabor] = F_PT;
+               --num_left;
+               for (HYPRE_Int k = Si[nabor]; k < Si[nabor + 1]; k++)
+               {
+                  const HYPRE_Int n2 = Sj[k];
+                  if (CF[n2] == UNDECIDED)
+                  {
+                     B.remove(meas[(size_t) n2], n2);
+                     const HYPRE_Int nm = ++meas[(size_t) n2];
+                     B.enter(nm, n2);
+                  }
+               }
+            }
+         }
+      }
+   }
+   for (HYPRE_Int i = 0; i < n; i++) { if (CF[i] == SC_PT) { CF[i] = C_PT; } }
+}
+
+HYPRE_Int hypre_BoomerAMGCoarsenHMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *A, HYPRE_Int measure_type,
+                                     HYPRE_Int cut_factor, HYPRE_Int debug_flag, hypre_IntArray **CF_marker_ptr)
+{
+   (void) measure_type; (void) cut_factor;
+   const HYPRE_Int n = S->diag->num_rows;
+   if (*CF_marker_ptr == nullptr)
+   {
+      *CF_marker_ptr = hypre_IntArrayCreate(n);
+      hypre_IntArrayInitialize_v2(*CF_marker_ptr, HYPRE_MEMORY_HOST);
+   }
+   ruge_first_pass(S, (*CF_marker_ptr)->data);
+   return hypre_BoomerAMGCoarsenPMIS(S, A, 1, debug_flag, CF_marker_ptr);
+}
+
+// par_coarse_parms.c: this rank's coarse range [first, first + local)
+static void coarse_parms(MPI_Comm comm, HYPRE_Int n, const HYPRE_Int *CF, HYPRE_BigInt *cpts_global,
+                         HYPRE_BigInt *total)
+{
+   HYPRE_BigInt local = 0;
+   for (HYPRE_Int i = 0; i < n; i++) { if (CF[i] == 1) { local++; } }
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   if (o && o->size > 1)
+   {
+      std::vector<HYPRE_BigInt> all((size_t) o->size);
+      o->allgather(o->ctx, &local, all.data(), sizeof(HYPRE_BigInt));
+      HYPRE_BigInt first = 0, tot = 0;
+      for (int r = 0; r < o->size; r++) { if (r < o->rank) { first += all[(size_t) r]; } tot += all[(size_t) r]; }
+      cpts_global[0] = first; cpts_global[1] = first + local; *total = tot;
+   }
+   else { cpts_global[0] = 0; cpts_global[1] = local; *total = local; }
+}
+
+// ===========================================================================
+// truncation of P (par_csr_matrix.c:2874-3400 with rescale = 1, inf-norm)
+// ===========================================================================
+static void qsort2_abs(HYPRE_Int *v, HYPRE_Real *w, HYPRE_Int left, HYPRE_Int right)
+{
+   // utilities/qsort.c:395-417 (decreasing |w|; tie order is part of the contract)
+   if (left >= right) { return; }
+   std::swap(v[left], v[(left + right) / 2]); std::swap(w[left], w[(left + right) / 2]);
+   HYPRE_Int last = left;
+   for (HYPRE_Int i = left + 1; i <= right; i++)
+   {
+      if (std::fabs(w[i]) > std::fabs(w[left])) { ++last; std::swap(v[last], v[i]); std::swap(w[last], w[i]); }
+   }
+   std::swap(v[left], v[last]); std::swap(w[left], w[last]);
+   qsort2_abs(v, w, left, last - 1);
+   qsort2_abs(v, w, last + 1, right);
+}
+
+HYPRE_Int hypre_BoomerAMGInterpTruncation(hypre_ParCSRMatrix *P, HYPRE_Real tol, HYPRE_Int max_elmts)
+{
+   if (tol <= 0.0 && max_elmts == 0) { return hypre_error_flag; }
+   hypre_CSRMatrix *Pd = P->diag, *Po = P->offd;
+   const HYPRE_Int n = Pd->num_rows, ncols = Pd->num_cols;
+   std::vector<HYPRE_Int> ndi((size_t) n + 1, 0), noi((size_t) n + 1, 0);
+   // rows are independent: rewrite every row in place (rows only shrink), then compact
+   std::vector<HYPRE_Int> cntd((size_t) std::max(n, 1)), cnto((size_t) std::max(n, 1));
+#pragma omp parallel
+   {
+      std::vector<HYPRE_Int> aj;
+      std::vector<HYPRE_Real> aa;
+#pragma omp for schedule(static)
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         HYPRE_Int d0 = Pd->i[i], d1 = Pd->i[i + 1], o0 = Po->i[i], o1 = Po->i[i + 1];
+         if (tol > 0)
+         {
+            HYPRE_Real row_nrm = 0;
+            for (HYPRE_Int k = d0; k < d1; k++) { row_nrm = std::max(row_nrm, std::fabs(Pd->data[k])); }
+            for (HYPRE_Int k = o0; k < o1; k++) { row_nrm = std::max(row_nrm, std::fabs(Po->data[k])); }
+            const HYPRE_Real drop = tol * row_nrm;
+            HYPRE_Real row_sum = 0, scale = 0;
+            HYPRE_Int w = d0;
+            for (HYPRE_Int k = d0; k < d1; k++)
+            {
+               row_sum += Pd->data[k];
+               if (!(std::fabs(Pd->data[k]) < drop)) { scale += Pd->data[k]; Pd->data[w] = Pd->data[k]; Pd->j[w] = Pd->j[k]; w++; }
+            }
+            d1 = w; w = o0;
+            for (HYPRE_Int k = o0; k < o1; k++)
+            {
+               row_sum += Po->data[k];
+               if (!(std::fabs(Po->data[k]) < drop)) { scale += Po->data[k]; Po->data[w] = Po->data[k]; Po->j[w] = Po->j[k]; w++; }
+            }
+            o1 = w;
+            if (scale != 0. && scale != row_sum)
+            {
+               scale = row_sum / scale;
+               for (HYPRE_Int k = d0; k < d1; k++) { Pd->data[k] *= scale; }
+               for (HYPRE_Int k = o0; k < o1; k++) { Po->data[k] *= scale; }
+            }
+         }
+         const HYPRE_Int num = (d1 - d0) + (o1 - o0);
+         if (max_elmts > 0 && max_elmts < num)
+         {
+            aj.resize((size_t) num); aa.resize((size_t) num);
+            HYPRE_Int c = 0;
+            HYPRE_Real row_sum = 0;
+            for (HYPRE_Int k = d0; k < d1; k++) { aj[(size_t) c] = Pd->j[k]; aa[(size_t) c++] = Pd->data[k]; row_sum += Pd->data[k]; }
+            for (HYPRE_Int k = o0; k < o1; k++) { aj[(size_t) c] = Po->j[k] + ncols; aa[(size_t) c++] = Po->data[k]; row_sum += Po->data[k]; }
+            qsort2_abs(aj.data(), aa.data(), 0, c - 1);
+            HYPRE_Real scale = 0;
+            HYPRE_Int wd = d0, wo = o0;
+            for (HYPRE_Int k = 0; k < max_elmts; k++)
+            {
+               scale += aa[(size_t) k];
+               if (aj[(size_t) k] < ncols) { Pd->j[wd] = aj[(size_t) k]; Pd->data[wd++] = aa[(size_t) k]; }
+               else { Po->j[wo] = aj[(size_t) k] - ncols; Po->data[wo++] = aa[(size_t) k]; }
+            }
+            d1 = wd; o1 = wo;
+            if (scale != 0. && scale != row_sum)
+            {
+               scale = row_sum / scale;
+               for (HYPRE_Int k = d0; k < d1; k++) { Pd->data[k] *= scale; }
+               for (HYPRE_Int k = o0; k < o1; k++) { Po->data[k] *= scale; }
+            }
+         }
+         cntd[(size_t) i] = d1 - d0; cnto[(size_t) i] = o1 - o0;
+      }
+   }
+   for (HYPRE_Int i = 0; i < n; i++) { ndi[(size_t) i + 1] = ndi[(size_t) i] + cntd[(size_t) i]; noi[(size_t) i + 1] = noi[(size_t) i] + cnto[(size_t) i]; }
+   // compact front to back (new offsets never exceed old ones)
+   for (HYPRE_Int i = 0; i < n; i++)
+   {
+      const HYPRE_Int s = Pd->i[i], t = ndi[(size_t) i];
+      if (s != t) { for (HYPRE_Int k = 0; k < cntd[(size_t) i]; k++) { Pd->j[t + k] = Pd->j[s + k]; Pd->data[t + k] = Pd->data[s + k]; } }
+      const HYPRE_Int so = Po->i[i], to = noi[(size_t) i];
+      if (so != to) { for (HYPRE_Int k = 0; k < cnto[(size_t) i]; k++) { Po->j[to + k] = Po->j[so + k]; Po->data[to + k] = Po->data[so + k]; } }
+   }
+   memcpy(Pd->i, ndi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+   memcpy(Po->i, noi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+   Pd->num_nonzeros = ndi[(size_t) n];
+   Po->num_nonzeros = noi[(size_t) n];
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// extended+i interpolation (par_lr_interp.c:1024-1700), single-rank form.
+// For an F-point i the interpolatory set C^_i is: strong C neighbours of i and
+// strong C neighbours of i's strong F neighbours (distance two).  Weights:
+//   w_ij = -( a_ij + sum_{k in F_i^s} a_ik a^-_kj / sum_{l in C^_i u {i}} a^-_kl ) / a~_ii
+// with a~_ii = a_ii + weak couplings + the "+i" share of every distributed F neighbour.
+// ===========================================================================
+HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                          HYPRE_BigInt *num_cpts_global, HYPRE_Int num_functions,
+                                          HYPRE_Int *dof_func, HYPRE_Int debug_flag, HYPRE_Real trunc_factor,
+                                          HYPRE_Int max_elmts, hypre_ParCSRMatrix **P_ptr)
+{
+   (void) num_functions; (void) dof_func; (void) debug_flag;
+   MPI_Comm comm = A->comm;
+   if (comm_size(comm) > 1)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildExtPIInterp: distributed setup is not available yet");
+      return hypre_error_flag;
+   }
+   hypre_CSRMatrix *Ad = A->diag;
+   const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
+   const HYPRE_Real *Aa = Ad->data;
+   const HYPRE_Int *Si = S->diag->i, *Sj = S->diag->j;
+   const HYPRE_Int n = Ad->num_rows;
+   const HYPRE_BigInt total_cpts = num_cpts_global[1];
+
+   std::vector<HYPRE_Int> f2c((size_t) std::max(n, 1), -1);
+   {
+      HYPRE_Int c = 0;
+      for (HYPRE_Int i = 0; i < n; i++) { if (CF_marker[i] >= 0) { f2c[(size_t) i] = c++; } }
+   }
+   const int T = num_threads_avail();
+   std::vector<std::vector<HYPRE_Int>> tj((size_t) T);
+   std::vector<std::vector<HYPRE_Real>> ta((size_t) T);
+   std::vector<HYPRE_Int> rowlen((size_t) std::max(n, 1), 0);
+
+#pragma omp parallel num_threads(T)
+   {
+      const int t = omp_get_thread_num();
+      int rb, re;
+      chunk(n, T, t, &rb, &re);
+      std::vector<HYPRE_Int> &pj = tj[(size_t) t];
+      std::vector<HYPRE_Real> &pa = ta[(size_t) t];
+      // marker holds, per fine point, either the position of its column in
+      // the current row (>= row begin), or the strong-F tag of the current row
+      std::vector<long long> marker((size_t) std::max(n, 1), -1);
+      long long strong_f = -2;
+      for (HYPRE_Int i = rb; i < re; i++)
+      {
+         const long long begin = (long long) pj.size();
+         if (CF_marker[i] >= 0)
+         {
+            pj.push_back(f2c[(size_t) i]); pa.push_back(1.0);
+         }
+         else if (CF_marker[i] != -3)
+         {
+            strong_f--;
+            for (HYPRE_Int jj = Si[i]; jj < Si[i + 1]; jj++)
+            {
+               const HYPRE_Int i1 = Sj[jj];
+               if (CF_marker[i1] >= 0)
+               {
+                  if (marker[(size_t) i1] < begin) { marker[(size_t) i1] = (long long) pj.size(); pj.push_back(f2c[(size_t) i1]); pa.push_back(0.0); }
+               }
+               else if (CF_marker[i1] != -3)
+               {
+                  marker[(size_t) i1] = strong_f;
+                  for (HYPRE_Int kk = Si[i1]; kk < Si[i1 + 1]; kk++)
+                  {
+                     const HYPRE_Int k1 = Sj[kk];
+                     if (CF_marker[k1] >= 0 && marker[(size_t) k1] < begin)
+                     {
+                        marker[(size_t) k1] = (long long) pj.size(); pj.push_back(f2c[(size_t) k1]); pa.push_back(0.0);
+                     }
+                  }
+               }
+            }
+            HYPRE_Real diagonal = Aa[Ai[i]];
+            for (HYPRE_Int jj = Ai[i] + 1; jj < Ai[i + 1]; jj++)
+            {
+               const HYPRE_Int i1 = Aj[jj];
+               if (marker[(size_t) i1] >= begin) { pa[(size_t) marker[(size_t) i1]] += Aa[jj]; }
+               else if (marker[(size_t) i1] == strong_f)
+               {
+                  HYPRE_Real sum = 0.0;
+                  const int sgn = Aa[Ai[i1]] < 0 ? -1 : 1;
+                  for (HYPRE_Int j1 = Ai[i1] + 1; j1 < Ai[i1 + 1]; j1++)
+                  {
+                     const HYPRE_Int i2 = Aj[j1];
+                     if ((marker[(size_t) i2] >= begin || i2 == i) && (sgn * Aa[j1]) < 0) { sum += Aa[j1]; }
+                  }
+                  if (sum != 0)
+                  {
+                     const HYPRE_Real distribute = Aa[jj] / sum;
+                     for (HYPRE_Int j1 = Ai[i1] + 1; j1 < Ai[i1 + 1]; j1++)
+                     {
+                        const HYPRE_Int i2 = Aj[j1];
+                        if (marker[(size_t) i2] >= begin && (sgn * Aa[j1]) < 0) { pa[(size_t) marker[(size_t) i2]] += distribute * Aa[j1]; }
+                        if (i2 == i && (sgn * Aa[j1]) < 0) { diagonal += distribute * Aa[j1]; }
+                     }
+                  }
+                  else { diagonal += Aa[jj]; }
+               }
+               else if (CF_marker[i1] != -3) { diagonal += Aa[jj]; }
+            }
+            if (diagonal) { for (size_t k = (size_t) begin; k < pj.size(); k++) { pa[k] /= -diagonal; } }
+            strong_f--;
+         }
+         rowlen[(size_t) i] = (HYPRE_Int) ((long long) pj.size() - begin);
+      }
+   }
+   // stitch
+   std::vector<HYPRE_Int> Pi((size_t) n + 1, 0);
+   for (HYPRE_Int i = 0; i < n; i++) { Pi[(size_t) i + 1] = Pi[(size_t) i] + rowlen[(size_t) i]; }
+   const HYPRE_Int nnz = Pi[(size_t) n];
+   HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
+   hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_cpts, A->col_starts, cs, 0, nnz, 0);
+   hypre_ParCSRMatrixInitialize_v2(P, HYPRE_MEMORY_HOST);
+   memcpy(P->diag->i, Pi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+#pragma omp parallel num_threads(T)
+   {
+      const int t = omp_get_thread_num();
+      int rb, re;
+      chunk(n, T, t, &rb, &re);
+      if (re > rb)
+      {
+         const size_t off = (size_t) Pi[(size_t) rb];
+         if (!tj[(size_t) t].empty())
+         {
+            memcpy(P->diag->j + off, tj[(size_t) t].data(), sizeof(HYPRE_Int) * tj[(size_t) t].size());
+            memcpy(P->diag->data + off, ta[(size_t) t].data(), sizeof(HYPRE_Real) * ta[(size_t) t].size());
+         }
+      }
+   }
+   if (trunc_factor != 0.0 || max_elmts > 0) { hypre_BoomerAMGInterpTruncation(P, trunc_factor, max_elmts); }
+   hypre_CSRMatrixSetRownnz(P->offd);
+   *P_ptr = P;
+   return hypre_error_flag;
+}
+
+// Direct interpolation (par_interp.c hypre_BoomerAMGBuildDirInterpHost, interp_type 3):
+//   w_ij = -alpha a_ij / a_ii for strong C neighbours, alpha/beta rescale negative
+//   and positive couplings so that the row sum of A is reproduced.
+HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                        HYPRE_BigInt *num_cpts_global, HYPRE_Int num_functions,
+                                        HYPRE_Int *dof_func, HYPRE_Int debug_flag, HYPRE_Real trunc_factor,
+                                        HYPRE_Int max_elmts, HYPRE_Int interp_type, hypre_ParCSRMatrix **P_ptr)
+{
+   (void) num_functions; (void) dof_func; (void) debug_flag; (void) interp_type;
+   MPI_Comm comm = A->comm;
+   if (comm_size(comm) > 1)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildDirInterp: distributed setup is not available yet");
+      return hypre_error_flag;
+   }
+   hypre_CSRMatrix *Ad = A->diag;
+   const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
+   const HYPRE_Real *Aa = Ad->data;
+   const HYPRE_Int *Si = S->diag->i, *Sj = S->diag->j;
+   const HYPRE_Int n = Ad->num_rows;
+   std::vector<HYPRE_Int> f2c((size_t) std::max(n, 1), -1);
+   HYPRE_Int c = 0;
+   for (HYPRE_Int i = 0; i < n; i++) { if (CF_marker[i] >= 0) { f2c[(size_t) i] = c++; } }
+   std::vector<HYPRE_Int> Pi((size_t) n + 1, 0), pj;
+   std::vector<HYPRE_Real> pa;
+   std::vector<HYPRE_Int> marker((size_t) std::max(n, 1), -1);
+   for (HYPRE_Int i = 0; i < n; i++)
+   {
+      const HYPRE_Int begin = (HYPRE_Int) pj.size();
+      if (CF_marker[i] >= 0) { pj.push_back(f2c[(size_t) i]); pa.push_back(1.0); }
+      else
+      {
+         for (HYPRE_Int jj = Si[i]; jj < Si[i + 1]; jj++)
+         {
+            const HYPRE_Int i1 = Sj[jj];
+            if (CF_marker[i1] >= 0) { marker[(size_t) i1] = (HYPRE_Int) pj.size(); pj.push_back(f2c[(size_t) i1]); pa.push_back(0.0); }
+         }
+         const HYPRE_Int end = (HYPRE_Int) pj.size();
+         const HYPRE_Real diagonal = Aa[Ai[i]];
+         HYPRE_Real sum_N_pos = 0, sum_N_neg = 0, sum_P_pos = 0, sum_P_neg = 0;
+         for (HYPRE_Int jj = Ai[i] + 1; jj < Ai[i + 1]; jj++)
+         {
+            const HYPRE_Int i1 = Aj[jj];
+            if (Aa[jj] > 0) { sum_N_pos += Aa[jj]; } else { sum_N_neg += Aa[jj]; }
+            if (marker[(size_t) i1] >= begin)
+            {
+               pa[(size_t) marker[(size_t) i1]] += Aa[jj];
+               if (Aa[jj] > 0) { sum_P_pos += Aa[jj]; } else { sum_P_neg += Aa[jj]; }
+            }
+         }
+         HYPRE_Real alfa = 1.0, beta = 1.0, diag = diagonal;
+         if (sum_P_neg) { alfa = sum_N_neg / sum_P_neg / diag; }
+         if (sum_P_pos) { beta = sum_N_pos / sum_P_pos / diag; }
+         for (HYPRE_Int k = begin; k < end; k++)
+         {
+            if (pa[(size_t) k] > 0) { pa[(size_t) k] *= -beta; } else { pa[(size_t) k] *= -alfa; }
+         }
+      }
+      Pi[(size_t) i + 1] = (HYPRE_Int) pj.size();
+   }
+   HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
+   hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, num_cpts_global[1], A->col_starts, cs, 0,
+                                                    Pi[(size_t) n], 0);
+   hypre_ParCSRMatrixInitialize_v2(P, HYPRE_MEMORY_HOST);
+   memcpy(P->diag->i, Pi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+   if (!pj.empty())
+   {
+      memcpy(P->diag->j, pj.data(), sizeof(HYPRE_Int) * pj.size());
+      memcpy(P->diag->data, pa.data(), sizeof(HYPRE_Real) * pa.size());
+   }
+   if (trunc_factor != 0.0 || max_elmts > 0) { hypre_BoomerAMGInterpTruncation(P, trunc_factor, max_elmts); }
+   hypre_CSRMatrixSetRownnz(P->offd);
+   *P_ptr = P;
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// Galerkin product A_c = P^T A P (par_rap.c:30-2000), single-rank form.
+// Row ic: diagonal slot first, then RA = sum_{i1 in R(ic,:)} r * A(i1,:)
+// accumulated in first-touch order, then RA * P in first-touch order.
+// ===========================================================================
+HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A,
+                                               hypre_ParCSRMatrix *P, HYPRE_Int keepTranspose,
+                                               hypre_ParCSRMatrix **RAP_ptr)
+{
+   MPI_Comm comm = A->comm;
+   if (comm_size(comm) > 1)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildCoarseOperatorKT: distributed setup is not available yet");
+      return hypre_error_flag;
+   }
+   hypre_CSRMatrix *R = nullptr;
+   hypre_CSRMatrixTranspose(RT->diag, &R, 1);
+   const HYPRE_Int nc = R->num_rows, nf = A->diag->num_rows;
+   const HYPRE_Int *Ri = R->i, *Rj = R->j; const HYPRE_Real *Ra = R->data;
+   const HYPRE_Int *Ai = A->diag->i, *Aj = A->diag->j; const HYPRE_Real *Aa = A->diag->data;
+   const HYPRE_Int *Pi = P->diag->i, *Pj = P->diag->j; const HYPRE_Real *Pa = P->diag->data;
+   const bool square = (RT->diag->num_cols == P->diag->num_cols);
+
+   const int T = num_threads_avail();
+   std::vector<std::vector<HYPRE_Int>> tj((size_t) T);
+   std::vector<std::vector<HYPRE_Real>> ta((size_t) T);
+   std::vector<HYPRE_Int> rowlen((size_t) std::max(nc, 1), 0);
+#pragma omp parallel num_threads(T)
+   {
+      const int t = omp_get_thread_num();
+      int rb, re;
+      chunk(nc, T, t, &rb, &re);
+      std::vector<HYPRE_Int> &oj = tj[(size_t) t];
+      std::vector<HYPRE_Real> &oa = ta[(size_t) t];
+      std::vector<long long> Pmark((size_t) std::max(nc, 1), -1);
+      std::vector<HYPRE_Int> Amark((size_t) std::max(nf, 1), -1);
+      std::vector<HYPRE_Int> raj;
+      std::vector<HYPRE_Real> raa;
+      for (HYPRE_Int ic = rb; ic < re; ic++)
+      {
+         const long long begin = (long long) oj.size();
+         if (square) { Pmark[(size_t) ic] = begin; oj.push_back(ic); oa.push_back(0.0); }
+         raj.clear(); raa.clear();
+         for (HYPRE_Int j1 = Ri[ic]; j1 < Ri[ic + 1]; j1++)
+         {
+            const HYPRE_Int i1 = Rj[j1];
+            const HYPRE_Real r = Ra[j1];
+            for (HYPRE_Int j2 = Ai[i1]; j2 < Ai[i1 + 1]; j2++)
+            {
+               const HYPRE_Int i2 = Aj[j2];
+               const HYPRE_Int m = Amark[(size_t) i2];
+               if (m < 0 || m >= (HYPRE_Int) raj.size() || raj[(size_t) m] != i2)
+               {
+                  Amark[(size_t) i2] = (HYPRE_Int) raj.size();
+                  raj.push_back(i2); raa.push_back(r * Aa[j2]);
+               }
+               else { raa[(size_t) m] += r * Aa[j2]; }
+            }
+         }
+         for (size_t q = 0; q < raj.size(); q++)
+         {
+            const HYPRE_Int i1 = raj[q];
+            const HYPRE_Real rap = raa[q];
+            for (HYPRE_Int j2 = Pi[i1]; j2 < Pi[i1 + 1]; j2++)
+            {
+               const HYPRE_Int i2 = Pj[j2];
+               const long long m = Pmark[(size_t) i2];
+               if (m < begin) { Pmark[(size_t) i2] = (long long) oj.size(); oj.push_back(i2); oa.push_back(rap * Pa[j2]); }
+               else { oa[(size_t) m] += rap * Pa[j2]; }
+            }
+         }
+         rowlen[(size_t) ic] = (HYPRE_Int) ((long long) oj.size() - begin);
+      }
+   }
+   std::vector<HYPRE_Int> Ci((size_t) nc + 1, 0);
+   for (HYPRE_Int i = 0; i < nc; i++) { Ci[(size_t) i + 1] = Ci[(size_t) i] + rowlen[(size_t) i]; }
+   hypre_ParCSRMatrix *C = hypre_ParCSRMatrixCreate(comm, RT->global_num_cols, P->global_num_cols, RT->col_starts,
+                                                    P->col_starts, 0, Ci[(size_t) nc], 0);
+   hypre_ParCSRMatrixInitialize_v2(C, HYPRE_MEMORY_HOST);
+   memcpy(C->diag->i, Ci.data(), sizeof(HYPRE_Int) * ((size_t) nc + 1));
+#pragma omp parallel num_threads(T)
+   {
+      const int t = omp_get_thread_num();
+      int rb, re;
+      chunk(nc, T, t, &rb, &re);
+      if (re > rb && !tj[(size_t) t].empty())
+      {
+         const size_t off = (size_t) Ci[(size_t) rb];
+         memcpy(C->diag->j + off, tj[(size_t) t].data(), sizeof(HYPRE_Int) * tj[(size_t) t].size());
+         memcpy(C->diag->data + off, ta[(size_t) t].data(), sizeof(HYPRE_Real) * ta[(size_t) t].size());
+      }
+   }
+   if (keepTranspose) { RT->diagT = R; } else { hypre_CSRMatrixDestroy(R); }
+   hypre_CSRMatrixSetRownnz(C->offd);
+   hypre_ParCSRMatrixSetNumNonzeros(C);
+   hypre_ParCSRMatrixSetDNumNonzeros(C);
+   *RAP_ptr = C;
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// smoother diagonals (ams.c:527-830), host
+// ===========================================================================
+HYPRE_Int hypre_ParCSRComputeL1Norms(hypre_ParCSRMatrix *A, HYPRE_Int option, HYPRE_Int *cf_marker,
+                                     HYPRE_Real **l1_norm_ptr)
+{
+   hypre_CSRMatrix *D = A->diag, *O = A->offd;
+   if (D->memory_location != HYPRE_MEMORY_HOST)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRComputeL1Norms: setup-time routine, expects host matrices");
+      return hypre_error_flag;
+   }
+   const HYPRE_Int n = D->num_rows, nco = O->num_cols;
+   HYPRE_Real *l1 = hypre_TAlloc(HYPRE_Real, std::max(n, 1), HYPRE_MEMORY_HOST);
+   std::vector<HYPRE_Int> cf_offd;
+   const HYPRE_Int *cfo = nullptr;
+   if (cf_marker && nco)
+   {
+      cf_offd.resize((size_t) nco);
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      halo_forward<HYPRE_Int>(A->comm_pkg, cf_marker, cf_offd.data());
+      cfo = cf_offd.data();
+   }
+   auto abs_sum = [&](hypre_CSRMatrix *M, const HYPRE_Int *ci, const HYPRE_Int *cj, HYPRE_Real *out, double scal, bool add)
+   {
+#pragma omp parallel for schedule(static)
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         HYPRE_Real s = add ? out[i] : 0.0;
+         for (HYPRE_Int k = M->i[i]; k < M->i[i + 1]; k++)
+         {
+            if (ci && cj && ci[i] != cj[M->j[k]]) { continue; }
+            s += scal * std::fabs(M->data[k]);
+         }
+         out[i] = s;
+      }
+   };
+   auto get_diag = [&](HYPRE_Real *d, bool take_abs)
+   {
+#pragma omp parallel for schedule(static)
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         HYPRE_Real v = 0.0;
+         for (HYPRE_Int k = D->i[i]; k < D->i[i + 1]; k++) { if (D->j[k] == i) { v = take_abs ? std::fabs(D->data[k]) : D->data[k]; break; } }
+         d[i] = v;
+      }
+   };
+   std::vector<HYPRE_Real> tmp((size_t) std::max(n, 1));
+   if (option == 1)
+   {
+      abs_sum(D, cf_marker, cf_marker, l1, 1.0, false);
+      if (nco) { abs_sum(O, cf_marker, cfo, l1, 1.0, true); }
+   }
+   else if (option == 4)
+   {
+      get_diag(l1, true);
+      memcpy(tmp.data(), l1, sizeof(HYPRE_Real) * (size_t) n);
+      if (nco) { abs_sum(O, cf_marker, cfo, l1, 0.5, true); }
+      for (HYPRE_Int i = 0; i < n; i++) { if (l1[i] <= 4.0 / 3.0 * tmp[(size_t) i]) { l1[i] = tmp[(size_t) i]; } }
+   }
+   else if (option == 5)
+   {
+      get_diag(l1, false);
+      for (HYPRE_Int i = 0; i < n; i++) { if (l1[i] == 0.0) { l1[i] = 1.0; } }
+      *l1_norm_ptr = l1;
+      return hypre_error_flag;
+   }
+   else if (option == 6)
+   {
+      get_diag(l1, true);
+      if (nco)
+      {
+         abs_sum(O, cf_marker, cfo, tmp.data(), 1.0, false);
+         for (HYPRE_Int i = 0; i < n; i++)
+         {
+            l1[i] = 0.5 * (tmp[(size_t) i] + l1[i] + std::sqrt(tmp[(size_t) i] * tmp[(size_t) i] + l1[i] * l1[i]));
+         }
+      }
+   }
+   else
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRComputeL1Norms: option not supported");
+   }
+   get_diag(tmp.data(), false);
+   for (HYPRE_Int i = 0; i < n; i++) { if (tmp[(size_t) i] < 0.0) { l1[i] = -l1[i]; } }
+   for (HYPRE_Int i = 0; i < n; i++) { if (std::fabs(l1[i]) == 0.0) { hypre_error_in_arg(1); break; } }
+   *l1_norm_ptr = l1;
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// coarsest level: dense copy of the operator (par_gauss_elim.c:25-300)
+// ===========================================================================
+HYPRE_Int hypre_GaussElimSetup(hypre_ParAMGData *d, HYPRE_Int level, HYPRE_Int relax_type)
+{
+   (void) relax_type;
+   hypre_ParCSRMatrix *A = d->A_array[level];
+   const HYPRE_Int n = (HYPRE_Int) A->global_num_rows;
+   const HYPRE_Int nloc = A->diag->num_rows;
+   const HYPRE_Int first = (HYPRE_Int) A->first_row_index;
+   std::vector<double> local((size_t) std::max(nloc, 1) * (size_t) std::max(n, 1), 0.0);
+   for (HYPRE_Int i = 0; i < nloc; i++)
+   {
+      for (HYPRE_Int k = A->diag->i[i]; k < A->diag->i[i + 1]; k++) { local[(size_t) i * n + (size_t) (A->diag->j[k] + first)] = A->diag->data[k]; }
+      for (HYPRE_Int k = A->offd->i[i]; k < A->offd->i[i + 1]; k++) { local[(size_t) i * n + (size_t) A->col_map_offd[A->offd->j[k]]] = A->offd->data[k]; }
+   }
+   free(d->A_mat); free(d->b_vec);
+   d->A_mat = (HYPRE_Real *) calloc((size_t) std::max(n, 1) * (size_t) std::max(n, 1), sizeof(HYPRE_Real));
+   d->b_vec = (HYPRE_Real *) calloc((size_t) std::max(n, 1), sizeof(HYPRE_Real));
+   const hypre_amd_CommOps *o = comm_ops(A->comm);
+   if (o && o->size > 1)
+   {
+      // rows are contiguous per rank in rank order: gather row counts, then padded blocks
+      std::vector<HYPRE_Int> counts((size_t) o->size);
+      o->allgather(o->ctx, &nloc, counts.data(), sizeof(HYPRE_Int));
+      HYPRE_Int maxc = 0;
+      for (int r = 0; r < o->size; r++) { maxc = std::max(maxc, counts[(size_t) r]); }
+      std::vector<double> sendb((size_t) std::max(maxc, 1) * (size_t) n, 0.0), all((size_t) std::max(maxc, 1) * (size_t) n * (size_t) o->size);
+      memcpy(sendb.data(), local.data(), sizeof(double) * (size_t) nloc * (size_t) n);
+      o->allgather(o->ctx, sendb.data(), all.data(), sizeof(double) * sendb.size());
+      HYPRE_Int row = 0;
+      for (int r = 0; r < o->size; r++)
+      {
+         memcpy(d->A_mat + (size_t) row * n, all.data() + (size_t) r * sendb.size(), sizeof(double) * (size_t) counts[(size_t) r] * (size_t) n);
+         row += counts[(size_t) r];
+      }
+   }
+   else
+   {
+      memcpy(d->A_mat, local.data(), sizeof(double) * (size_t) nloc * (size_t) n);
+   }
+   d->gs_setup = 1;
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// the level loop (par_amg_setup.c:28-3560 reduced to the in-scope options)
+// ===========================================================================
+static hypre_ParVector *new_vec(MPI_Comm comm, HYPRE_BigInt gsize, HYPRE_BigInt *part, HYPRE_MemoryLocation loc)
+{
+   hypre_ParVector *v = hypre_ParVectorCreate(comm, gsize, part);
+   hypre_ParVectorInitialize_v2(v, loc);
+   return v;
+}
+
+HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_ParVector *f, hypre_ParVector *u)
+{
+   (void) f; (void) u;
+   hypre_ParAMGData *d = (hypre_ParAMGData *) amg_vdata;
+   if (!d) { hypre_error_in_arg(1); return hypre_error_flag; }
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   amg_free_hierarchy(d);
+   MPI_Comm comm = A->comm;
+   const HYPRE_MemoryLocation target = d->memory_location;
+   if (target == HYPRE_MEMORY_DEVICE && !ensure_device())
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: hierarchy requested in device memory but no HIP device is available");
+      return hypre_error_flag;
+   }
+   const int max_levels = d->max_levels;
+   d->A = A;
+   d->A_array = (hypre_ParCSRMatrix **) calloc((size_t) max_levels, sizeof(void *));
+   d->P_array = (hypre_ParCSRMatrix **) calloc((size_t) max_levels, sizeof(void *));
+   d->R_array = d->P_array;
+   d->F_array = (hypre_ParVector **) calloc((size_t) max_levels, sizeof(void *));
+   d->U_array = (hypre_ParVector **) calloc((size_t) max_levels, sizeof(void *));
+   d->CF_marker_array = (hypre_IntArray **) calloc((size_t) max_levels, sizeof(void *));
+   d->l1_norms = (hypre_Vector **) calloc((size_t) max_levels, sizeof(void *));
+   d->relax_weight = (HYPRE_Real *) calloc((size_t) max_levels, sizeof(HYPRE_Real));
+   d->omega = (HYPRE_Real *) calloc((size_t) max_levels, sizeof(HYPRE_Real));
+   for (int l = 0; l < max_levels; l++) { d->relax_weight[l] = d->user_relax_weight; d->omega[l] = d->outer_wt; }
+
+   // the setup works on host copies; a device-resident A is cloned once
+   std::vector<hypre_ParCSRMatrix *> hostA((size_t) max_levels, nullptr);
+   const bool A_on_device = A->diag->memory_location == HYPRE_MEMORY_DEVICE;
+   hostA[0] = A_on_device ? hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST) : A;
+   d->A_array[0] = A;
+   if (hostA[0]->d_num_nonzeros < 0) { hypre_ParCSRMatrixSetDNumNonzeros(hostA[0]); A->d_num_nonzeros = hostA[0]->d_num_nonzeros; }
+
+   int level = 0;
+   bool not_finished = max_levels > 1;     // the loop always coarsens once (par_amg_setup.c:960-990)
+   HYPRE_Int coarsen_type = d->coarsen_type;
+   HYPRE_BigInt fine_size = A->global_num_rows, coarse_size = fine_size;
+   if (max_levels == 1)
+   {
+      d->CF_marker_array[0] = hypre_IntArrayCreate(A->diag->num_rows);
+      hypre_IntArrayInitialize_v2(d->CF_marker_array[0], HYPRE_MEMORY_HOST);
+      for (HYPRE_Int i = 0; i < A->diag->num_rows; i++) { d->CF_marker_array[0]->data[i] = 1; }
+   }
+   while (not_finished)
+   {
+      hypre_ParCSRMatrix *Al = hostA[(size_t) level];
+      fine_size = Al->global_num_rows;
+      if (level > 0)
+      {
+         d->F_array[level] = new_vec(comm, fine_size, Al->row_starts, HYPRE_MEMORY_HOST);
+         d->U_array[level] = new_vec(comm, fine_size, Al->row_starts, HYPRE_MEMORY_HOST);
+      }
+      hypre_ParCSRMatrix *S = nullptr;
+      hypre_BoomerAMGCreateS(Al, d->strong_threshold, d->max_row_sum, 1, nullptr, &S);
+      const HYPRE_Int nloc = Al->diag->num_rows;
+      d->CF_marker_array[level] = hypre_IntArrayCreate(nloc);
+      hypre_IntArrayInitialize_v2(d->CF_marker_array[level], HYPRE_MEMORY_HOST);
+      if (coarsen_type == 8) { hypre_BoomerAMGCoarsenPMIS(S, Al, 0, 0, &d->CF_marker_array[level]); }
+      else if (coarsen_type == 9) { hypre_BoomerAMGCoarsenPMIS(S, Al, 2, 0, &d->CF_marker_array[level]); }
+      else if (coarsen_type == 10) { hypre_BoomerAMGCoarsenHMIS(S, Al, d->measure_type, 0, 0, &d->CF_marker_array[level]); }
+      else
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: coarsen_type must be 8 (PMIS), 9 (PMIS, sequential random numbers) or 10 (HMIS)");
+         hypre_ParCSRMatrixDestroy(S);
+         break;
+      }
+      HYPRE_Int *CF = d->CF_marker_array[level]->data;
+      HYPRE_BigInt cpts[2];
+      coarse_parms(comm, nloc, CF, cpts, &coarse_size);
+      if (coarse_size == 0 || coarse_size == fine_size)
+      {
+         // no coarse grid: one sweep of the default smoother on the last level (par_amg_setup.c:1655-1690)
+         HYPRE_Int *gt = d->grid_relax_type;
+         if (gt[3] == 9 || gt[3] == 99 || gt[3] == 19 || gt[3] == 98)
+         {
+            gt[3] = gt[0];
+            d->num_grid_sweeps[3] = 1;
+            if (d->grid_relax_points) { d->grid_relax_points[3][0] = 0; }
+         }
+         hypre_ParCSRMatrixDestroy(S);
+         if (level > 0)
+         {
+            hypre_IntArrayDestroy(d->CF_marker_array[level]); d->CF_marker_array[level] = nullptr;
+            hypre_ParVectorDestroy(d->F_array[level]); d->F_array[level] = nullptr;
+            hypre_ParVectorDestroy(d->U_array[level]); d->U_array[level] = nullptr;
+         }
+         coarse_size = fine_size;
+         break;
+      }
+      if (coarse_size < (HYPRE_BigInt) d->min_coarse_size)
+      {
+         hypre_ParCSRMatrixDestroy(S);
+         hypre_IntArrayDestroy(d->CF_marker_array[level]); d->CF_marker_array[level] = nullptr;
+         if (level > 0)
+         {
+            hypre_ParVectorDestroy(d->F_array[level]); d->F_array[level] = nullptr;
+            hypre_ParVectorDestroy(d->U_array[level]); d->U_array[level] = nullptr;
+         }
+         coarse_size = fine_size;
+         break;
+      }
+      hypre_ParCSRMatrix *P = nullptr;
+      if (d->interp_type == 6)
+      {
+         hypre_BoomerAMGBuildExtPIInterp(Al, CF, S, cpts, 1, nullptr, 0, d->trunc_factor, d->P_max_elmts, &P);
+      }
+      else if (d->interp_type == 3)
+      {
+         hypre_BoomerAMGBuildDirInterp(Al, CF, S, cpts, 1, nullptr, 0, d->trunc_factor, d->P_max_elmts, 0, &P);
+      }
+      else
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: interp_type must be 6 (extended+i) or 3 (direct)");
+      }
+      hypre_ParCSRMatrixDestroy(S);
+      if (!P || hypre_error_flag) { break; }
+      hypre_ParCSRMatrixSetNumNonzeros(P);
+      hypre_ParCSRMatrixSetDNumNonzeros(P);
+      d->P_array[level] = P;
+      hypre_ParCSRMatrix *AH = nullptr;
+      hypre_BoomerAMGBuildCoarseOperatorKT(P, Al, P, 1, &AH);
+      if (!AH || hypre_error_flag) { break; }
+      ++level;
+      hostA[(size_t) level] = AH;
+      d->A_array[level] = AH;
+      // (par_amg_setup.c:3128-3136) switch to plain CLJP-free coarsening when the grid barely shrinks
+      if (coarsen_type > 0 && (double) coarse_size >= 0.75 * (double) fine_size) { coarsen_type = 0; }
+      if (level == max_levels - 1 || coarse_size <= (HYPRE_BigInt) d->max_coarse_size) { not_finished = false; }
+      if (coarsen_type == 0)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: coarsening stalled (coarse grid >= 75% of fine); CLJP fallback is out of scope");
+         not_finished = false;
+      }
+   }
+   const int num_levels = level + 1;
+   d->num_levels = num_levels;
+   if (num_levels > 1 && !d->F_array[num_levels - 1])
+   {
+      hypre_ParCSRMatrix *Al = hostA[(size_t) num_levels - 1];
+      d->F_array[num_levels - 1] = new_vec(comm, Al->global_num_rows, Al->row_starts, HYPRE_MEMORY_HOST);
+      d->U_array[num_levels - 1] = new_vec(comm, Al->global_num_rows, Al->row_starts, HYPRE_MEMORY_HOST);
+   }
+
+   // coarsest-level solver (par_amg_setup.c:3165-3200)
+   {
+      HYPRE_Int *gt = d->grid_relax_type;
+      if (gt[3] == 9 || gt[3] == 19 || gt[3] == 98 || gt[3] == 99 || gt[3] == 198 || gt[3] == 199)
+      {
+         hypre_ParCSRMatrix *Ac = hostA[(size_t) num_levels - 1];
+         if (Ac->global_num_rows <= (HYPRE_BigInt) d->max_coarse_size)
+         {
+            d->A_array[num_levels - 1] = Ac;
+            hypre_GaussElimSetup(d, num_levels - 1, gt[3]);
+         }
+         else { gt[3] = gt[1]; }
+      }
+   }
+
+   // smoother diagonals per level (par_amg_setup.c:3296-3500)
+   {
+      const HYPRE_Int *gt = d->grid_relax_type;
+      for (int j = 0; j < num_levels; j++)
+      {
+         HYPRE_Real *l1 = nullptr;
+         hypre_ParCSRMatrix *Al = hostA[(size_t) j];
+         HYPRE_Int *cf = (d->relax_order && d->CF_marker_array[j]) ? d->CF_marker_array[j]->data : nullptr;
+         const bool last = (j == num_levels - 1);
+         auto any = [&](int a, int b, int c, int e) { return gt[1] == a || gt[1] == b || gt[1] == c || gt[1] == e ||
+                                                            gt[2] == a || gt[2] == b || gt[2] == c || gt[2] == e; };
+         auto last_is = [&](int a, int b, int c, int e) { return gt[3] == a || gt[3] == b || gt[3] == c || gt[3] == e; };
+         if (!last && any(8, 89, 13, 14)) { hypre_ParCSRComputeL1Norms(Al, 4, cf, &l1); }
+         else if (last && last_is(8, 89, 13, 14)) { hypre_ParCSRComputeL1Norms(Al, 4, nullptr, &l1); }
+         if (!last && (gt[1] == 88 || gt[2] == 88)) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 6, cf, &l1); }
+         else if (last && gt[3] == 88) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 6, nullptr, &l1); }
+         if (!last && (gt[1] == 18 || gt[2] == 18)) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 1, cf, &l1); }
+         else if (last && gt[3] == 18) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 1, nullptr, &l1); }
+         if (gt[1] == 7 || gt[2] == 7 || (gt[3] == 7 && last) || gt[1] == 11 || gt[2] == 11 || (gt[3] == 11 && last) ||
+             gt[1] == 12 || gt[2] == 12 || (gt[3] == 12 && last))
+         {
+            hypre_Free(l1, HYPRE_MEMORY_HOST);
+            hypre_ParCSRComputeL1Norms(Al, 5, nullptr, &l1);
+         }
+         if (l1)
+         {
+            d->l1_norms[j] = hypre_SeqVectorCreate(Al->diag->num_rows);
+            d->l1_norms[j]->data = l1;
+            d->l1_norms[j]->memory_location = HYPRE_MEMORY_HOST;
+            hypre_SeqVectorInitialize_v2(d->l1_norms[j], HYPRE_MEMORY_HOST);
+         }
+      }
+   }
+
+   // work vectors sized for the finest level
+   d->Vtemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
+   d->Ztemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
+   d->Rtemp = nullptr; d->Ptemp = nullptr;
+
+   // algorithmic bytes of one V(1,1) cycle on this hierarchy: per level below the
+   // coarsest 2 passes over A plus one over P and one over P^T
+   {
+      double bytes = 0.0;
+      for (int l = 0; l < num_levels - 1; l++)
+      {
+         hypre_ParCSRMatrix *Al = hostA[(size_t) l], *Pl = d->P_array[l];
+         const double nA = (double) Al->diag->num_nonzeros + Al->offd->num_nonzeros, rA = Al->diag->num_rows;
+         const double nP = (double) Pl->diag->num_nonzeros + Pl->offd->num_nonzeros, cP = Pl->diag->num_cols;
+         const double sA = nA * 12 + (rA + 1) * 4 + rA * 8 + rA * 8;
+         bytes += 2.0 * sA;                                   // residual + post-smoothing pass
+         bytes += 3.0 * rA * 8;                               // f read (x2) + l1 read of the fused sweep / residual
+         bytes += 3.0 * rA * 8;                               // zero-guess pre-smoothing: f, l1 read, u write
+         bytes += nP * 12 + (rA + 1) * 4 + cP * 8 + 2 * rA * 8;   // prolongation u += P e
+         bytes += nP * 12 + (cP + 1) * 4 + rA * 8 + cP * 8;       // restriction f_c = P^T r
+      }
+      pv->cycle_bytes = bytes;
+   }
+
+   // place the hierarchy where the solve phase will run
+   if (target == HYPRE_MEMORY_DEVICE)
+   {
+      for (int l = 0; l < num_levels; l++)
+      {
+         if (l > 0) { hypre_ParCSRMatrixMigrate(d->A_array[l], HYPRE_MEMORY_DEVICE); }
+         if (l < num_levels - 1)
+         {
+            hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]);
+            hypre_ParCSRMatrixMigrate(d->P_array[l], HYPRE_MEMORY_DEVICE);
+         }
+         if (l > 0)
+         {
+            hypre_ParVectorMigrate(d->F_array[l], HYPRE_MEMORY_DEVICE);
+            hypre_ParVectorMigrate(d->U_array[l], HYPRE_MEMORY_DEVICE);
+         }
+         if (d->l1_norms[l]) { hypre_SeqVectorMigrate(d->l1_norms[l], HYPRE_MEMORY_DEVICE); }
+         if (d->CF_marker_array[l])
+         {
+            hypre_IntArray *a = d->CF_marker_array[l];
+            HYPRE_Int *dd = hypre_TAlloc(HYPRE_Int, std::max(a->size, 1), HYPRE_MEMORY_DEVICE);
+            hypre_TMemcpy(dd, a->data, HYPRE_Int, a->size, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+            hypre_Free(a->data, HYPRE_MEMORY_HOST);
+            a->data = dd; a->memory_location = HYPRE_MEMORY_DEVICE;
+         }
+      }
+      hypre_ParVectorMigrate(d->Vtemp, HYPRE_MEMORY_DEVICE);
+      hypre_ParVectorMigrate(d->Ztemp, HYPRE_MEMORY_DEVICE);
+      if (A_on_device) { hypre_ParCSRMatrixDestroy(hostA[0]); }
+   }
+   else
+   {
+      for (int l = 0; l < num_levels - 1; l++) { hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]); }
+   }
+   return hypre_error_flag;
+}
+
+HYPRE_Real hypre_amd_BoomerAMGCycleBytes(HYPRE_Solver s)
+{
+   hypre_ParAMGData *d = (hypre_ParAMGData *) s;
+   return d ? ((AmgPrivate *) d->amd_private)->cycle_bytes : 0.0;
+}
+
+}  // extern "C"

@@ -1,0 +1,783 @@
+// hypre_amd — the BoomerAMG solve phase on the device: relaxation sweeps, the
+// V/W/F cycle, the outer solve loop and the PCG caller.
+//
+// Reference counterparts (behaviour; the structure is MI355X-first):
+//   parcsr_ls/par_relax.c:24-173,1178-1254,1506-1666   relaxation dispatcher, Jacobi, two-stage GS
+//   parcsr_ls/par_relax_device.c:19-155                device smoothers
+//   parcsr_ls/par_relax_interface.c:20-117             CF-ordered passes
+//   parcsr_ls/par_gauss_elim.c:457-697                 coarsest-level solve
+//   parcsr_ls/par_cycle.c:23-803                       cycle state machine
+//   parcsr_ls/par_amg_solve.c:22-424                   outer loop, convergence test
+//   krylov/pcg.c:318-1000                              PCG
+//
+// What is different from the reference's device path:
+//   * a Jacobi / l1-Jacobi sweep is ONE pass over the matrix (SpMV with the
+//     update fused into the row epilogue) instead of copy + SpMV + elementwise;
+//   * sweeps are out-of-place and every level ping-pongs between two solution
+//     buffers, so no copy-back pass exists inside a cycle;
+//   * nothing inside a cycle synchronises with the host (the reference syncs
+//     after every vector op and SpMV); one stream sync ends the cycle;
+//   * the coarsest-level elimination runs on the device from precomputed
+//     factors instead of a device->host->device round trip per cycle.
+#include "amg_internal.hpp"
+#include <algorithm>
+#include <cmath>
+
+using namespace hamd;
+
+namespace hamd {
+
+void AmgPrivate::release_device()
+{
+   for (double *p : u_alt) { if (p) { hypre_Free(p, HYPRE_MEMORY_DEVICE); } }
+   u_alt.clear(); u_alt_len.clear();
+   if (d_coarse_lu) { hypre_Free(d_coarse_lu, HYPRE_MEMORY_DEVICE); d_coarse_lu = nullptr; }
+   if (d_coarse_rhs) { hypre_Free(d_coarse_rhs, HYPRE_MEMORY_DEVICE); d_coarse_rhs = nullptr; }
+   coarse_n = 0;
+}
+
+// ---------------------------------------------------------------------------
+// raw-pointer cores
+// ---------------------------------------------------------------------------
+static inline void wrap(hypre_Vector *v, const double *data, int size)
+{
+   memset(v, 0, sizeof(*v));
+   v->data = const_cast<double *>(data);
+   v->size = size; v->num_vectors = 1; v->vecstride = size; v->idxstride = 1;
+   v->memory_location = HYPRE_MEMORY_DEVICE;
+}
+static inline void wrap_par(hypre_ParVector *pv, hypre_Vector *lv, MPI_Comm comm, HYPRE_BigInt gsize)
+{
+   memset(pv, 0, sizeof(*pv));
+   pv->comm = comm; pv->global_size = gsize; pv->local_vector = lv;
+}
+
+void dev_par_matvec(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, const double *x, HYPRE_Complex beta,
+                    const double *b, double *y)
+{
+   hypre_Vector xv, bv, yv;
+   hypre_ParVector xp, bp, yp;
+   wrap(&xv, x, A->diag->num_cols); wrap(&bv, b, A->diag->num_rows); wrap(&yv, y, A->diag->num_rows);
+   wrap_par(&xp, &xv, A->comm, A->global_num_cols);
+   wrap_par(&bp, &bv, A->comm, A->global_num_rows);
+   wrap_par(&yp, &yv, A->comm, A->global_num_rows);
+   hypre_ParCSRMatrixMatvecOutOfPlaceDevice(alpha, A, &xp, beta, &bp, &yp);
+}
+
+void dev_par_matvecT(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, const double *x, HYPRE_Complex beta, double *y)
+{
+   hypre_Vector xv, yv;
+   hypre_ParVector xp, yp;
+   wrap(&xv, x, A->diag->num_rows); wrap(&yv, y, A->diag->num_cols);
+   wrap_par(&xp, &xv, A->comm, A->global_num_rows);
+   wrap_par(&yp, &yv, A->comm, A->global_num_cols);
+   hypre_ParCSRMatrixMatvecTDevice(alpha, A, &xp, beta, &yp);
+}
+
+// u_out = u_in + (w f - w A u_in)./d  on rows with cf_marker == relax_points
+// (all rows when relax_points == 0); other rows are copied.  Single rank: one
+// fused pass.  Distributed: the interior pass is fused as well and the ghost
+// couplings are folded in by a second, halo-sized pass.
+void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_marker, int relax_points,
+                      double w, const double *d, const double *u_in, double *u_out)
+{
+   hipStream_t s = stream();
+   hypre_CSRMatrix *diag = A->diag;
+   const int n = diag->num_rows;
+   if (n <= 0) { return; }
+   HYPRE_Int nprocs;
+   hypre_MPI_Comm_size(A->comm, &nprocs);
+   if (nprocs > 1 && A->offd->num_cols > 0)
+   {
+      // r = w f - w A u (with halo), then the update; two passes but still no copy-back
+      double *r = u_out;          // use the output buffer as residual scratch
+      dev_par_matvec(-w, A, u_in, w, f, r);
+      launch_jacobi_update(u_in, r, d, cf_marker, relax_points, u_out, (size_t) n, s);
+      return;
+   }
+   SpmvPlan *plan = get_plan(diag);
+   SpmvArgs a{};
+   a.Ai = diag->i; a.Aj = diag->j; a.Aa = diag->data; a.Aa32 = nullptr;
+   a.x = u_in; a.b = f; a.y = u_out; a.aux = nullptr; a.d = d;
+   a.marker = cf_marker; a.marker_val = relax_points;
+   a.alpha = w; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_WHOLE; a.row_offset = 0;
+   launch_spmv(plan, a, (relax_points != 0 && cf_marker) ? OP_JACOBI_CF : OP_JACOBI, s);
+}
+
+}  // namespace hamd
+
+// per-matrix scratch for the in-place public relax entry (result lands in the
+// caller's u, so one extra vector is needed for the out-of-place sweep)
+static double *relax_scratch(size_t n)
+{
+   static double *buf = nullptr;
+   static size_t len = 0;
+   if (len < n)
+   {
+      if (buf) { hypre_Free(buf, HYPRE_MEMORY_DEVICE); }
+      buf = hypre_TAlloc(double, n, HYPRE_MEMORY_DEVICE);
+      len = n;
+   }
+   return buf;
+}
+static double *diag_scratch(size_t n)
+{
+   static double *buf = nullptr;
+   static size_t len = 0;
+   if (len < n)
+   {
+      if (buf) { hypre_Free(buf, HYPRE_MEMORY_DEVICE); }
+      buf = hypre_TAlloc(double, n, HYPRE_MEMORY_DEVICE);
+      len = n;
+   }
+   return buf;
+}
+
+extern "C" {
+
+// ===========================================================================
+// relaxation (public, in-place on u as the reference)
+// ===========================================================================
+HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f,
+                                                        HYPRE_Real relax_weight, HYPRE_Real omega,
+                                                        HYPRE_Real *A_diag_diag, hypre_ParVector *u,
+                                                        hypre_ParVector *r, hypre_ParVector *z,
+                                                        HYPRE_Int num_inner_iters)
+{
+   (void) omega;
+   hipStream_t s = stream();
+   hypre_CSRMatrix *diag = A->diag;
+   const int n = diag->num_rows;
+   double *ud = u->local_vector->data, *rd = r->local_vector->data, *zd = z->local_vector->data;
+   const int saved = handle().sync_compute;
+   handle().sync_compute = 0;
+   // 0) r = w (f - A u)     1) z = r./D ; u += z
+   dev_par_matvec(-relax_weight, A, ud, relax_weight, f->local_vector->data, rd);
+   launch_diagscale2(A_diag_diag, rd, 1.0, zd, ud, 1, (size_t) n, s);
+   double mult = -1.0;
+   double *zin = zd, *zout = rd;
+   if (n > 0 && diag->num_nonzeros > 0)
+   {
+      SpmvPlan *plan = get_plan(diag);
+      for (int k = 0; k < num_inner_iters; k++)
+      {
+         // 2+3) z_out = (L_strict z_in)./D ; u += mult * z_out   — one fused pass
+         SpmvArgs a{};
+         a.Ai = diag->i; a.Aj = diag->j; a.Aa = diag->data; a.Aa32 = nullptr;
+         a.x = zin; a.b = nullptr; a.y = zout; a.aux = ud; a.d = A_diag_diag; a.marker = nullptr;
+         a.alpha = mult; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_STRICT_LOWER;
+         launch_spmv(plan, a, OP_TSGS, s);
+         std::swap(zin, zout);
+         mult *= -1.0;
+      }
+   }
+   handle().sync_compute = saved;
+   maybe_sync();
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f,
+                                                      HYPRE_Int *cf_marker, HYPRE_Int relax_points,
+                                                      HYPRE_Real relax_weight, HYPRE_Real omega,
+                                                      HYPRE_Real *l1_norms, hypre_ParVector *u,
+                                                      hypre_ParVector *Vtemp, hypre_ParVector *Ztemp,
+                                                      HYPRE_Int GS_order, HYPRE_Int Symm)
+{
+   (void) A; (void) f; (void) cf_marker; (void) relax_points; (void) relax_weight; (void) omega;
+   (void) l1_norms; (void) u; (void) Vtemp; (void) Ztemp; (void) GS_order; (void) Symm;
+   hypre_error_w_msg(HYPRE_ERROR_GENERIC,
+                     "hybrid Gauss-Seidel (relax 3/4/6/8/13/14/88/89) is not available on the device yet: "
+                     "use relax 18/7/0 (Jacobi family) or 11/12 (two-stage Gauss-Seidel)");
+   return hypre_error_flag;
+}
+
+HYPRE_Int hypre_BoomerAMGRelax(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                               HYPRE_Int relax_type, HYPRE_Int relax_points, HYPRE_Real relax_weight,
+                               HYPRE_Real omega, HYPRE_Real *l1_norms, hypre_ParVector *u,
+                               hypre_ParVector *Vtemp, hypre_ParVector *Ztemp)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(A->diag->memory_location, "hypre_BoomerAMGRelax(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(u->local_vector->memory_location, "hypre_BoomerAMGRelax(u)");
+   HYPRE_AMD_REQUIRE_DEVICE(f->local_vector->memory_location, "hypre_BoomerAMGRelax(f)");
+   hipStream_t s = stream();
+   const int n = A->diag->num_rows;
+   const int saved = handle().sync_compute;
+   handle().sync_compute = 0;
+   double *ud = u->local_vector->data;
+   const double *fd = f->local_vector->data;
+   switch (relax_type)
+   {
+      case 0: case 7: case 18:
+      {
+         // smoother diagonal: l1 norms (18), stored diagonal vector (7), first row entry (0)
+         const double *d = l1_norms;
+         if (relax_type == 0 || !d)
+         {
+            double *dd = diag_scratch((size_t) std::max(n, 1));
+            launch_diag_first(A->diag->i, A->diag->data, dd, n, s);
+            d = dd;
+         }
+         if (u->all_zeros && relax_type != 0)
+         {
+            // par_relax.c:1221-1228: u == 0 => u = (w f)./d, no SpMV
+            launch_scaled_div(relax_weight, fd, d, ud, relax_points ? cf_marker : nullptr, relax_points, (size_t) n, s);
+         }
+         else
+         {
+            double *tmp = relax_scratch((size_t) std::max(n, 1));
+            dev_jacobi_sweep(A, fd, cf_marker, relax_points, relax_weight, d, ud, tmp);
+            launch_copy(ud, tmp, (size_t) n, s);
+         }
+         break;
+      }
+      case 11:
+         hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(A, f, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, 1);
+         break;
+      case 12:
+         hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(A, f, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, 2);
+         break;
+      case 3: case 4: case 6: case 8: case 13: case 14: case 88: case 89:
+         hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u,
+                                                     Vtemp, Ztemp, 1, 0);
+         break;
+      default:
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGRelax: relax_type is outside the scope of this library");
+         break;
+   }
+   u->all_zeros = 0;
+   handle().sync_compute = saved;
+   maybe_sync();
+   return 0;     // relax_error (par_relax.c:36,172)
+}
+
+HYPRE_Int hypre_BoomerAMGRelaxIF(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                                 HYPRE_Int relax_type, HYPRE_Int relax_order, HYPRE_Int cycle_param,
+                                 HYPRE_Real relax_weight, HYPRE_Real omega, HYPRE_Real *l1_norms,
+                                 hypre_ParVector *u, hypre_ParVector *Vtemp, hypre_ParVector *Ztemp)
+{
+   HYPRE_Int err = 0;
+   if (relax_order == 1 && cycle_param < 3)
+   {
+      const HYPRE_Int pts[2] = {cycle_param < 2 ? 1 : -1, cycle_param < 2 ? -1 : 1};
+      for (int i = 0; i < 2; i++)
+      {
+         err = hypre_BoomerAMGRelax(A, f, cf_marker, relax_type, pts[i], relax_weight, omega, l1_norms, u, Vtemp, Ztemp);
+      }
+   }
+   else
+   {
+      err = hypre_BoomerAMGRelax(A, f, cf_marker, relax_type, 0, relax_weight, omega, l1_norms, u, Vtemp, Ztemp);
+   }
+   return err;
+}
+
+HYPRE_Int hypre_ParCSRRelax_L1_Jacobi(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                                      HYPRE_Int relax_points, HYPRE_Real relax_weight, HYPRE_Real *l1_norms,
+                                      hypre_ParVector *u, hypre_ParVector *Vtemp)
+{
+   return hypre_BoomerAMGRelax(A, f, cf_marker, 18, relax_points, relax_weight, 0.0, l1_norms, u, Vtemp, nullptr);
+}
+
+HYPRE_Int hypre_BoomerAMGRelax_FCFJacobi(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                                         HYPRE_Real relax_weight, hypre_ParVector *u, hypre_ParVector *Vtemp)
+{
+   const HYPRE_Int pts[3] = {-1, 1, -1};
+   for (int i = 0; i < 3; i++) { hypre_BoomerAMGRelax(A, f, cf_marker, 0, pts[i], relax_weight, 0.0, nullptr, u, Vtemp, nullptr); }
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// coarsest level
+// ===========================================================================
+// Factor the dense operator once with the reference's elimination order; the
+// device kernel then replays the right-hand-side operations of hypre_gselim.
+static void ensure_coarse_factors(hypre_ParAMGData *d)
+{
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   if (pv->d_coarse_lu || !d->A_mat) { return; }
+   hypre_ParCSRMatrix *A = d->A_array[d->num_levels - 1];
+   const int n = (int) A->global_num_rows;
+   std::vector<double> M(d->A_mat, d->A_mat + (size_t) n * n);
+   for (int k = 0; k < n - 1; k++)
+   {
+      if (M[(size_t) k * n + k] != 0.0)
+      {
+         const double divA = 1.0 / M[(size_t) k * n + k];
+         for (int j = k + 1; j < n; j++)
+         {
+            if (M[(size_t) j * n + k] != 0.0)
+            {
+               const double factor = M[(size_t) j * n + k] * divA;
+               for (int m = k + 1; m < n; m++) { M[(size_t) j * n + m] -= factor * M[(size_t) k * n + m]; }
+               M[(size_t) j * n + k] = factor;      // keep the multiplier in the eliminated slot
+            }
+         }
+      }
+      else
+      {
+         for (int j = k + 1; j < n; j++) { M[(size_t) j * n + k] = 0.0; }
+      }
+   }
+   pv->coarse_n = n;
+   pv->coarse_first_row = (int) A->first_row_index;
+   pv->d_coarse_lu = hypre_TAlloc(double, (size_t) std::max(n * n, 1), HYPRE_MEMORY_DEVICE);
+   pv->d_coarse_rhs = hypre_TAlloc(double, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+   hypre_TMemcpy(pv->d_coarse_lu, M.data(), double, (size_t) n * n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+}
+
+HYPRE_Int hypre_GaussElimSolve(hypre_ParAMGData *d, HYPRE_Int level, HYPRE_Int relax_type)
+{
+   (void) relax_type;
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   hypre_ParCSRMatrix *A = d->A_array[level];
+   if (!d->gs_setup) { hypre_GaussElimSetup(d, level, relax_type); }
+   ensure_coarse_factors(d);
+   hipStream_t s = stream();
+   const int n = pv->coarse_n, nloc = A->diag->num_rows;
+   double *fd = d->F_array[level]->local_vector->data;
+   double *ud = d->U_array[level]->local_vector->data;
+   HYPRE_Int nprocs;
+   hypre_MPI_Comm_size(A->comm, &nprocs);
+   if (nprocs == 1)
+   {
+      HIP_CHECK(hipMemcpyAsync(pv->d_coarse_rhs, fd, sizeof(double) * (size_t) n, hipMemcpyDeviceToDevice, s));
+      launch_coarse_solve(pv->d_coarse_lu, pv->d_coarse_rhs, n, s);
+      HIP_CHECK(hipMemcpyAsync(ud, pv->d_coarse_rhs, sizeof(double) * (size_t) n, hipMemcpyDeviceToDevice, s));
+   }
+   else
+   {
+      // gather the (<= max_coarse_size) right-hand side on every rank: zero-fill,
+      // drop the own slice in, sum over ranks (one tiny all-reduce instead of an
+      // Allgatherv through the host, par_gauss_elim.c:575)
+      const hypre_amd_CommOps *o = comm_ops(A->comm);
+      HIP_CHECK(hipMemsetAsync(pv->d_coarse_rhs, 0, sizeof(double) * (size_t) n, s));
+      if (nloc) { HIP_CHECK(hipMemcpyAsync(pv->d_coarse_rhs + pv->coarse_first_row, fd, sizeof(double) * (size_t) nloc, hipMemcpyDeviceToDevice, s)); }
+      if (o->device_buffers) { o->allreduce_sum(o->ctx, pv->d_coarse_rhs, n, 1, (void *) s); }
+      else
+      {
+         std::vector<double> h((size_t) n);
+         hypre_TMemcpy(h.data(), pv->d_coarse_rhs, double, n, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+         o->allreduce_sum(o->ctx, h.data(), n, 0, nullptr);
+         hypre_TMemcpy(pv->d_coarse_rhs, h.data(), double, n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      }
+      launch_coarse_solve(pv->d_coarse_lu, pv->d_coarse_rhs, n, s);
+      if (nloc) { HIP_CHECK(hipMemcpyAsync(ud, pv->d_coarse_rhs + pv->coarse_first_row, sizeof(double) * (size_t) nloc, hipMemcpyDeviceToDevice, s)); }
+   }
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// the cycle
+// ===========================================================================
+namespace {
+
+// where a level's current iterate lives: its home vector or the alternate
+struct LevelVec
+{
+   double *home = nullptr, *alt = nullptr, *cur = nullptr;
+   double *other() const { return cur == home ? alt : home; }
+   void flip() { cur = other(); }
+};
+
+bool is_jacobi_type(int t) { return t == 0 || t == 7 || t == 18; }
+bool is_ge_type(int t) { return t == 9 || t == 19 || t == 98 || t == 99 || t == 198 || t == 199; }
+
+}  // namespace
+
+HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre_ParVector **U_array)
+{
+   hypre_ParAMGData *d = (hypre_ParAMGData *) amg_vdata;
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   const int L = d->num_levels;
+   hypre_ParCSRMatrix **A = d->A_array, **P = d->P_array;
+   HYPRE_AMD_REQUIRE_DEVICE(A[0]->diag->memory_location, "hypre_BoomerAMGCycle(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(U_array[0]->local_vector->memory_location, "hypre_BoomerAMGCycle(u)");
+   HYPRE_AMD_REQUIRE_DEVICE(F_array[0]->local_vector->memory_location, "hypre_BoomerAMGCycle(f)");
+   hipStream_t s = stream();
+   const int saved_sync = handle().sync_compute;
+   handle().sync_compute = 0;
+
+   // alternate solution buffers (allocated on the first cycle, reused afterwards)
+   if ((int) pv->u_alt.size() != L) { pv->u_alt.assign((size_t) L, nullptr); pv->u_alt_len.assign((size_t) L, 0); }
+   std::vector<LevelVec> lv((size_t) L);
+   for (int l = 0; l < L; l++)
+   {
+      const int n = A[l]->diag->num_rows;
+      if (pv->u_alt_len[(size_t) l] < n)
+      {
+         if (pv->u_alt[(size_t) l]) { hypre_Free(pv->u_alt[(size_t) l], HYPRE_MEMORY_DEVICE); }
+         pv->u_alt[(size_t) l] = hypre_TAlloc(double, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+         pv->u_alt_len[(size_t) l] = n;
+      }
+      lv[(size_t) l].home = U_array[l]->local_vector->data;
+      lv[(size_t) l].alt = pv->u_alt[(size_t) l];
+      lv[(size_t) l].cur = lv[(size_t) l].home;
+   }
+   std::vector<int> lev_counter((size_t) L, 0), zeros((size_t) L, 0);
+   zeros[0] = U_array[0]->all_zeros;
+   lev_counter[0] = 1;
+   for (int k = 1; k < L; k++) { lev_counter[(size_t) k] = d->fcycle ? 1 : d->cycle_type; }
+   int fcycle_lev = L - 2, level = 0, cycle_param = 1, err = 0;
+   bool not_finished = true;
+   double *vtemp = d->Vtemp->local_vector->data;
+   double *ztemp = d->Ztemp->local_vector->data;
+   const bool old_version = d->grid_relax_points != nullptr;
+
+   while (not_finished)
+   {
+      const int n = A[level]->diag->num_rows;
+      int num_sweep, relax_type;
+      if (L > 1) { num_sweep = d->num_grid_sweeps[cycle_param]; relax_type = d->grid_relax_type[cycle_param]; }
+      else
+      {
+         num_sweep = d->num_grid_sweeps[0];
+         relax_type = d->user_relax_type;
+         if (relax_type == -1) { relax_type = 6; }
+      }
+      const int *cf = d->CF_marker_array[level] ? d->CF_marker_array[level]->data : nullptr;
+      const double *l1 = d->l1_norms[level] ? d->l1_norms[level]->data : nullptr;
+      const double *fd = F_array[level]->local_vector->data;
+      LevelVec &u = lv[(size_t) level];
+      const double w = d->relax_weight[level];
+
+      for (int j = 0; j < num_sweep; j++)
+      {
+         int relax_points = 0, relax_local = d->relax_order;
+         if (L == 1 && d->max_levels > 1) { relax_points = 0; relax_local = 0; }
+         else if (old_version) { relax_points = d->grid_relax_points[cycle_param][j]; }
+         if (is_ge_type(relax_type))
+         {
+            // the dense solve reads F[level] and writes the home vector
+            hypre_GaussElimSolve(d, level, relax_type);
+            u.cur = u.home;
+            zeros[(size_t) level] = 0;
+         }
+         else if (is_jacobi_type(relax_type))
+         {
+            // point sets of this sweep: all points, or C then F / F then C
+            int pts[2] = {relax_points, 0}, npass = 1;
+            if (!old_version && relax_local == 1 && cycle_param < 3)
+            {
+               npass = 2;
+               pts[0] = cycle_param < 2 ? 1 : -1; pts[1] = -pts[0];
+            }
+            const double *dg = l1;
+            if (relax_type == 0 || !dg)
+            {
+               double *dd = diag_scratch((size_t) std::max(n, 1));
+               launch_diag_first(A[level]->diag->i, A[level]->diag->data, dd, n, s);
+               dg = dd;
+            }
+            for (int pss = 0; pss < npass; pss++)
+            {
+               if (zeros[(size_t) level] && relax_type != 0)
+               {
+                  launch_scaled_div(w, fd, dg, u.cur, pts[pss] ? cf : nullptr, pts[pss], (size_t) n, s);
+               }
+               else
+               {
+                  dev_jacobi_sweep(A[level], fd, cf, pts[pss], w, dg, u.cur, u.other());
+                  u.flip();
+               }
+               zeros[(size_t) level] = 0;
+            }
+         }
+         else
+         {
+            // in-place smoothers go through the public entry on a view of the current buffer
+            hypre_Vector uv; hypre_ParVector up;
+            wrap(&uv, u.cur, n);
+            wrap_par(&up, &uv, A[level]->comm, A[level]->global_num_rows);
+            up.all_zeros = zeros[(size_t) level];
+            hypre_ParVectorSetLocalSize(d->Vtemp, n);
+            hypre_ParVectorSetLocalSize(d->Ztemp, n);
+            if (old_version) { err = hypre_BoomerAMGRelax(A[level], F_array[level], (HYPRE_Int *) cf, relax_type, relax_points, w, d->omega[level], (HYPRE_Real *) l1, &up, d->Vtemp, d->Ztemp); }
+            else { err = hypre_BoomerAMGRelaxIF(A[level], F_array[level], (HYPRE_Int *) cf, relax_type, relax_local, cycle_param, w, d->omega[level], (HYPRE_Real *) l1, &up, d->Vtemp, d->Ztemp); }
+            zeros[(size_t) level] = 0;
+            if (hypre_error_flag) { err = 1; }
+         }
+         if (err) { break; }
+      }
+      if (err) { break; }
+
+      --lev_counter[(size_t) level];
+      if (lev_counter[(size_t) level] >= 0 && level != L - 1)
+      {
+         // descend: u_c = 0 ; r = f - A u ; f_c = P^T r
+         const int fine = level, coarse = level + 1;
+         LevelVec &uc = lv[(size_t) coarse];
+         uc.cur = uc.home;
+         const int nc = A[coarse]->diag->num_rows;
+         // the zero-guess sweep on the coarse level overwrites every row it
+         // relaxes; rows it skips (CF passes, zero diagonals never occur) must
+         // read as zero, so the vector is cleared unless the first coarse
+         // operation is known to overwrite all of it
+         const int ctype = d->grid_relax_type[coarse == L - 1 ? 3 : 1];
+         const bool overwrites_all = (is_jacobi_type(ctype) && ctype != 0 && !(d->relax_order == 1 && coarse != L - 1) &&
+                                      !old_version && d->num_grid_sweeps[coarse == L - 1 ? 3 : 1] > 0) || is_ge_type(ctype);
+         if (!overwrites_all) { launch_set(uc.cur, 0.0, (size_t) nc, s); }
+         zeros[(size_t) coarse] = 1;
+         dev_par_matvec(-1.0, A[fine], u.cur, 1.0, fd, vtemp);
+         dev_par_matvecT(1.0, P[fine], vtemp, 0.0, F_array[coarse]->local_vector->data);
+         ++level;
+         lev_counter[(size_t) level] = std::max(lev_counter[(size_t) level], (int) d->cycle_type);
+         cycle_param = (level == L - 1) ? 3 : 1;
+      }
+      else if (level != 0)
+      {
+         // ascend: u_f += P u_c, written to whichever buffer lets the
+         // post-smoothing sweeps end in the level's home vector
+         const int fine = level - 1, coarse = level;
+         LevelVec &uf = lv[(size_t) fine];
+         int flips = 0;
+         {
+            const int t = d->grid_relax_type[2];
+            if (is_jacobi_type(t))
+            {
+               const int passes = (!old_version && d->relax_order == 1) ? 2 : 1;
+               flips = d->num_grid_sweeps[2] * passes;
+            }
+         }
+         double *target = (flips % 2 == 0) ? uf.home : uf.alt;
+         dev_par_matvec(1.0, P[fine], u.cur, 1.0, uf.cur, target);
+         uf.cur = target;
+         zeros[(size_t) fine] = 0;
+         --level;
+         cycle_param = 2;
+         if (d->fcycle && fcycle_lev == level)
+         {
+            lev_counter[(size_t) level] = std::max(lev_counter[(size_t) level], 1);
+            fcycle_lev--;
+         }
+      }
+      else
+      {
+         not_finished = false;
+      }
+   }
+   // the caller's vector must hold the result
+   if (lv[0].cur != lv[0].home)
+   {
+      launch_copy(lv[0].home, lv[0].cur, (size_t) A[0]->diag->num_rows, s);
+   }
+   U_array[0]->all_zeros = 0;
+   (void) ztemp;
+   handle().sync_compute = saved_sync;
+   maybe_sync();
+   return err;
+}
+
+// ===========================================================================
+// outer solve loop (par_amg_solve.c:22-424)
+// ===========================================================================
+HYPRE_Int hypre_BoomerAMGSolve(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_ParVector *f, hypre_ParVector *u)
+{
+   hypre_ParAMGData *d = (hypre_ParAMGData *) amg_vdata;
+   if (!d) { hypre_error_in_arg(1); return hypre_error_flag; }
+   if (d->num_levels < 1 || !d->A_array)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSolve: setup has not been run");
+      return hypre_error_flag;
+   }
+   HYPRE_AMD_REQUIRE_DEVICE(A->diag->memory_location, "hypre_BoomerAMGSolve(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(f->local_vector->memory_location, "hypre_BoomerAMGSolve(f)");
+   HYPRE_AMD_REQUIRE_DEVICE(u->local_vector->memory_location, "hypre_BoomerAMGSolve(u)");
+   const HYPRE_Real tol = d->tol;
+   const int saved_sync = handle().sync_compute;
+   handle().sync_compute = 0;
+   d->A_array[0] = A; d->F_array[0] = f; d->U_array[0] = u;
+   hypre_ParVector *Vtemp = d->Vtemp;
+   hypre_ParVectorSetLocalSize(Vtemp, A->diag->num_rows);
+
+   HYPRE_Real resid_nrm = 1.0, resid_nrm_init = 1.0, rhs_norm = 0.0, relative_resid = 1.0, old_resid, conv_factor = 0.0;
+   HYPRE_Int cycle_count = 0;
+   if (d->print_level > 1 || d->logging > 1 || tol > 0.)
+   {
+      hypre_ParVectorCopy(f, Vtemp);
+      // r0 = A u - f: alpha = +1, beta = -1 exactly as the reference forms it (:170-189)
+      if (tol > 0) { hypre_ParCSRMatrixMatvec(1.0, A, u, -1.0, Vtemp); }
+      resid_nrm = std::sqrt(hypre_ParVectorInnerProd(Vtemp, Vtemp));
+      HYPRE_Real ieee_check = 0.;
+      if (resid_nrm != 0.) { ieee_check = resid_nrm / resid_nrm; }
+      if (ieee_check != ieee_check)
+      {
+         if (d->print_level > 0)
+         {
+            fprintf(stderr, "ERROR -- hypre_BoomerAMGSolve: INFs and/or NaNs detected in input.\n");
+         }
+         handle().sync_compute = saved_sync;
+         hypre_error(HYPRE_ERROR_GENERIC);
+         return hypre_error_flag;
+      }
+      resid_nrm_init = resid_nrm;
+      if (d->converge_type == 0)
+      {
+         rhs_norm = std::sqrt(hypre_ParVectorInnerProd(f, f));
+         relative_resid = rhs_norm ? resid_nrm_init / rhs_norm : resid_nrm_init;
+      }
+      else { relative_resid = 1.0; }
+   }
+   else { relative_resid = 1.; }
+
+   HYPRE_Int Solve_err_flag = 0;
+   while ((relative_resid >= tol || cycle_count < d->min_iter) && cycle_count < d->max_iter)
+   {
+      d->cycle_op_count = 0;
+      hypre_BoomerAMGCycle(d, d->F_array, d->U_array);
+      if (d->print_level > 1 || d->logging > 1 || tol > 0.)
+      {
+         old_resid = resid_nrm;
+         hypre_ParVectorSetLocalSize(Vtemp, A->diag->num_rows);
+         hypre_ParCSRMatrixMatvecOutOfPlace(1.0, A, u, -1.0, f, Vtemp);
+         resid_nrm = std::sqrt(hypre_ParVectorInnerProd(Vtemp, Vtemp));
+         conv_factor = old_resid ? resid_nrm / old_resid : resid_nrm;
+         if (d->converge_type == 0) { relative_resid = rhs_norm ? resid_nrm / rhs_norm : resid_nrm; }
+         else { relative_resid = resid_nrm / resid_nrm_init; }
+         d->rel_resid_norm = relative_resid;
+      }
+      ++cycle_count;
+      d->num_iterations = cycle_count;
+      if (d->print_level > 1)
+      {
+         HYPRE_Int rank; hypre_MPI_Comm_rank(A->comm, &rank);
+         if (rank == 0) { printf("    Cycle %2d   %e    %f     %e \n", cycle_count, resid_nrm, conv_factor, relative_resid); }
+      }
+   }
+   if (cycle_count == d->max_iter && tol > 0.)
+   {
+      Solve_err_flag = 1;
+      hypre_error(HYPRE_ERROR_CONV);
+   }
+   (void) Solve_err_flag;
+   handle().sync_compute = saved_sync;
+   maybe_sync();
+   return hypre_error_flag;
+}
+
+// ===========================================================================
+// PCG (krylov/pcg.c:318-1000 with the defaults flex = rel_change = 0,
+// recompute_residual = 0, stop_crit = 0, atolf = 0, cf_tol = 0)
+// ===========================================================================
+struct hypre_amd_PCGData
+{
+   hypre_Solver base;
+   MPI_Comm comm;
+   HYPRE_Real tol = 1e-6, a_tol = 0.0;
+   HYPRE_Int max_iter = 1000, two_norm = 0;
+   HYPRE_PtrToSolverFcn precond = nullptr, precond_setup = nullptr;
+   HYPRE_Solver precond_data = nullptr;
+   hypre_ParVector *p = nullptr, *s = nullptr, *r = nullptr;
+   HYPRE_Int num_iterations = 0, converged = 0;
+   HYPRE_Real rel_residual_norm = 0.0;
+};
+
+HYPRE_Int HYPRE_ParCSRPCGCreate(MPI_Comm comm, HYPRE_Solver *solver)
+{
+   hypre_amd_PCGData *d = new hypre_amd_PCGData();
+   memset(&d->base, 0, sizeof(d->base));
+   d->comm = comm;
+   *solver = (HYPRE_Solver) d;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver solver)
+{
+   hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
+   if (!d) { return hypre_error_flag; }
+   hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r);
+   delete d;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_PCGSetTol(HYPRE_Solver s, HYPRE_Real v) { ((hypre_amd_PCGData *) s)->tol = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGSetAbsoluteTol(HYPRE_Solver s, HYPRE_Real v) { ((hypre_amd_PCGData *) s)->a_tol = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGSetMaxIter(HYPRE_Solver s, HYPRE_Int v) { ((hypre_amd_PCGData *) s)->max_iter = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGSetTwoNorm(HYPRE_Solver s, HYPRE_Int v) { ((hypre_amd_PCGData *) s)->two_norm = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn precond, HYPRE_PtrToSolverFcn precond_setup,
+                              HYPRE_Solver precond_solver)
+{
+   hypre_amd_PCGData *d = (hypre_amd_PCGData *) s;
+   d->precond = precond; d->precond_setup = precond_setup; d->precond_data = precond_solver;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_PCGGetNumIterations(HYPRE_Solver s, HYPRE_Int *v) { *v = ((hypre_amd_PCGData *) s)->num_iterations; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v) { *v = ((hypre_amd_PCGData *) s)->rel_residual_norm; return hypre_error_flag; }
+
+HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
+   hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r);
+   const HYPRE_MemoryLocation loc = x->local_vector->memory_location;
+   auto mk = [&]() { hypre_ParVector *v = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts); hypre_ParVectorInitialize_v2(v, loc); return v; };
+   d->p = mk(); d->s = mk(); d->r = mk();
+   if (d->precond_setup) { d->precond_setup(d->precond_data, A, b, x); }
+   return hypre_error_flag;
+}
+
+HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
+{
+   hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
+   hypre_ParVector *p = d->p, *s = d->s, *r = d->r;
+   const HYPRE_Real r_tol = d->tol, a_tol = d->a_tol;
+   HYPRE_Real alpha, beta, gamma, gamma_old, bi_prod, eps, sdotp, i_prod = 0.0, i_prod_0 = 0.0;
+   HYPRE_Int i = 0;
+   d->converged = 0;
+   const int saved_sync = handle().sync_compute;
+   handle().sync_compute = 0;
+   auto precond = [&](hypre_ParVector *rhs, hypre_ParVector *sol)
+   {
+      hypre_ParVectorSetZeros(sol);       // ClearVector: all_zeros = 1 (par_vector.c:335-340)
+      if (d->precond) { d->precond(d->precond_data, A, rhs, sol); }
+      else { hypre_ParVectorCopy(rhs, sol); }
+   };
+   if (d->two_norm) { bi_prod = hypre_ParVectorInnerProd(b, b); }
+   else { precond(b, p); bi_prod = hypre_ParVectorInnerProd(p, b); }
+   HYPRE_Real ieee_check = 0.;
+   if (bi_prod != 0.) { ieee_check = bi_prod / bi_prod; }
+   if (ieee_check != ieee_check) { handle().sync_compute = saved_sync; hypre_error(HYPRE_ERROR_GENERIC); return hypre_error_flag; }
+   eps = r_tol * r_tol;
+   if (bi_prod > 0.0) { eps = std::max(r_tol * r_tol, a_tol * a_tol / bi_prod); }
+   else
+   {
+      hypre_ParVectorCopy(b, x);
+      d->num_iterations = 0; d->rel_residual_norm = 0.0;
+      handle().sync_compute = saved_sync;
+      return hypre_error_flag;
+   }
+   hypre_ParVectorCopy(b, r);
+   hypre_ParCSRMatrixMatvec(-1.0, A, x, 1.0, r);
+   precond(r, p);
+   gamma = hypre_ParVectorInnerProd(r, p);
+   if (gamma != 0.) { ieee_check = gamma / gamma; }
+   if (ieee_check != ieee_check) { handle().sync_compute = saved_sync; hypre_error(HYPRE_ERROR_GENERIC); return hypre_error_flag; }
+   i_prod_0 = d->two_norm ? hypre_ParVectorInnerProd(r, r) : gamma;
+   while ((i + 1) <= d->max_iter)
+   {
+      i++;
+      hypre_ParCSRMatrixMatvec(1.0, A, p, 0.0, s);
+      sdotp = hypre_ParVectorInnerProd(s, p);
+      if (sdotp == 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Zero sdotp value in PCG"); if (i == 1) { i_prod = i_prod_0; } break; }
+      alpha = gamma / sdotp;
+      if (alpha <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero alpha value in PCG"); if (i == 1) { i_prod = i_prod_0; } break; }
+      gamma_old = gamma;
+      hypre_ParVectorAxpy(alpha, p, x);
+      hypre_ParVectorAxpy(-alpha, s, r);
+      precond(r, s);
+      gamma = hypre_ParVectorInnerProd(r, s);
+      i_prod = d->two_norm ? hypre_ParVectorInnerProd(r, r) : gamma;
+      if (i_prod / bi_prod < eps) { d->converged = 1; break; }
+      if (gamma <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero gamma value in PCG"); break; }
+      beta = gamma / gamma_old;
+      hypre_ParVectorScale(beta, p);
+      hypre_ParVectorAxpy(1.0, s, p);
+   }
+   if (i >= d->max_iter && (i_prod / bi_prod) >= eps && eps > 0)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_CONV, "Reached max iterations in PCG before convergence");
+   }
+   d->num_iterations = i;
+   d->rel_residual_norm = std::sqrt(i_prod / bi_prod);
+   handle().sync_compute = saved_sync;
+   maybe_sync();
+   return hypre_error_flag;
+}
+
+}  // extern "C"

@@ -445,8 +445,9 @@ hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate_v2(HYPRE_Int job, hypre_Par
    const hypre_amd_CommOps *o = comm_ops(pkg->comm);
    if (!o || o->size <= 1) { return h; }
 
+   // jobs 1/2: HYPRE_Complex, 11/12: HYPRE_Int, 21/22: HYPRE_BigInt (par_csr_communication.c:483-614)
    const size_t esz = (job == 11 || job == 12) ? sizeof(HYPRE_Int) : sizeof(HYPRE_Complex);
-   const bool forward = (job == 1 || job == 11);
+   const bool forward = (job % 10 == 1);
    const HYPRE_Int ns = forward ? pkg->num_sends : pkg->num_recvs;
    const HYPRE_Int nr = forward ? pkg->num_recvs : pkg->num_sends;
    const HYPRE_Int *sprocs  = forward ? pkg->send_procs : pkg->recv_procs;

@@ -1,0 +1,277 @@
+/*
+ * hypre_amd — BoomerAMG: relaxation, V-cycle, solve (the hot path), plus the
+ * host-side setup that produces the hierarchy the cycle runs on, and the PCG
+ * caller.
+ *
+ * Functions replace (paths relative to /root/reference/src):
+ *   parcsr_ls/par_relax.c:24-173               hypre_BoomerAMGRelax (dispatcher)
+ *   parcsr_ls/par_relax.c:1178-1254,180-369    Jacobi / l1-Jacobi (relax 7, 18, 0)
+ *   parcsr_ls/par_relax.c:1506-1666, par_relax_device.c:97-155   two-stage GS (11, 12)
+ *   parcsr_ls/par_relax.c:691-1377, par_relax_device.c:19-90     hybrid GS family (3,4,6,8,13,14,88,89)
+ *   parcsr_ls/par_relax_interface.c:20-117     hypre_BoomerAMGRelaxIF, L1_Jacobi, FCFJacobi
+ *   parcsr_ls/par_cycle.c:23-803               hypre_BoomerAMGCycle
+ *   parcsr_ls/par_amg_solve.c:22-424           hypre_BoomerAMGSolve
+ *   parcsr_ls/HYPRE_parcsr_amg.c:64-91         HYPRE_BoomerAMGSolve
+ *   parcsr_ls/par_gauss_elim.c:457-697         hypre_GaussElimSolve (coarsest level)
+ *   parcsr_ls/ams.c:527-830                    hypre_ParCSRComputeL1Norms
+ *   parcsr_ls/par_amg.c / HYPRE_parcsr_amg.c   Create / Destroy / Set* / Get*
+ *   parcsr_ls/par_amg_setup.c:28-4046          hypre_BoomerAMGSetup (host; "next" row of the scope table)
+ *   krylov/pcg.c:318-1000 + parcsr_ls/HYPRE_parcsr_pcg.c   PCG with a BoomerAMG preconditioner
+ *
+ * hypre_ParAMGData below is the solve- and setup-relevant SLICE of the
+ * reference struct (parcsr_ls/par_amg.h:19-295): member names and the
+ * accessor macros match, the byte layout does not (the reference struct
+ * carries ~250 members for solvers outside this path).  Code that touches
+ * the solver object only through the HYPRE_BoomerAMG* calls or the
+ * hypre_ParAMGData* macros is source compatible; see INTEGRATION.md.
+ */
+#ifndef HYPRE_AMD_PARCSR_LS_H
+#define HYPRE_AMD_PARCSR_LS_H
+
+#include "hypre_amd_parcsr_mv.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct
+{
+   hypre_Solver          base;               /* setup / solve / destroy */
+   HYPRE_MemoryLocation  memory_location;    /* where the hierarchy lives after setup */
+
+   /* setup parameters (par_amg.c:162-316 defaults) */
+   HYPRE_Int      max_levels;
+   HYPRE_Real     strong_threshold;
+   HYPRE_Real     max_row_sum;
+   HYPRE_Real     trunc_factor;
+   HYPRE_Int      measure_type;
+   HYPRE_Int      coarsen_type;              /* 8 PMIS, 9 PMIS(seq rand), 10 HMIS */
+   HYPRE_Int      P_max_elmts;
+   HYPRE_Int      interp_type;               /* 6 ext+i, 3 direct */
+   HYPRE_Int      agg_num_levels;
+   HYPRE_Int      max_coarse_size;
+   HYPRE_Int      min_coarse_size;
+   HYPRE_Int      keepTranspose;
+   HYPRE_Int      num_functions;
+
+   /* solve parameters */
+   HYPRE_Int      max_iter;
+   HYPRE_Int      min_iter;
+   HYPRE_Int      fcycle;
+   HYPRE_Int      cycle_type;
+   HYPRE_Int     *num_grid_sweeps;           /* [4] */
+   HYPRE_Int     *grid_relax_type;           /* [4] */
+   HYPRE_Int    **grid_relax_points;         /* NULL unless set by the user */
+   HYPRE_Int      relax_order;
+   HYPRE_Int      user_coarse_relax_type;
+   HYPRE_Int      user_relax_type;
+   HYPRE_Int      user_num_sweeps;
+   HYPRE_Real     user_relax_weight;
+   HYPRE_Real     outer_wt;
+   HYPRE_Real    *relax_weight;              /* [max_levels] */
+   HYPRE_Real    *omega;                     /* [max_levels] */
+   HYPRE_Int      converge_type;
+   HYPRE_Real     tol;
+
+   /* hierarchy */
+   hypre_ParCSRMatrix  *A;
+   hypre_ParCSRMatrix **A_array;
+   hypre_ParVector    **F_array;
+   hypre_ParVector    **U_array;
+   hypre_ParCSRMatrix **P_array;
+   hypre_ParCSRMatrix **R_array;             /* == P_array (restriction is P^T) */
+   hypre_IntArray     **CF_marker_array;
+   HYPRE_Int            num_levels;
+   hypre_Vector       **l1_norms;
+
+   /* work vectors (fine-grid sized, re-sized per level in place) */
+   hypre_ParVector   *Vtemp;
+   hypre_ParVector   *Rtemp;
+   hypre_ParVector   *Ptemp;
+   hypre_ParVector   *Ztemp;
+   HYPRE_Real         cycle_op_count;
+
+   /* coarsest-level dense solve (par_gauss_elim.c) */
+   HYPRE_Int          gs_setup;
+   HYPRE_Real        *A_mat;                 /* dense coarse operator, row major, host */
+   HYPRE_Real        *b_vec;
+
+   /* log */
+   HYPRE_Int        logging;
+   HYPRE_Int        num_iterations;
+   HYPRE_Real       rel_resid_norm;
+   HYPRE_Int        print_level;
+   HYPRE_Int        debug_flag;
+
+   /* library-private state (device plans, graphs, mixed-precision copies) */
+   void            *amd_private;
+} hypre_ParAMGData;
+
+#define hypre_ParAMGDataMemoryLocation(d)   ((d)->memory_location)
+#define hypre_ParAMGDataMaxLevels(d)        ((d)->max_levels)
+#define hypre_ParAMGDataStrongThreshold(d)  ((d)->strong_threshold)
+#define hypre_ParAMGDataMaxRowSum(d)        ((d)->max_row_sum)
+#define hypre_ParAMGDataTruncFactor(d)      ((d)->trunc_factor)
+#define hypre_ParAMGDataCoarsenType(d)      ((d)->coarsen_type)
+#define hypre_ParAMGDataPMaxElmts(d)        ((d)->P_max_elmts)
+#define hypre_ParAMGDataInterpType(d)       ((d)->interp_type)
+#define hypre_ParAMGDataMaxCoarseSize(d)    ((d)->max_coarse_size)
+#define hypre_ParAMGDataMinCoarseSize(d)    ((d)->min_coarse_size)
+#define hypre_ParAMGDataKeepTranspose(d)    ((d)->keepTranspose)
+#define hypre_ParAMGDataMaxIter(d)          ((d)->max_iter)
+#define hypre_ParAMGDataMinIter(d)          ((d)->min_iter)
+#define hypre_ParAMGDataFCycle(d)           ((d)->fcycle)
+#define hypre_ParAMGDataCycleType(d)        ((d)->cycle_type)
+#define hypre_ParAMGDataNumGridSweeps(d)    ((d)->num_grid_sweeps)
+#define hypre_ParAMGDataGridRelaxType(d)    ((d)->grid_relax_type)
+#define hypre_ParAMGDataGridRelaxPoints(d)  ((d)->grid_relax_points)
+#define hypre_ParAMGDataRelaxOrder(d)       ((d)->relax_order)
+#define hypre_ParAMGDataUserRelaxType(d)    ((d)->user_relax_type)
+#define hypre_ParAMGDataRelaxWeight(d)      ((d)->relax_weight)
+#define hypre_ParAMGDataOmega(d)            ((d)->omega)
+#define hypre_ParAMGDataConvergeType(d)     ((d)->converge_type)
+#define hypre_ParAMGDataTol(d)              ((d)->tol)
+#define hypre_ParAMGDataAArray(d)           ((d)->A_array)
+#define hypre_ParAMGDataFArray(d)           ((d)->F_array)
+#define hypre_ParAMGDataUArray(d)           ((d)->U_array)
+#define hypre_ParAMGDataPArray(d)           ((d)->P_array)
+#define hypre_ParAMGDataRArray(d)           ((d)->R_array)
+#define hypre_ParAMGDataCFMarkerArray(d)    ((d)->CF_marker_array)
+#define hypre_ParAMGDataNumLevels(d)        ((d)->num_levels)
+#define hypre_ParAMGDataL1Norms(d)          ((d)->l1_norms)
+#define hypre_ParAMGDataVtemp(d)            ((d)->Vtemp)
+#define hypre_ParAMGDataRtemp(d)            ((d)->Rtemp)
+#define hypre_ParAMGDataPtemp(d)            ((d)->Ptemp)
+#define hypre_ParAMGDataZtemp(d)            ((d)->Ztemp)
+#define hypre_ParAMGDataCycleOpCount(d)     ((d)->cycle_op_count)
+#define hypre_ParAMGDataNumIterations(d)    ((d)->num_iterations)
+#define hypre_ParAMGDataRelativeResidualNorm(d) ((d)->rel_resid_norm)
+#define hypre_ParAMGDataPrintLevel(d)       ((d)->print_level)
+#define hypre_ParAMGDataLogging(d)          ((d)->logging)
+
+/* ---- life cycle and parameters (HYPRE_parcsr_amg.c) ---- */
+HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver);
+HYPRE_Int HYPRE_BoomerAMGDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_BoomerAMGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_BoomerAMGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_BoomerAMGSetMaxLevels(HYPRE_Solver solver, HYPRE_Int max_levels);
+HYPRE_Int HYPRE_BoomerAMGSetMaxCoarseSize(HYPRE_Solver solver, HYPRE_Int max_coarse_size);
+HYPRE_Int HYPRE_BoomerAMGSetMinCoarseSize(HYPRE_Solver solver, HYPRE_Int min_coarse_size);
+HYPRE_Int HYPRE_BoomerAMGSetStrongThreshold(HYPRE_Solver solver, HYPRE_Real strong_threshold);
+HYPRE_Int HYPRE_BoomerAMGSetMaxRowSum(HYPRE_Solver solver, HYPRE_Real max_row_sum);
+HYPRE_Int HYPRE_BoomerAMGSetCoarsenType(HYPRE_Solver solver, HYPRE_Int coarsen_type);
+HYPRE_Int HYPRE_BoomerAMGSetInterpType(HYPRE_Solver solver, HYPRE_Int interp_type);
+HYPRE_Int HYPRE_BoomerAMGSetTruncFactor(HYPRE_Solver solver, HYPRE_Real trunc_factor);
+HYPRE_Int HYPRE_BoomerAMGSetPMaxElmts(HYPRE_Solver solver, HYPRE_Int P_max_elmts);
+HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver solver, HYPRE_Int keepTranspose);
+HYPRE_Int HYPRE_BoomerAMGSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_BoomerAMGSetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);
+HYPRE_Int HYPRE_BoomerAMGSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
+HYPRE_Int HYPRE_BoomerAMGSetConvergeType(HYPRE_Solver solver, HYPRE_Int type);
+HYPRE_Int HYPRE_BoomerAMGSetCycleType(HYPRE_Solver solver, HYPRE_Int cycle_type);
+HYPRE_Int HYPRE_BoomerAMGSetFCycle(HYPRE_Solver solver, HYPRE_Int fcycle);
+HYPRE_Int HYPRE_BoomerAMGSetNumSweeps(HYPRE_Solver solver, HYPRE_Int num_sweeps);
+HYPRE_Int HYPRE_BoomerAMGSetCycleNumSweeps(HYPRE_Solver solver, HYPRE_Int num_sweeps, HYPRE_Int k);
+HYPRE_Int HYPRE_BoomerAMGSetRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type);
+HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_type, HYPRE_Int k);
+HYPRE_Int HYPRE_BoomerAMGSetRelaxOrder(HYPRE_Solver solver, HYPRE_Int relax_order);
+HYPRE_Int HYPRE_BoomerAMGSetRelaxWt(HYPRE_Solver solver, HYPRE_Real relax_weight);
+HYPRE_Int HYPRE_BoomerAMGSetOuterWt(HYPRE_Solver solver, HYPRE_Real omega);
+HYPRE_Int HYPRE_BoomerAMGSetPrintLevel(HYPRE_Solver solver, HYPRE_Int print_level);
+HYPRE_Int HYPRE_BoomerAMGSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
+HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *rel_resid_norm);
+
+/* library extensions (no reference counterpart) */
+/* memory location the hierarchy is placed in by Setup (default: device) */
+HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver solver, HYPRE_MemoryLocation location);
+/* OpenMP thread count the host setup emulates in its thread-partitioned loops
+ * (0 = 1; results of the hybrid smoothers' block partition depend on it) */
+HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_threads);
+/* store matrix values of every level in fp32 for the SpMV / smoother kernels;
+ * residuals on level 0 stay fp64 (mixed-precision configuration) */
+HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on);
+/* grid / operator complexity of the last setup */
+HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
+/* algorithmic HBM bytes of one cycle on the current hierarchy (SURVEY §8d formula) */
+HYPRE_Real hypre_amd_BoomerAMGCycleBytes(HYPRE_Solver solver);
+/* level accessors for tests / the oracle harness */
+HYPRE_Int hypre_amd_BoomerAMGGetNumLevels(HYPRE_Solver solver);
+hypre_ParCSRMatrix *hypre_amd_BoomerAMGGetA(HYPRE_Solver solver, HYPRE_Int level);
+hypre_ParCSRMatrix *hypre_amd_BoomerAMGGetP(HYPRE_Solver solver, HYPRE_Int level);
+hypre_IntArray     *hypre_amd_BoomerAMGGetCFMarker(HYPRE_Solver solver, HYPRE_Int level);
+hypre_Vector       *hypre_amd_BoomerAMGGetL1Norms(HYPRE_Solver solver, HYPRE_Int level);
+HYPRE_Int hypre_amd_BoomerAMGGetGridRelaxType(HYPRE_Solver solver, HYPRE_Int k);
+HYPRE_Int hypre_amd_BoomerAMGGetNumGridSweeps(HYPRE_Solver solver, HYPRE_Int k);
+
+/* ---- setup building blocks (host) ---- */
+HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_ParVector *f, hypre_ParVector *u);
+HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real strength_threshold, HYPRE_Real max_row_sum,
+                                 HYPRE_Int num_functions, HYPRE_Int *dof_func, hypre_ParCSRMatrix **S_ptr);
+HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *A, HYPRE_Int CF_init,
+                                     HYPRE_Int debug_flag, hypre_IntArray **CF_marker_ptr);
+HYPRE_Int hypre_BoomerAMGCoarsenHMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *A, HYPRE_Int measure_type,
+                                     HYPRE_Int cut_factor, HYPRE_Int debug_flag, hypre_IntArray **CF_marker_ptr);
+HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                          HYPRE_BigInt *num_cpts_global, HYPRE_Int num_functions,
+                                          HYPRE_Int *dof_func, HYPRE_Int debug_flag, HYPRE_Real trunc_factor,
+                                          HYPRE_Int max_elmts, hypre_ParCSRMatrix **P_ptr);
+HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                        HYPRE_BigInt *num_cpts_global, HYPRE_Int num_functions,
+                                        HYPRE_Int *dof_func, HYPRE_Int debug_flag, HYPRE_Real trunc_factor,
+                                        HYPRE_Int max_elmts, HYPRE_Int interp_type, hypre_ParCSRMatrix **P_ptr);
+HYPRE_Int hypre_BoomerAMGInterpTruncation(hypre_ParCSRMatrix *P, HYPRE_Real trunc_factor, HYPRE_Int max_elmts);
+HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A,
+                                               hypre_ParCSRMatrix *P, HYPRE_Int keepTranspose,
+                                               hypre_ParCSRMatrix **RAP_ptr);
+HYPRE_Int hypre_ParCSRComputeL1Norms(hypre_ParCSRMatrix *A, HYPRE_Int option, HYPRE_Int *cf_marker,
+                                     HYPRE_Real **l1_norm_ptr);
+
+/* ---- the hot path ---- */
+HYPRE_Int hypre_BoomerAMGRelax(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                               HYPRE_Int relax_type, HYPRE_Int relax_points, HYPRE_Real relax_weight,
+                               HYPRE_Real omega, HYPRE_Real *l1_norms, hypre_ParVector *u,
+                               hypre_ParVector *Vtemp, hypre_ParVector *Ztemp);
+HYPRE_Int hypre_BoomerAMGRelaxIF(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                                 HYPRE_Int relax_type, HYPRE_Int relax_order, HYPRE_Int cycle_param,
+                                 HYPRE_Real relax_weight, HYPRE_Real omega, HYPRE_Real *l1_norms,
+                                 hypre_ParVector *u, hypre_ParVector *Vtemp, hypre_ParVector *Ztemp);
+HYPRE_Int hypre_ParCSRRelax_L1_Jacobi(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                                      HYPRE_Int relax_points, HYPRE_Real relax_weight, HYPRE_Real *l1_norms,
+                                      hypre_ParVector *u, hypre_ParVector *Vtemp);
+HYPRE_Int hypre_BoomerAMGRelax_FCFJacobi(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
+                                         HYPRE_Real relax_weight, hypre_ParVector *u, hypre_ParVector *Vtemp);
+HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f,
+                                                        HYPRE_Real relax_weight, HYPRE_Real omega,
+                                                        HYPRE_Real *A_diag_diag, hypre_ParVector *u,
+                                                        hypre_ParVector *r, hypre_ParVector *z,
+                                                        HYPRE_Int num_inner_iters);
+HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f,
+                                                      HYPRE_Int *cf_marker, HYPRE_Int relax_points,
+                                                      HYPRE_Real relax_weight, HYPRE_Real omega,
+                                                      HYPRE_Real *l1_norms, hypre_ParVector *u,
+                                                      hypre_ParVector *Vtemp, hypre_ParVector *Ztemp,
+                                                      HYPRE_Int GS_order, HYPRE_Int Symm);
+HYPRE_Int hypre_GaussElimSetup(hypre_ParAMGData *amg_data, HYPRE_Int level, HYPRE_Int relax_type);
+HYPRE_Int hypre_GaussElimSolve(hypre_ParAMGData *amg_data, HYPRE_Int level, HYPRE_Int relax_type);
+HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre_ParVector **U_array);
+HYPRE_Int hypre_BoomerAMGSolve(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_ParVector *f, hypre_ParVector *u);
+
+/* ---- PCG with BoomerAMG as preconditioner (the caller in the benchmark configs) ---- */
+HYPRE_Int HYPRE_ParCSRPCGCreate(MPI_Comm comm, HYPRE_Solver *solver);
+HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_PCGSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_PCGSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_PCGSetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);
+HYPRE_Int HYPRE_PCGSetTwoNorm(HYPRE_Solver solver, HYPRE_Int two_norm);
+HYPRE_Int HYPRE_PCGSetPrecond(HYPRE_Solver solver, HYPRE_PtrToSolverFcn precond,
+                              HYPRE_PtrToSolverFcn precond_setup, HYPRE_Solver precond_solver);
+HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_PCGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_PCGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

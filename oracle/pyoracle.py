@@ -247,3 +247,80 @@ def relax(A, f, cf_marker, relax_type, relax_points, w, omega, l1, u, num_thread
     err = load().oracle_relax(C.byref(A.c), _rp(f), _ip(cf) if cf is not None else None, relax_type,
                               relax_points, w, omega, _rp(l1), _rp(u), _rp(vtemp), num_threads, C.byref(az))
     return err
+
+
+# ---------------------------------------------------------------------------
+# bridges from the product's objects (fetched through the C ABI) to oracle structs
+# ---------------------------------------------------------------------------
+def par_from_handles(handles):
+    """handles: list (one per rank, rank order) of hypre_ParCSRMatrix pointers
+    (ctypes POINTER(ParCSRMatrix) or raw addresses) living in this process."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    blocks, rs, cs = [], [], []
+    last_r = last_c = 0
+    for h in handles:
+        if not isinstance(h, C.POINTER(B.ParCSRMatrix)):
+            h = C.cast(h, C.POINTER(B.ParCSRMatrix))
+        m = h.contents
+        di, dj, da = B.csr_to_arrays(m.diag)
+        oi, oj, oa = B.csr_to_arrays(m.offd)
+        nco = m.offd.contents.num_cols
+        cmap = np.array([m.col_map_offd[k] for k in range(nco)], dtype=np.int64)
+        rn = np.nonzero(np.diff(oi))[0].astype(np.int32)
+        with_rn = rn if (0 < len(rn) < m.offd.contents.num_rows) else None
+        d = Csr(m.diag.contents.num_rows, m.diag.contents.num_cols, di, dj, da)
+        o = Csr(m.offd.contents.num_rows, nco, oi, oj, oa, with_rn)
+        blocks.append((d, o, cmap))
+        rs.append(int(m.row_starts[0])); cs.append(int(m.col_starts[0]))
+        last_r, last_c = int(m.row_starts[1]), int(m.col_starts[1])
+    rs.append(last_r); cs.append(last_c)
+    return Par(blocks, rs, cs)
+
+
+def amg_from_solvers(solvers, num_threads=1):
+    """Build the oracle's hierarchy from one product solver per (virtual) rank."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    L = B.load_library()
+    nl = L.hypre_amd_BoomerAMGGetNumLevels(solvers[0])
+    A_levels, P_levels, cfs, l1s = [], [], [], []
+    for l in range(nl):
+        A_levels.append(par_from_handles([L.hypre_amd_BoomerAMGGetA(s, l) for s in solvers]))
+        if l < nl - 1:
+            P_levels.append(par_from_handles([L.hypre_amd_BoomerAMGGetP(s, l) for s in solvers]))
+        cf_parts, l1_parts = [], []
+        for s in solvers:
+            cfp = L.hypre_amd_BoomerAMGGetCFMarker(s, l)
+            if cfp:
+                ia = C.cast(cfp, C.POINTER(B.IntArray)).contents
+                cf_parts.append(B.fetch(ia.data, ia.size, np.int32, ia.memory_location))
+            lp = L.hypre_amd_BoomerAMGGetL1Norms(s, l)
+            if lp:
+                v = C.cast(lp, C.POINTER(B.Vector)).contents
+                l1_parts.append(B.fetch(v.data, v.size, np.float64, v.memory_location))
+        cfs.append(np.concatenate(cf_parts) if cf_parts else None)
+        l1s.append(np.concatenate(l1_parts) if l1_parts else None)
+    s0 = solvers[0]
+    sweeps = [L.hypre_amd_BoomerAMGGetNumGridSweeps(s0, k) for k in range(4)]
+    types = [L.hypre_amd_BoomerAMGGetGridRelaxType(s0, k) for k in range(4)]
+    d = C.cast(s0, C.POINTER(AmgDataView)).contents
+    rw = np.array([d.relax_weight[k] for k in range(nl)])
+    om = np.array([d.omega[k] for k in range(nl)])
+    return Amg(A_levels, P_levels, cfs, l1s, sweeps, types, relax_order=d.relax_order, relax_weight=rw, omega=om,
+               cycle_type=d.cycle_type, fcycle=d.fcycle, num_threads=num_threads, max_levels=d.max_levels,
+               user_relax_type=d.user_relax_type)
+
+
+class AmgDataView(C.Structure):
+    """Leading members of hypre_ParAMGData (include/hypre_amd_parcsr_ls.h) up to omega."""
+    _fields_ = [("setup", C.c_void_p), ("solve", C.c_void_p), ("destroy", C.c_void_p), ("memory_location", C.c_int),
+                ("max_levels", C.c_int), ("strong_threshold", C.c_double), ("max_row_sum", C.c_double),
+                ("trunc_factor", C.c_double), ("measure_type", C.c_int), ("coarsen_type", C.c_int),
+                ("P_max_elmts", C.c_int), ("interp_type", C.c_int), ("agg_num_levels", C.c_int),
+                ("max_coarse_size", C.c_int), ("min_coarse_size", C.c_int), ("keepTranspose", C.c_int),
+                ("num_functions", C.c_int), ("max_iter", C.c_int), ("min_iter", C.c_int), ("fcycle", C.c_int),
+                ("cycle_type", C.c_int), ("num_grid_sweeps", IntP), ("grid_relax_type", IntP),
+                ("grid_relax_points", C.c_void_p), ("relax_order", C.c_int), ("user_coarse_relax_type", C.c_int),
+                ("user_relax_type", C.c_int), ("user_num_sweeps", C.c_int), ("user_relax_weight", C.c_double),
+                ("outer_wt", C.c_double), ("relax_weight", RealP), ("omega", RealP)]

@@ -1,0 +1,88 @@
+"""CPU: the C-ABI library loads, exports every function include/*.h declares, and the
+ctypes prototype tables cover exactly that set (no compute call is made)."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    names = set()
+    pat = re.compile(r"^\s*(?:[A-Za-z_][\w\s\*]*?)\b((?:hypre|HYPRE|hypreDevice|Generate)\w*)\s*\(", re.M)
+    for fn in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        txt = open(os.path.join(ROOT, "include", fn)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith("#"))
+        txt = re.sub(r"typedef\s[^;{]*\(\s*\*[^;]*;", "", txt)          # function-pointer typedefs
+        txt = re.sub(r"typedef\s+struct[^{;]*\{.*?\}[^;]*;", "", txt, flags=re.S)   # struct bodies (callback members)
+        for m in pat.finditer(txt):
+            name = m.group(1)
+            if name.startswith("HYPRE_PtrTo"):
+                continue
+            names.add(name)
+    return names
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from hypre_amd import binding, parcsr_ls_binding
+    declared = _declared()
+    assert len(declared) > 150
+    bound = set(binding.PROTOTYPES) | set(parcsr_ls_binding.PROTOTYPES)
+    missing_export = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing_export, missing_export
+    assert not (declared - bound), sorted(declared - bound)
+    assert not (bound - declared), sorted(bound - declared)
+
+
+def test_struct_sizes_match_headers(lib):
+    """The ctypes mirrors must have the C layout (LP64)."""
+    import subprocess
+    import tempfile
+    from hypre_amd import binding as B
+    # the headers must be plain C: compile a probe with gcc and compare layouts
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "hypre_amd_parcsr_ls.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hypre_CSRMatrix), sizeof(hypre_Vector),
+         sizeof(hypre_ParCSRMatrix), sizeof(hypre_ParVector), sizeof(hypre_ParCSRCommPkg),
+         offsetof(hypre_ParCSRMatrix, comm_pkg), offsetof(hypre_ParVector, all_zeros),
+         sizeof(hypre_amd_CommOps));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "probe.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(td, "probe.c"), "-o", os.path.join(td, "probe")], check=True)
+        out = subprocess.run([os.path.join(td, "probe")], capture_output=True, text=True, check=True).stdout.split()
+    sizes = [int(v) for v in out]
+    assert sizes[0] == C.sizeof(B.CSRMatrix)
+    assert sizes[1] == C.sizeof(B.Vector)
+    assert sizes[2] == C.sizeof(B.ParCSRMatrix)
+    assert sizes[3] == C.sizeof(B.ParVector)
+    assert sizes[4] == C.sizeof(B.CommPkg)
+    assert sizes[5] == B.ParCSRMatrix.comm_pkg.offset
+    assert sizes[6] == B.ParVector.all_zeros.offset
+    assert sizes[7] == C.sizeof(B.CommOps)
+    m = lib.hypre_CSRMatrixCreate(3, 4, 5)
+    assert (m.contents.num_rows, m.contents.num_cols, m.contents.num_nonzeros, m.contents.owns_data) == (3, 4, 5, 1)
+    lib.hypre_CSRMatrixDestroy(m)
+    v = lib.hypre_ParVectorCreate(0, 10, None)
+    assert v.contents.global_size == 10 and v.contents.local_vector.contents.size == 10
+    lib.hypre_ParVectorDestroy(v)
+
+
+def test_error_word_convention(lib):
+    from hypre_amd import binding as B
+    lib.HYPRE_ClearAllErrors()
+    assert lib.HYPRE_BoomerAMGSolve(None, None, None, None) != 0       # arg 2 (A) is checked first
+    assert lib.HYPRE_GetError() & 4 and lib.HYPRE_GetErrorArg() == 2
+    lib.HYPRE_ClearAllErrors()
+    s = C.c_void_p()
+    lib.HYPRE_BoomerAMGCreate(C.byref(s))
+    lib.HYPRE_BoomerAMGSetNumSweeps(s, 0)                               # invalid -> arg 2
+    assert lib.HYPRE_GetErrorArg() == 2
+    lib.HYPRE_ClearAllErrors()
+    lib.HYPRE_BoomerAMGDestroy(s)

@@ -1,0 +1,199 @@
+"""Parity of the device solve phase (relaxation, V/W/F cycle, solve, PCG) against
+the CPU oracle on the SAME hierarchy (built once by the library's host setup and
+handed to both).  fp64.  Tolerances: one sweep / one cycle agree to 1e-12
+relative in the max norm (different summation association only); complete
+solves must take the identical number of iterations and agree on the final
+relative residual to 1e-6 relative (hard part 5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import rand_vector
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(lib, **kw):
+    from hypre_amd import binding as B, ij
+    opt = ij.IJOptions(**kw)
+    A = ij.build_matrix(opt)
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+    lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+    B.check()
+    lib.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+    return opt, A, s
+
+
+def _level(lib, s, l):
+    from hypre_amd import binding as B
+    A = C.cast(lib.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
+    cfp = lib.hypre_amd_BoomerAMGGetCFMarker(s, l)
+    l1p = lib.hypre_amd_BoomerAMGGetL1Norms(s, l)
+    cf = C.cast(cfp, C.POINTER(B.IntArray)).contents.data if cfp else None
+    l1 = C.cast(l1p, C.POINTER(B.Vector)).contents.data if l1p else None
+    return A, cf, l1
+
+
+@pytest.mark.parametrize("relax_type,relax_points,w,zero", [
+    (18, 0, 1.0, False), (18, 0, 0.8, True), (18, 1, 1.0, False), (18, -1, 0.9, False), (18, 1, 1.0, True),
+    (7, 0, 0.7, False), (7, 0, 1.0, True), (0, 0, 0.6, False), (0, 1, 1.0, False), (0, -1, 0.5, False),
+    (11, 0, 1.0, False), (12, 0, 0.9, False)])
+@pytest.mark.parametrize("level", [0, 1])
+def test_single_sweep(gpu_lib, oracle, relax_type, relax_points, w, zero, level):
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    # relax_order=1 makes the setup keep CF-restricted l1 norms like the reference does
+    opt, A0, s = _setup(lib, n=(9, 8, 7), relax_type=relax_type if relax_type != 0 else 18, coarsen_type=8,
+                        relax_order=1 if relax_points else 0)
+    A, cf, l1 = _level(lib, s, level)
+    amg = oracle.amg_from_solvers([s])
+    n = amg.A_levels[level].nrows
+    f = rand_vector(n, 3)
+    u0 = np.zeros(n) if zero else rand_vector(n, 4)
+    du = B.parvec_from_numpy(u0)
+    df = B.parvec_from_numpy(f)
+    dv = B.parvec_from_numpy(np.zeros(n))
+    dz = B.parvec_from_numpy(np.zeros(n))
+    if zero:
+        lib.hypre_ParVectorSetZeros(du)
+    l1_arg = l1 if relax_type in (7, 18, 11, 12) else None
+    err = lib.hypre_BoomerAMGRelax(A, df, cf, relax_type, relax_points, w, 1.0, l1_arg, du, dv, dz)
+    B.check()
+    assert err == 0 and du.contents.all_zeros == 0
+    u = B.parvec_to_numpy(du)
+    ur = u0.copy()
+    l1_np = amg.l1[level] if relax_type in (7, 18, 11, 12) else None
+    oracle.relax(amg.A_levels[level], f, amg.cf[level], relax_type, relax_points, w, 1.0, l1_np, ur, all_zeros=zero)
+    assert np.max(np.abs(u - ur)) <= 1e-12 * max(1.0, np.max(np.abs(ur)))
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(relax_type=18, coarsen_type=8),
+    dict(relax_type=18, coarsen_type=8, relax_order=1),
+    dict(relax_type=18, coarsen_type=10, num_sweeps=2),
+    dict(relax_type=7, coarsen_type=8, relax_wt=0.8),
+    dict(relax_type=0, coarsen_type=9, P_max_elmts=0, relax_wt=0.7),
+    dict(relax_type=18, coarsen_type=8, cycle_type=2),
+    dict(relax_type=18, coarsen_type=8, fcycle=1),
+    dict(relax_type=11, coarsen_type=8),
+    dict(relax_type=12, coarsen_type=8),
+    dict(relax_type=18, coarsen_type=8, problem="27pt"),
+])
+def test_one_cycle_matches_oracle(gpu_lib, oracle, kw):
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    opt, A, s = _setup(lib, n=(12, 11, 10), **kw)
+    amg = oracle.amg_from_solvers([s])
+    n = amg.A_levels[0].nrows
+    f = rand_vector(n, 5)
+    for zero in (True, False):
+        u0 = np.zeros(n) if zero else rand_vector(n, 6)
+        du, df = B.parvec_from_numpy(u0), B.parvec_from_numpy(f)
+        if zero:
+            lib.hypre_ParVectorSetZeros(du)
+        lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+        lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+        lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+        B.check()
+        u = B.parvec_to_numpy(du)
+        ur = u0.copy()
+        amg.cycle(f, ur, u_all_zeros=zero)
+        assert np.max(np.abs(u - ur)) <= 1e-11 * np.max(np.abs(ur)), (kw, zero)
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(relax_type=18, coarsen_type=8),
+    dict(relax_type=18, coarsen_type=10, relax_order=1),
+    dict(relax_type=0, coarsen_type=9, P_max_elmts=0, rhs="xisone"),
+    dict(relax_type=12, coarsen_type=8),
+])
+def test_amg_solve_iterations_match_oracle(gpu_lib, oracle, kw):
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt, A, s = _setup(lib, n=(16, 16, 16), **kw)
+    amg = oracle.amg_from_solvers([s])
+    n = amg.A_levels[0].nrows
+    b, x0 = ij.build_rhs_host(opt, A)
+    if b is None:
+        b = np.zeros(n)
+        oracle.par_matvec(1.0, amg.A_levels[0], np.ones(n), 0.0, b, b)
+    its_r, rel_r, conv_r, hist = amg.solve(b, x0.copy(), tol=opt.tol, max_iter=opt.mg_max_iter)
+    dx, db = B.parvec_from_numpy(x0), B.parvec_from_numpy(b)
+    lib.HYPRE_BoomerAMGSolve(s, A, db, dx)
+    its, rel = C.c_int(), C.c_double()
+    lib.HYPRE_BoomerAMGGetNumIterations(s, C.byref(its))
+    lib.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+    B.check()
+    assert its.value == its_r
+    assert abs(rel.value - rel_r) <= 1e-6 * rel_r
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+def test_golden_fsai103_pcg_relax7_on_device(gpu_lib):
+    """TEST_ij/fsai.saved:89-91 — `ij -n 10 10 10 -solver 1 -rlx 7`: 22 iterations, 7.480945e-09."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt, A, s = _setup(lib, n=(10, 10, 10), solver=1, relax_type=7)
+    lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    b, x0 = ij.build_rhs_host(opt, A)
+    dx, db = B.parvec_from_numpy(x0), B.parvec_from_numpy(b)
+    pcg = C.c_void_p()
+    lib.HYPRE_ParCSRPCGCreate(0, C.byref(pcg))
+    lib.HYPRE_PCGSetTol(pcg, opt.tol)
+    lib.HYPRE_PCGSetMaxIter(pcg, opt.max_iter)
+    lib.HYPRE_PCGSetTwoNorm(pcg, 1)
+    lib.HYPRE_PCGSetPrecond(pcg, C.cast(lib.HYPRE_BoomerAMGSolve, C.c_void_p), None, s)
+    lib.HYPRE_ParCSRPCGSetup(pcg, A, db, dx)
+    lib.HYPRE_ParCSRPCGSolve(pcg, A, db, dx)
+    its, rel = C.c_int(), C.c_double()
+    lib.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
+    lib.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
+    B.check()
+    assert its.value == 22
+    assert abs(rel.value - 7.480945e-09) <= 1e-6 * 7.480945e-09
+    lib.HYPRE_ParCSRPCGDestroy(pcg)
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+def test_golden_default0_relax0_on_device(gpu_lib):
+    """TEST_ij/default.saved:1-6 — `ij -pmis1 -Pmx 0 -rlx 0 -xisone`: average convergence
+    factor 0.678738, grid complexity 1.407000, operator complexity 3.252344."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt, A, s = _setup(lib, coarsen_type=9, P_max_elmts=0, relax_type=0, rhs="xisone")
+    g, o = C.c_double(), C.c_double()
+    lib.hypre_amd_BoomerAMGGetComplexities(s, C.byref(g), C.byref(o))
+    assert round(g.value, 6) == 1.407000 and round(o.value, 6) == 3.252344
+    n = 1000
+    dx = B.parvec_from_numpy(np.ones(n))
+    db = B.parvec_from_numpy(np.zeros(n))
+    lib.hypre_ParCSRMatrixMatvec(1.0, A, dx, 0.0, db)
+    lib.hypre_ParVectorSetConstantValues(dx, 0.0)
+    r0 = np.linalg.norm(B.parvec_to_numpy(db))
+    lib.HYPRE_BoomerAMGSolve(s, A, db, dx)
+    its, rel = C.c_int(), C.c_double()
+    lib.HYPRE_BoomerAMGGetNumIterations(s, C.byref(its))
+    lib.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+    B.check()
+    cf = rel.value ** (1.0 / its.value)
+    assert its.value == 48 and abs(cf - 0.678738) < 5e-7
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+def test_host_hierarchy_fails_loudly(gpu_lib):
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt = ij.IJOptions(relax_type=18, coarsen_type=8)
+    A = ij.build_matrix(opt)
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_HOST)
+    lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+    B.check()
+    hx = B.parvec_from_numpy(np.zeros(1000), location=B.HYPRE_MEMORY_HOST)
+    hb = B.parvec_from_numpy(np.ones(1000), location=B.HYPRE_MEMORY_HOST)
+    lib.HYPRE_BoomerAMGSolve(s, A, hb, hx)
+    with pytest.raises(B.HypreAmdError, match="host execution is not part of this library"):
+        B.check()

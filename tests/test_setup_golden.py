@@ -1,0 +1,54 @@
+"""CPU: the reference's own regression goldens (test/TEST_ij/*.saved) reproduced by
+the library's host setup + the CPU oracle's solve phase.  This is what pins the
+oracle: iteration counts, final residuals, convergence factors and complexities
+printed by the reference driver for the same command lines."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "ij_saved.json")))
+
+
+def _run(lib, oracle, case):
+    from hypre_amd import binding as B, ij
+    opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
+    A = ij.build_matrix(opt)
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_HOST)
+    lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+    B.check()
+    g, o = C.c_double(), C.c_double()
+    lib.hypre_amd_BoomerAMGGetComplexities(s, C.byref(g), C.byref(o))
+    amg = oracle.amg_from_solvers([s], num_threads=opt.num_threads)
+    n = amg.A_levels[0].nrows
+    b, x = ij.build_rhs_host(opt, A)
+    if b is None:
+        b = np.zeros(n)
+        oracle.par_matvec(1.0, amg.A_levels[0], np.ones(n), 0.0, b, b)
+    out = {"grid": g.value, "operator": o.value}
+    if opt.solver == 0:
+        its, rel, conv, hist = amg.solve(b, x, tol=opt.tol, max_iter=opt.mg_max_iter)
+        out.update(iterations=its, rel_resid=rel, conv_factor=(hist[-1] / hist[0]) ** (1.0 / its))
+    else:
+        its, rel, conv = amg.pcg(b, x, tol=opt.tol, max_iter=opt.max_iter, two_norm=opt.two_norm)
+        out.update(iterations=its, rel_resid=rel)
+    lib.HYPRE_BoomerAMGDestroy(s)
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(k for k, v in GOLD.items() if v.get("ranks", 1) == 1))
+def test_single_rank_goldens(lib, oracle, name):
+    case = GOLD[name]
+    out = _run(lib, oracle, case)
+    exp = case["expect"]
+    if "iterations" in exp:
+        assert out["iterations"] == exp["iterations"]
+    if "rel_resid" in exp:
+        # the .saved files print 7 significant digits
+        assert abs(out["rel_resid"] - exp["rel_resid"]) <= 5e-7 * exp["rel_resid"]
+    for key in ("conv_factor", "grid", "operator"):
+        if key in exp:
+            assert abs(out[key] - exp[key]) < 5.1e-7, (key, out[key], exp[key])
