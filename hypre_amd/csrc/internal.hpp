@@ -84,6 +84,8 @@ struct SpmvPlan
    int   max_row_nnz = 0;
    int   num_tiles = 0;
    int  *d_tile_row = nullptr;       // [num_tiles+1] first row of every tile
+   int  *d_tile_k   = nullptr;       // [num_tiles+1] Ai[tile_row[b]]
+   int   prod_elems = 0;             // LDS product slots per tile: TILE + max row + pad
    bool  tiled = false;              // false -> wave-per-row kernel (long rows)
    // cached explicit transpose (built on first MatvecT)
    hypre_CSRMatrix *AT = nullptr;
@@ -123,7 +125,7 @@ struct SpmvArgs
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
-                        hipStream_t s);
+                        int *d_tile_k, hipStream_t s);
 int  device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s);
 
 // BLAS-1 kernels

@@ -1,14 +1,10 @@
 // hypre_amd — hand-written gfx950 (CDNA4) kernels for the BoomerAMG solve phase.
 //
-// Everything here is HBM-bound fp64/int32 streaming work (0.13-0.17 flop/B), so
-// the design rules are: 16-byte coalesced loads of the column-index / value
-// streams, enough independent loads in flight per lane to cover HBM latency,
-// per-row reductions through LDS (64-wide waves), fused epilogues so that a
-// smoother sweep is one pass over the matrix, and an XCD-aware tile mapping so
-// that the x-vector window of neighbouring tiles stays in one XCD's 4 MiB L2.
+// This file: BLAS-1 and small utility kernels (the SpMV family lives in
+// spmv_kernels.hip).  All of it is HBM-bound streaming work: 16-byte loads and
+// stores, grid-stride loops capped at ~2048 workgroups.
 //
 // Replaces (behaviourally, not structurally) the reference kernels of
-//   seq_mv/csr_spmv_device.c:35-260     K-lanes-per-row shuffle SpMV
 //   utilities/device_utils.c:649-720    IVAXPY / IVAXPYMarked
 //   utilities/device_utils.c:2422-2468  DiagScaleVector2
 //   seq_mv/vector_device.c              axpy / scale / dot via rocBLAS+thrust
@@ -26,355 +22,6 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); }
    return v;
-}
-
-template <int W>
-__device__ __forceinline__ double subwave_sum(double v)
-{
-#pragma unroll
-   for (int off = W / 2; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); }
-   return v;
-}
-
-__device__ __forceinline__ bool fill_keep(int fill, int row, int col)
-{
-   switch (fill)
-   {
-      case HYPRE_SPMV_FILL_STRICT_LOWER: return col <  row;
-      case HYPRE_SPMV_FILL_LOWER:        return col <= row;
-      case HYPRE_SPMV_FILL_UPPER:        return col >= row;
-      case HYPRE_SPMV_FILL_STRICT_UPPER: return col >  row;
-      default:                           return true;
-   }
-}
-
-// Row epilogue shared by every SpMV flavour.
-template <int OP>
-__device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double sum)
-{
-   if (OP == OP_AXPBY)
-   {
-      double r = p.alpha * sum;
-      if (p.beta != 0.0) { r += p.beta * p.b[row]; }
-      p.y[row] = r;
-   }
-   else if (OP == OP_TSGS)
-   {
-      // inner step of the two-stage Gauss-Seidel sweep (par_relax_device.c:139-150):
-      //    z_out = (L_strict z_in) ./ D ;  u += mult * z_out
-      const double z = sum * (1.0 / p.d[row]);
-      p.y[row] = z;
-      p.aux[row] += p.alpha * z;
-   }
-   else
-   {
-      // Jacobi / l1-Jacobi sweep fused into the SpMV pass:
-      //    y = x + (w*f - w*(A x)) ./ d          (par_relax.c:1216-1244)
-      const double xr = p.x[row];
-      if (OP == OP_JACOBI_CF && p.marker[row] != p.marker_val) { p.y[row] = xr; return; }
-      const double t = p.alpha * p.b[row] - p.alpha * sum;
-      p.y[row] = xr + t / p.d[row];
-   }
-}
-
-// ---------------------------------------------------------------------------
-// Tiled ("stream") SpMV.  One 256-thread workgroup per tile of <= TILE+MAXROW
-// stored entries.  Phase 1 streams the tile's (col,val) pairs with 16-byte
-// loads, gathers x, and parks the products in LDS.  Phase 2 reduces each row
-// from LDS with 1..64 lanes per row and applies the epilogue.
-// ---------------------------------------------------------------------------
-constexpr int LDS_ELEMS = SPMV_TILE + SPMV_MAXROW + 8;
-
-template <int OP, bool F32, bool HASFILL>
-__global__ __launch_bounds__(SPMV_THREADS)
-void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, int num_tiles)
-{
-   __shared__ double prod[LDS_ELEMS];
-
-   // XCD-aware mapping: hardware deals workgroups round-robin over the 8 XCDs,
-   // so workgroup g lands on XCD g%8; give every XCD one contiguous eighth of
-   // the tiles (speed only; any placement is correct).
-   const int per_xcd = (num_tiles + 7) >> 3;
-   const int tile    = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-   if (tile >= num_tiles) { return; }
-
-   const int r0 = tile_row[tile];
-   const int r1 = tile_row[tile + 1];
-   if (r1 <= r0) { return; }
-
-   const int tid = threadIdx.x;
-   const int k0  = p.Ai[r0];
-   const int k1  = p.Ai[r1];
-   const int ka  = k0 & ~3;
-
-   // ---- phase 1: stream entries, gather x, stage products -----------------
-   for (int k = ka + 4 * tid; k < k1; k += 4 * SPMV_THREADS)
-   {
-      const int4 c = *reinterpret_cast<const int4 *>(p.Aj + k);
-      double v0, v1, v2, v3;
-      if (F32)
-      {
-         const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + k);
-         v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
-      }
-      else
-      {
-         const double2 va = *reinterpret_cast<const double2 *>(p.Aa + k);
-         const double2 vb = *reinterpret_cast<const double2 *>(p.Aa + k + 2);
-         v0 = va.x; v1 = va.y; v2 = vb.x; v3 = vb.y;
-      }
-      double *dst = prod + (k - ka);
-      if (k >= k0 && k + 4 <= k1)
-      {
-         const double x0 = p.x[c.x], x1 = p.x[c.y], x2 = p.x[c.z], x3 = p.x[c.w];
-         double2 o0, o1;
-         o0.x = v0 * x0; o0.y = v1 * x1; o1.x = v2 * x2; o1.y = v3 * x3;
-         *reinterpret_cast<double2 *>(dst)     = o0;
-         *reinterpret_cast<double2 *>(dst + 2) = o1;
-      }
-      else
-      {
-         if (k     >= k0 && k     < k1) { dst[0] = v0 * p.x[c.x]; }
-         if (k + 1 >= k0 && k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
-         if (k + 2 >= k0 && k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
-         if (k + 3 >= k0 && k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
-      }
-   }
-   __syncthreads();
-
-   // ---- phase 2: per-row reduction ---------------------------------------
-   const int nrows = r1 - r0;
-   const int avg   = (k1 - k0) / nrows;
-   if (avg <= 12)
-   {
-      // one lane per row, entries summed in stored order
-      for (int rr = tid; rr < nrows; rr += SPMV_THREADS)
-      {
-         const int row = r0 + rr;
-         const int s = p.Ai[row], e = p.Ai[row + 1];
-         double sum = 0.0;
-         for (int k = s; k < e; k++)
-         {
-            double t = prod[k - ka];
-            if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-            sum += t;
-         }
-         row_epilogue<OP>(p, row, sum);
-      }
-   }
-   else if (avg <= 48)
-   {
-      constexpr int W = 8;
-      const int sub = tid & (W - 1);
-      for (int rr = tid / W; rr < ((nrows + SPMV_THREADS / W - 1) / (SPMV_THREADS / W)) * (SPMV_THREADS / W);
-           rr += SPMV_THREADS / W)
-      {
-         double sum = 0.0;
-         const int row = r0 + rr;
-         if (rr < nrows)
-         {
-            const int s = p.Ai[row], e = p.Ai[row + 1];
-            for (int k = s + sub; k < e; k += W)
-            {
-               double t = prod[k - ka];
-               if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-               sum += t;
-            }
-         }
-         sum = subwave_sum<W>(sum);
-         if (rr < nrows && sub == 0) { row_epilogue<OP>(p, row, sum); }
-      }
-   }
-   else
-   {
-      constexpr int W = 32;
-      const int sub = tid & (W - 1);
-      for (int rr = tid / W; rr < ((nrows + SPMV_THREADS / W - 1) / (SPMV_THREADS / W)) * (SPMV_THREADS / W);
-           rr += SPMV_THREADS / W)
-      {
-         double sum = 0.0;
-         const int row = r0 + rr;
-         if (rr < nrows)
-         {
-            const int s = p.Ai[row], e = p.Ai[row + 1];
-            for (int k = s + sub; k < e; k += W)
-            {
-               double t = prod[k - ka];
-               if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-               sum += t;
-            }
-         }
-         sum = subwave_sum<W>(sum);
-         if (rr < nrows && sub == 0) { row_epilogue<OP>(p, row, sum); }
-      }
-   }
-}
-
-// ---------------------------------------------------------------------------
-// Wave-per-row SpMV: fallback for matrices with rows longer than SPMV_MAXROW
-// (never hit by the AMG hierarchies of the benchmark; kept for generality).
-// ---------------------------------------------------------------------------
-template <int OP, bool F32, bool HASFILL>
-__global__ __launch_bounds__(SPMV_THREADS)
-void spmv_wave_kernel(SpmvArgs p, int num_rows)
-{
-   const int lane   = threadIdx.x & 63;
-   const int wave   = (blockIdx.x * SPMV_THREADS + threadIdx.x) >> 6;
-   const int nwaves = (gridDim.x * SPMV_THREADS) >> 6;
-   for (int row = wave; row < num_rows; row += nwaves)
-   {
-      const int s = p.Ai[row], e = p.Ai[row + 1];
-      double sum = 0.0;
-      for (int k = s + lane; k < e; k += 64)
-      {
-         const int c = p.Aj[k];
-         double v = F32 ? (double) p.Aa32[k] : p.Aa[k];
-         if (HASFILL) { if (!fill_keep(p.fill, row, c)) { v = 0.0; } }
-         sum += v * p.x[c];
-      }
-      sum = wave_sum(sum);
-      if (lane == 0) { row_epilogue<OP>(p, row, sum); }
-   }
-}
-
-// y[row] += alpha * (A x)[row] over the listed non-empty rows only (offd blocks:
-// seq_mv/csr_matvec.c:381-670 rownnz path).  8 lanes per listed row.
-__global__ __launch_bounds__(SPMV_THREADS)
-void spmv_rownnz_kernel(SpmvArgs p, const int *__restrict__ rownnz, int num_rownnz)
-{
-   const int g   = (blockIdx.x * SPMV_THREADS + threadIdx.x) >> 3;
-   const int sub = threadIdx.x & 7;
-   double sum = 0.0;
-   int row = 0;
-   if (g < num_rownnz)
-   {
-      row = rownnz[g];
-      const int s = p.Ai[row], e = p.Ai[row + 1];
-      for (int k = s + sub; k < e; k += 8)
-      {
-         const double v = p.Aa32 ? (double) p.Aa32[k] : p.Aa[k];
-         sum += v * p.x[p.Aj[k]];
-      }
-   }
-   sum = subwave_sum<8>(sum);
-   if (g < num_rownnz && sub == 0) { p.y[row] += p.alpha * sum; }
-}
-
-// ---------------------------------------------------------------------------
-// plan construction
-// ---------------------------------------------------------------------------
-// tile_row[b] = first row r with Ai[r] >= b*TILE  (rows are owned by the tile
-// their first entry falls into); tile_row[num_tiles] = num_rows.
-__global__ void build_tiles_kernel(const int *__restrict__ Ai, int num_rows, int num_tiles,
-                                   int *__restrict__ tile_row)
-{
-   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-   if (b > num_tiles) { return; }
-   if (b == num_tiles) { tile_row[b] = num_rows; return; }
-   const long long target = (long long) b * SPMV_TILE;
-   int lo = 0, hi = num_rows;           // first r in [0,num_rows] with Ai[r] >= target
-   while (lo < hi)
-   {
-      const int mid = (lo + hi) >> 1;
-      if ((long long) Ai[mid] >= target) { hi = mid; } else { lo = mid + 1; }
-   }
-   tile_row[b] = lo;
-}
-
-__global__ void max_row_nnz_kernel(const int *__restrict__ Ai, int num_rows, int *__restrict__ out)
-{
-   int m = 0;
-   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < num_rows; r += gridDim.x * blockDim.x)
-   {
-      m = max(m, Ai[r + 1] - Ai[r]);
-   }
-#pragma unroll
-   for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off, 64)); }
-   if ((threadIdx.x & 63) == 0) { atomicMax(out, m); }
-}
-
-void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
-                        hipStream_t s)
-{
-   (void) nnz;
-   const int n = num_tiles + 1;
-   hipLaunchKernelGGL(build_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, num_rows,
-                      num_tiles, d_tile_row);
-}
-
-int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
-{
-   if (num_rows <= 0) { return 0; }
-   int *d_out = reinterpret_cast<int *>(reduce_scratch(2));
-   HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(int), s));
-   int grid = (num_rows + 255) / 256;
-   if (grid > 2048) { grid = 2048; }
-   hipLaunchKernelGGL(max_row_nnz_kernel, dim3(grid), dim3(256), 0, s, Ai, num_rows, d_out);
-   int h = 0;
-   HIP_CHECK(hipMemcpyAsync(&h, d_out, sizeof(int), hipMemcpyDeviceToHost, s));
-   HIP_CHECK(hipStreamSynchronize(s));
-   return h;
-}
-
-// ---------------------------------------------------------------------------
-// launchers
-// ---------------------------------------------------------------------------
-template <int OP>
-static void launch_spmv_op(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
-{
-   const bool f32  = a.Aa32 != nullptr;
-   const bool fill = a.fill != HYPRE_SPMV_FILL_WHOLE;
-   if (plan->tiled)
-   {
-      const int grid = ((plan->num_tiles + 7) / 8) * 8;
-      dim3 g(grid), b(SPMV_THREADS);
-      if (f32)
-      {
-         if (fill) hipLaunchKernelGGL((spmv_tiled_kernel<OP, true, true>), g, b, 0, s, a, plan->d_tile_row, plan->num_tiles);
-         else      hipLaunchKernelGGL((spmv_tiled_kernel<OP, true, false>), g, b, 0, s, a, plan->d_tile_row, plan->num_tiles);
-      }
-      else
-      {
-         if (fill) hipLaunchKernelGGL((spmv_tiled_kernel<OP, false, true>), g, b, 0, s, a, plan->d_tile_row, plan->num_tiles);
-         else      hipLaunchKernelGGL((spmv_tiled_kernel<OP, false, false>), g, b, 0, s, a, plan->d_tile_row, plan->num_tiles);
-      }
-   }
-   else
-   {
-      int grid = (plan->num_rows + 3) / 4;
-      if (grid > 4096) { grid = 4096; }
-      if (grid < 1) { grid = 1; }
-      dim3 g(grid), b(SPMV_THREADS);
-      if (f32)
-      {
-         if (fill) hipLaunchKernelGGL((spmv_wave_kernel<OP, true, true>), g, b, 0, s, a, plan->num_rows);
-         else      hipLaunchKernelGGL((spmv_wave_kernel<OP, true, false>), g, b, 0, s, a, plan->num_rows);
-      }
-      else
-      {
-         if (fill) hipLaunchKernelGGL((spmv_wave_kernel<OP, false, true>), g, b, 0, s, a, plan->num_rows);
-         else      hipLaunchKernelGGL((spmv_wave_kernel<OP, false, false>), g, b, 0, s, a, plan->num_rows);
-      }
-   }
-}
-
-void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s)
-{
-   if (plan->num_rows <= 0) { return; }
-   switch (op)
-   {
-      case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, args, s); break;
-      case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, args, s); break;
-      case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, args, s); break;
-      case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, args, s); break;
-   }
-}
-
-void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s)
-{
-   if (num_rownnz <= 0) { return; }
-   const int grid = (num_rownnz * 8 + SPMV_THREADS - 1) / SPMV_THREADS;
-   hipLaunchKernelGGL(spmv_rownnz_kernel, dim3(grid), dim3(SPMV_THREADS), 0, s, args, rownnz, num_rownnz);
 }
 
 // ---------------------------------------------------------------------------

@@ -29,6 +29,7 @@ static void free_plan(SpmvPlan *p)
 {
    if (!p) { return; }
    if (p->d_tile_row) { HIP_CHECK(hipFree(p->d_tile_row)); }
+   if (p->d_tile_k) { HIP_CHECK(hipFree(p->d_tile_k)); }
    if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
    delete p;
@@ -73,7 +74,9 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
       {
          p->num_tiles = (int) (((long long) A->num_nonzeros + SPMV_TILE - 1) / SPMV_TILE);
          HIP_CHECK(hipMalloc((void **) &p->d_tile_row, sizeof(int) * (size_t) (p->num_tiles + 1)));
-         launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, s);
+         HIP_CHECK(hipMalloc((void **) &p->d_tile_k, sizeof(int) * (size_t) (p->num_tiles + 1)));
+         p->prod_elems = SPMV_TILE + ((p->max_row_nnz + 3) & ~3) + 8;
+         launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
       }
    }
    t[A] = p;

@@ -1,0 +1,472 @@
+// hypre_amd — CSR SpMV kernel family for gfx950 (CDNA4), fp64 values / int32 indices.
+//
+// One kernel template serves y = alpha*A*x + beta*b, the fused Jacobi / l1-Jacobi
+// sweep, and the two-stage Gauss-Seidel inner step (row epilogues), so a
+// smoother sweep is a single pass over the matrix.
+//
+// Tiled ("stream") kernel, one 256-thread workgroup per tile of ~2048 stored
+// entries (rows are binned into tiles by the position of their first entry):
+//   phase 0  row pointers of the tile -> LDS, epilogue operands (b, d, x of the
+//            row each lane will finish) -> registers; issued together with the
+//            matrix stream so their latency hides under it;
+//   phase 1  (col, val) streamed with 16-byte loads (2 x 4 entries per lane in
+//            flight), x gathered, products parked in LDS;
+//   phase 2  per-row reduction from LDS with 1, 8 or 32 lanes per row (chosen
+//            per tile from its mean row length), row sums of the multi-lane
+//            paths go through LDS so that the epilogue is one coalesced pass.
+// Tiles are handed to workgroups so that each XCD works on one contiguous
+// eighth of the matrix: neighbouring tiles share their x window in that XCD's L2.
+//
+// Replaces (behaviourally) seq_mv/csr_spmv_device.c:35-260 of the reference,
+// which uses K lanes per row chosen from the matrix-wide average row length,
+// no LDS, and one kernel per operation (copy, SpMV, elementwise update).
+#include "amg_internal.hpp"
+
+namespace hamd {
+
+__device__ __forceinline__ double wave_sum64(double v)
+{
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); }
+   return v;
+}
+
+template <int W>
+__device__ __forceinline__ double subwave_sum(double v)
+{
+#pragma unroll
+   for (int off = W / 2; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); }
+   return v;
+}
+
+__device__ __forceinline__ bool fill_keep(int fill, int row, int col)
+{
+   switch (fill)
+   {
+      case HYPRE_SPMV_FILL_STRICT_LOWER: return col <  row;
+      case HYPRE_SPMV_FILL_LOWER:        return col <= row;
+      case HYPRE_SPMV_FILL_UPPER:        return col >= row;
+      case HYPRE_SPMV_FILL_STRICT_UPPER: return col >  row;
+      default:                           return true;
+   }
+}
+
+// operands of one row's epilogue, fetched early
+struct RowOps
+{
+   double b, d, x;
+   int    m;
+};
+
+template <int OP>
+__device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
+{
+   RowOps o;
+   o.b = 0.0; o.d = 1.0; o.x = 0.0; o.m = 0;
+   if (OP == OP_AXPBY) { if (p.beta != 0.0) { o.b = p.b[row]; } }
+   else if (OP == OP_TSGS) { o.d = p.d[row]; }
+   else
+   {
+      o.b = p.b[row]; o.d = p.d[row]; o.x = p.x[row];
+      if (OP == OP_JACOBI_CF) { o.m = p.marker[row]; }
+   }
+   return o;
+}
+
+template <int OP>
+__device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double sum, const RowOps &o)
+{
+   if (OP == OP_AXPBY)
+   {
+      // y = alpha*(A x) + beta*b
+      double r = p.alpha * sum;
+      if (p.beta != 0.0) { r += p.beta * o.b; }
+      p.y[row] = r;
+   }
+   else if (OP == OP_TSGS)
+   {
+      // inner step of the two-stage Gauss-Seidel sweep (par_relax_device.c:139-150):
+      //    z_out = (L_strict z_in) ./ D ;  u += mult * z_out
+      const double z = sum * (1.0 / o.d);
+      p.y[row] = z;
+      p.aux[row] += p.alpha * z;
+   }
+   else
+   {
+      // Jacobi / l1-Jacobi sweep fused into the SpMV pass (par_relax.c:1216-1244):
+      //    y = x + (w f - w (A x)) ./ d      on the marked rows, y = x elsewhere
+      if (OP == OP_JACOBI_CF && o.m != p.marker_val) { p.y[row] = o.x; return; }
+      const double t = p.alpha * o.b - p.alpha * sum;
+      p.y[row] = o.x + t / o.d;
+   }
+}
+
+constexpr int RP_CAP = 640;      // row pointers staged in LDS per tile
+
+template <int OP, bool F32, bool HASFILL>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
+                       int num_tiles, int prod_elems)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *prod   = reinterpret_cast<double *>(smem_raw);
+   double *rowsum = prod + prod_elems;                       // [SPMV_THREADS]
+   int    *rp     = reinterpret_cast<int *>(rowsum + SPMV_THREADS);   // [RP_CAP + 1]
+
+   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs
+   // (workgroup g -> XCD g % 8); give every XCD one contiguous eighth of the
+   // tiles.  Speed only: any placement is correct.
+   const int per_xcd = (num_tiles + 7) >> 3;
+   const int tile    = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+   if (tile >= num_tiles) { return; }
+
+   const int r0 = tile_row[tile];
+   const int r1 = tile_row[tile + 1];
+   if (r1 <= r0) { return; }
+   const int k0 = tile_k[tile];
+   const int k1 = tile_k[tile + 1];
+   const int ka = k0 & ~3;
+   const int tid = threadIdx.x;
+   const int nrows = r1 - r0;
+
+   // ---- phase 1a: issue the matrix stream (two quads per lane) --------------
+   const int kA = ka + 4 * tid;
+   const int kB = kA + 4 * SPMV_THREADS;
+   int4 cA = make_int4(0, 0, 0, 0), cB = make_int4(0, 0, 0, 0);
+   double vA0 = 0, vA1 = 0, vA2 = 0, vA3 = 0, vB0 = 0, vB1 = 0, vB2 = 0, vB3 = 0;
+   if (kA < k1)
+   {
+      cA = *reinterpret_cast<const int4 *>(p.Aj + kA);
+      if (F32) { const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + kA); vA0 = v.x; vA1 = v.y; vA2 = v.z; vA3 = v.w; }
+      else
+      {
+         const double2 a = *reinterpret_cast<const double2 *>(p.Aa + kA);
+         const double2 b = *reinterpret_cast<const double2 *>(p.Aa + kA + 2);
+         vA0 = a.x; vA1 = a.y; vA2 = b.x; vA3 = b.y;
+      }
+   }
+   if (kB < k1)
+   {
+      cB = *reinterpret_cast<const int4 *>(p.Aj + kB);
+      if (F32) { const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + kB); vB0 = v.x; vB1 = v.y; vB2 = v.z; vB3 = v.w; }
+      else
+      {
+         const double2 a = *reinterpret_cast<const double2 *>(p.Aa + kB);
+         const double2 b = *reinterpret_cast<const double2 *>(p.Aa + kB + 2);
+         vB0 = a.x; vB1 = a.y; vB2 = b.x; vB3 = b.y;
+      }
+   }
+
+   // ---- phase 0: row pointers -> LDS, this lane's epilogue operands -> registers
+   for (int t = tid; t <= nrows && t <= RP_CAP; t += SPMV_THREADS) { rp[t] = p.Ai[r0 + t]; }
+   RowOps ops;
+   ops.b = 0.0; ops.d = 1.0; ops.x = 0.0; ops.m = 0;
+   if (tid < nrows) { ops = load_row_ops<OP>(p, r0 + tid); }
+
+   // ---- phase 1b: gather x, stage products ----------------------------------
+   if (kA < k1)
+   {
+      double *dst = prod + (kA - ka);
+      if (kA >= k0 && kA + 4 <= k1)
+      {
+         const double x0 = p.x[cA.x], x1 = p.x[cA.y], x2 = p.x[cA.z], x3 = p.x[cA.w];
+         *reinterpret_cast<double2 *>(dst)     = make_double2(vA0 * x0, vA1 * x1);
+         *reinterpret_cast<double2 *>(dst + 2) = make_double2(vA2 * x2, vA3 * x3);
+      }
+      else
+      {
+         if (kA     >= k0 && kA     < k1) { dst[0] = vA0 * p.x[cA.x]; }
+         if (kA + 1 >= k0 && kA + 1 < k1) { dst[1] = vA1 * p.x[cA.y]; }
+         if (kA + 2 >= k0 && kA + 2 < k1) { dst[2] = vA2 * p.x[cA.z]; }
+         if (kA + 3 >= k0 && kA + 3 < k1) { dst[3] = vA3 * p.x[cA.w]; }
+      }
+   }
+   if (kB < k1)
+   {
+      double *dst = prod + (kB - ka);
+      if (kB + 4 <= k1)
+      {
+         const double x0 = p.x[cB.x], x1 = p.x[cB.y], x2 = p.x[cB.z], x3 = p.x[cB.w];
+         *reinterpret_cast<double2 *>(dst)     = make_double2(vB0 * x0, vB1 * x1);
+         *reinterpret_cast<double2 *>(dst + 2) = make_double2(vB2 * x2, vB3 * x3);
+      }
+      else
+      {
+         if (kB     < k1) { dst[0] = vB0 * p.x[cB.x]; }
+         if (kB + 1 < k1) { dst[1] = vB1 * p.x[cB.y]; }
+         if (kB + 2 < k1) { dst[2] = vB2 * p.x[cB.z]; }
+         if (kB + 3 < k1) { dst[3] = vB3 * p.x[cB.w]; }
+      }
+   }
+   // tail of a tile whose last row runs past 2 quads per lane
+   for (int k = kB + 4 * SPMV_THREADS; k < k1; k += 4 * SPMV_THREADS)
+   {
+      const int4 c = *reinterpret_cast<const int4 *>(p.Aj + k);
+      double v0, v1, v2, v3;
+      if (F32) { const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + k); v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w; }
+      else
+      {
+         const double2 a = *reinterpret_cast<const double2 *>(p.Aa + k);
+         const double2 b = *reinterpret_cast<const double2 *>(p.Aa + k + 2);
+         v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
+      }
+      double *dst = prod + (k - ka);
+      if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
+      if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
+      if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
+      if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
+   }
+   __syncthreads();
+
+   // ---- phase 2: per-row reduction ------------------------------------------
+   const int avg = (k1 - k0) / nrows;
+   if (avg <= 12)
+   {
+      // one lane per row; entries are summed in stored order
+      for (int rr = tid; rr < nrows; rr += SPMV_THREADS)
+      {
+         const int row = r0 + rr;
+         const int s = (rr     <= RP_CAP) ? rp[rr]     : p.Ai[row];
+         const int e = (rr + 1 <= RP_CAP) ? rp[rr + 1] : p.Ai[row + 1];
+         double sum = 0.0;
+         for (int k = s; k < e; k++)
+         {
+            double t = prod[k - ka];
+            if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
+            sum += t;
+         }
+         if (rr == tid) { row_epilogue<OP>(p, row, sum, ops); }
+         else { const RowOps o = load_row_ops<OP>(p, row); row_epilogue<OP>(p, row, sum, o); }
+      }
+   }
+   else
+   {
+      // avg > 12  =>  nrows <= (TILE + MAXROW)/13 < SPMV_THREADS: row sums fit rowsum[]
+      if (avg <= 48)
+      {
+         constexpr int W = 8, G = SPMV_THREADS / W;
+         const int sub = tid & (W - 1);
+         for (int base = 0; base < nrows; base += G)
+         {
+            const int rr = base + tid / W;
+            double sum = 0.0;
+            if (rr < nrows)
+            {
+               const int row = r0 + rr;
+               const int s = rp[rr], e = rp[rr + 1];
+               for (int k = s + sub; k < e; k += W)
+               {
+                  double t = prod[k - ka];
+                  if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
+                  sum += t;
+               }
+            }
+            sum = subwave_sum<W>(sum);
+            if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
+         }
+      }
+      else
+      {
+         constexpr int W = 32, G = SPMV_THREADS / W;
+         const int sub = tid & (W - 1);
+         for (int base = 0; base < nrows; base += G)
+         {
+            const int rr = base + tid / W;
+            double sum = 0.0;
+            if (rr < nrows)
+            {
+               const int row = r0 + rr;
+               const int s = rp[rr], e = rp[rr + 1];
+               for (int k = s + sub; k < e; k += W)
+               {
+                  double t = prod[k - ka];
+                  if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
+                  sum += t;
+               }
+            }
+            sum = subwave_sum<W>(sum);
+            if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
+         }
+      }
+      __syncthreads();
+      if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, rowsum[tid], ops); }
+   }
+}
+
+// ---------------------------------------------------------------------------
+// Wave-per-row SpMV: fallback for matrices with rows longer than SPMV_MAXROW
+// or misaligned arrays (never hit by the AMG hierarchies of the benchmark).
+// ---------------------------------------------------------------------------
+template <int OP, bool F32, bool HASFILL>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_wave_kernel(SpmvArgs p, int num_rows)
+{
+   const int lane   = threadIdx.x & 63;
+   const int wave   = (blockIdx.x * SPMV_THREADS + threadIdx.x) >> 6;
+   const int nwaves = (gridDim.x * SPMV_THREADS) >> 6;
+   for (int row = wave; row < num_rows; row += nwaves)
+   {
+      const int s = p.Ai[row], e = p.Ai[row + 1];
+      double sum = 0.0;
+      for (int k = s + lane; k < e; k += 64)
+      {
+         const int c = p.Aj[k];
+         double v = F32 ? (double) p.Aa32[k] : p.Aa[k];
+         if (HASFILL) { if (!fill_keep(p.fill, row, c)) { v = 0.0; } }
+         sum += v * p.x[c];
+      }
+      sum = wave_sum64(sum);
+      if (lane == 0) { const RowOps o = load_row_ops<OP>(p, row); row_epilogue<OP>(p, row, sum, o); }
+   }
+}
+
+// y[row] += alpha * (A x)[row] over the listed non-empty rows only (offd blocks:
+// seq_mv/csr_matvec.c:381-670 rownnz path).  8 lanes per listed row.
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_rownnz_kernel(SpmvArgs p, const int *__restrict__ rownnz, int num_rownnz)
+{
+   const int g   = (blockIdx.x * SPMV_THREADS + threadIdx.x) >> 3;
+   const int sub = threadIdx.x & 7;
+   double sum = 0.0;
+   int row = 0;
+   if (g < num_rownnz)
+   {
+      row = rownnz[g];
+      const int s = p.Ai[row], e = p.Ai[row + 1];
+      for (int k = s + sub; k < e; k += 8)
+      {
+         const double v = p.Aa32 ? (double) p.Aa32[k] : p.Aa[k];
+         sum += v * p.x[p.Aj[k]];
+      }
+   }
+   sum = subwave_sum<8>(sum);
+   if (g < num_rownnz && sub == 0) { p.y[row] += p.alpha * sum; }
+}
+
+// ---------------------------------------------------------------------------
+// plan construction
+// ---------------------------------------------------------------------------
+// tile_row[b] = first row r with Ai[r] >= b*TILE (a row belongs to the tile its
+// first entry falls into); tile_k[b] = Ai[tile_row[b]].
+__global__ void build_tiles_kernel(const int *__restrict__ Ai, int num_rows, int num_tiles,
+                                   int *__restrict__ tile_row, int *__restrict__ tile_k)
+{
+   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b > num_tiles) { return; }
+   if (b == num_tiles) { tile_row[b] = num_rows; tile_k[b] = Ai[num_rows]; return; }
+   const long long target = (long long) b * SPMV_TILE;
+   int lo = 0, hi = num_rows;
+   while (lo < hi)
+   {
+      const int mid = (lo + hi) >> 1;
+      if ((long long) Ai[mid] >= target) { hi = mid; } else { lo = mid + 1; }
+   }
+   tile_row[b] = lo;
+   tile_k[b] = Ai[lo];
+}
+
+__global__ void max_row_nnz_kernel(const int *__restrict__ Ai, int num_rows, int *__restrict__ out)
+{
+   int m = 0;
+   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < num_rows; r += gridDim.x * blockDim.x)
+   {
+      m = max(m, Ai[r + 1] - Ai[r]);
+   }
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off, 64)); }
+   if ((threadIdx.x & 63) == 0) { atomicMax(out, m); }
+}
+
+void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
+                        int *d_tile_k, hipStream_t s)
+{
+   (void) nnz;
+   const int n = num_tiles + 1;
+   hipLaunchKernelGGL(build_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, num_rows,
+                      num_tiles, d_tile_row, d_tile_k);
+}
+
+int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
+{
+   if (num_rows <= 0) { return 0; }
+   int *d_out = reinterpret_cast<int *>(reduce_scratch(2));
+   HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(int), s));
+   int grid = (num_rows + 255) / 256;
+   if (grid > 2048) { grid = 2048; }
+   hipLaunchKernelGGL(max_row_nnz_kernel, dim3(grid), dim3(256), 0, s, Ai, num_rows, d_out);
+   int h = 0;
+   HIP_CHECK(hipMemcpyAsync(&h, d_out, sizeof(int), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   return h;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+template <int OP, bool F32, bool FILL>
+static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   const int grid = ((plan->num_tiles + 7) / 8) * 8;
+   const int prod_elems = plan->prod_elems;
+   const size_t lds = sizeof(double) * (size_t) (prod_elems + SPMV_THREADS) + sizeof(int) * (size_t) (RP_CAP + 4);
+   static bool attr_set = false;
+   if (!attr_set)
+   {
+      // allow > 64 KiB of dynamic LDS should a plan ever ask for it
+      (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_tiled_kernel<OP, F32, FILL>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr_set = true;
+   }
+   hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
+                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, prod_elems);
+}
+
+template <int OP>
+static void launch_spmv_op(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   const bool f32  = a.Aa32 != nullptr;
+   const bool fill = a.fill != HYPRE_SPMV_FILL_WHOLE;
+   if (plan->tiled)
+   {
+      if (f32) { if (fill) launch_tiled<OP, true, true>(plan, a, s); else launch_tiled<OP, true, false>(plan, a, s); }
+      else     { if (fill) launch_tiled<OP, false, true>(plan, a, s); else launch_tiled<OP, false, false>(plan, a, s); }
+   }
+   else
+   {
+      int grid = (plan->num_rows + 3) / 4;
+      if (grid > 4096) { grid = 4096; }
+      if (grid < 1) { grid = 1; }
+      dim3 g(grid), b(SPMV_THREADS);
+      if (f32)
+      {
+         if (fill) hipLaunchKernelGGL((spmv_wave_kernel<OP, true, true>), g, b, 0, s, a, plan->num_rows);
+         else      hipLaunchKernelGGL((spmv_wave_kernel<OP, true, false>), g, b, 0, s, a, plan->num_rows);
+      }
+      else
+      {
+         if (fill) hipLaunchKernelGGL((spmv_wave_kernel<OP, false, true>), g, b, 0, s, a, plan->num_rows);
+         else      hipLaunchKernelGGL((spmv_wave_kernel<OP, false, false>), g, b, 0, s, a, plan->num_rows);
+      }
+   }
+}
+
+void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s)
+{
+   if (plan->num_rows <= 0) { return; }
+   switch (op)
+   {
+      case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, args, s); break;
+      case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, args, s); break;
+      case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, args, s); break;
+      case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, args, s); break;
+   }
+}
+
+void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s)
+{
+   if (num_rownnz <= 0) { return; }
+   const int grid = (num_rownnz * 8 + SPMV_THREADS - 1) / SPMV_THREADS;
+   hipLaunchKernelGGL(spmv_rownnz_kernel, dim3(grid), dim3(SPMV_THREADS), 0, s, args, rownnz, num_rownnz);
+}
+
+}  // namespace hamd
