@@ -120,7 +120,10 @@ struct SpmvArgs
    HYPRE_Complex        alpha, beta;
    int                  fill;     // HYPRE_SPMV_FILL_*
    int                  row_offset;
+   int                  stream_nt;   // non-temporal loads for the (col,val) streams
+   int                  xcd_map;     // XCD-contiguous tile order
 };
+void spmv_default_flags(SpmvArgs &a);   // fills stream_nt / xcd_map from the tuning knobs
 
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);

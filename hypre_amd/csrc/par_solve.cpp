@@ -101,6 +101,7 @@ void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_mark
    a.x = u_in; a.b = f; a.y = u_out; a.aux = nullptr; a.d = d;
    a.marker = cf_marker; a.marker_val = relax_points;
    a.alpha = w; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_WHOLE; a.row_offset = 0;
+   spmv_default_flags(a);
    launch_spmv(plan, a, (relax_points != 0 && cf_marker) ? OP_JACOBI_CF : OP_JACOBI, s);
 }
 
@@ -166,6 +167,7 @@ HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, h
          a.Ai = diag->i; a.Aj = diag->j; a.Aa = diag->data; a.Aa32 = nullptr;
          a.x = zin; a.b = nullptr; a.y = zout; a.aux = ud; a.d = A_diag_diag; a.marker = nullptr;
          a.alpha = mult; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_STRICT_LOWER;
+         spmv_default_flags(a);
          launch_spmv(plan, a, OP_TSGS, s);
          std::swap(zin, zout);
          mult *= -1.0;

@@ -24,6 +24,39 @@
 
 namespace hamd {
 
+typedef int    v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float  v4f __attribute__((ext_vector_type(4)));
+
+// The (col, val) streams are read exactly once: load them with the
+// non-temporal policy so they do not push the re-used x window out of L2.
+template <bool NT>
+__device__ __forceinline__ int4 load_cols(const int *p)
+{
+   v4i v;
+   if (NT) { v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p)); } else { v = *reinterpret_cast<const v4i *>(p); }
+   return make_int4(v.x, v.y, v.z, v.w);
+}
+template <bool NT>
+__device__ __forceinline__ void load_vals(const double *p, double &a, double &b, double &c, double &d)
+{
+   v2d lo, hi;
+   if (NT)
+   {
+      lo = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
+      hi = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p + 2));
+   }
+   else { lo = *reinterpret_cast<const v2d *>(p); hi = *reinterpret_cast<const v2d *>(p + 2); }
+   a = lo.x; b = lo.y; c = hi.x; d = hi.y;
+}
+template <bool NT>
+__device__ __forceinline__ void load_vals32(const float *p, double &a, double &b, double &c, double &d)
+{
+   v4f v;
+   if (NT) { v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)); } else { v = *reinterpret_cast<const v4f *>(p); }
+   a = v.x; b = v.y; c = v.z; d = v.w;
+}
+
 __device__ __forceinline__ double wave_sum64(double v)
 {
 #pragma unroll
@@ -103,7 +136,7 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double 
 
 constexpr int RP_CAP = 640;      // row pointers staged in LDS per tile
 
-template <int OP, bool F32, bool HASFILL>
+template <int OP, bool F32, bool HASFILL, bool NT>
 __global__ __launch_bounds__(SPMV_THREADS)
 void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
                        int num_tiles, int prod_elems)
@@ -117,7 +150,7 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    // (workgroup g -> XCD g % 8); give every XCD one contiguous eighth of the
    // tiles.  Speed only: any placement is correct.
    const int per_xcd = (num_tiles + 7) >> 3;
-   const int tile    = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+   const int tile    = p.xcd_map ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int) blockIdx.x;
    if (tile >= num_tiles) { return; }
 
    const int r0 = tile_row[tile];
@@ -136,25 +169,13 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    double vA0 = 0, vA1 = 0, vA2 = 0, vA3 = 0, vB0 = 0, vB1 = 0, vB2 = 0, vB3 = 0;
    if (kA < k1)
    {
-      cA = *reinterpret_cast<const int4 *>(p.Aj + kA);
-      if (F32) { const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + kA); vA0 = v.x; vA1 = v.y; vA2 = v.z; vA3 = v.w; }
-      else
-      {
-         const double2 a = *reinterpret_cast<const double2 *>(p.Aa + kA);
-         const double2 b = *reinterpret_cast<const double2 *>(p.Aa + kA + 2);
-         vA0 = a.x; vA1 = a.y; vA2 = b.x; vA3 = b.y;
-      }
+      cA = load_cols<NT>(p.Aj + kA);
+      if (F32) { load_vals32<NT>(p.Aa32 + kA, vA0, vA1, vA2, vA3); } else { load_vals<NT>(p.Aa + kA, vA0, vA1, vA2, vA3); }
    }
    if (kB < k1)
    {
-      cB = *reinterpret_cast<const int4 *>(p.Aj + kB);
-      if (F32) { const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + kB); vB0 = v.x; vB1 = v.y; vB2 = v.z; vB3 = v.w; }
-      else
-      {
-         const double2 a = *reinterpret_cast<const double2 *>(p.Aa + kB);
-         const double2 b = *reinterpret_cast<const double2 *>(p.Aa + kB + 2);
-         vB0 = a.x; vB1 = a.y; vB2 = b.x; vB3 = b.y;
-      }
+      cB = load_cols<NT>(p.Aj + kB);
+      if (F32) { load_vals32<NT>(p.Aa32 + kB, vB0, vB1, vB2, vB3); } else { load_vals<NT>(p.Aa + kB, vB0, vB1, vB2, vB3); }
    }
 
    // ---- phase 0: row pointers -> LDS, this lane's epilogue operands -> registers
@@ -201,15 +222,9 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    // tail of a tile whose last row runs past 2 quads per lane
    for (int k = kB + 4 * SPMV_THREADS; k < k1; k += 4 * SPMV_THREADS)
    {
-      const int4 c = *reinterpret_cast<const int4 *>(p.Aj + k);
+      const int4 c = load_cols<NT>(p.Aj + k);
       double v0, v1, v2, v3;
-      if (F32) { const float4 v = *reinterpret_cast<const float4 *>(p.Aa32 + k); v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w; }
-      else
-      {
-         const double2 a = *reinterpret_cast<const double2 *>(p.Aa + k);
-         const double2 b = *reinterpret_cast<const double2 *>(p.Aa + k + 2);
-         v0 = a.x; v1 = a.y; v2 = b.x; v3 = b.y;
-      }
+      if (F32) { load_vals32<NT>(p.Aa32 + k, v0, v1, v2, v3); } else { load_vals<NT>(p.Aa + k, v0, v1, v2, v3); }
       double *dst = prod + (k - ka);
       if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
       if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
@@ -403,8 +418,8 @@ int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-template <int OP, bool F32, bool FILL>
-static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+template <int OP, bool F32, bool FILL, bool NT>
+static void launch_tiled_nt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
    const int grid = ((plan->num_tiles + 7) / 8) * 8;
    const int prod_elems = plan->prod_elems;
@@ -413,12 +428,19 @@ static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
    if (!attr_set)
    {
       // allow > 64 KiB of dynamic LDS should a plan ever ask for it
-      (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_tiled_kernel<OP, F32, FILL>),
+      (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_tiled_kernel<OP, F32, FILL, NT>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
       attr_set = true;
    }
-   hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
+   hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL, NT>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
                       plan->d_tile_row, plan->d_tile_k, plan->num_tiles, prod_elems);
+}
+
+template <int OP, bool F32, bool FILL>
+static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   if (a.stream_nt) { launch_tiled_nt<OP, F32, FILL, true>(plan, a, s); }
+   else { launch_tiled_nt<OP, F32, FILL, false>(plan, a, s); }
 }
 
 template <int OP>
