@@ -46,6 +46,13 @@ void dev_par_matvecT(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, const double *x
 void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_marker, int relax_points,
                       double w, const double *d, const double *u_in, double *u_out);
 
+// distributed setup pieces (par_amg_setup_dist.cpp)
+HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                  HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts,
+                                  HYPRE_Real trunc_factor, HYPRE_Int max_elmts, hypre_ParCSRMatrix **P_ptr);
+HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
+                                     HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr);
+
 void launch_jacobi_update(const double *u_in, const double *r, const double *d, const int *marker, int mval,
                           double *u_out, size_t n, hipStream_t s);
 void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStream_t s);

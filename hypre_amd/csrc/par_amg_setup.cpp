@@ -673,8 +673,11 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
    MPI_Comm comm = A->comm;
    if (comm_size(comm) > 1)
    {
-      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildExtPIInterp: distributed setup is not available yet");
-      return hypre_error_flag;
+      // total number of coarse points = upper bound of the last rank's range
+      const hypre_amd_CommOps *o = comm_ops(comm);
+      std::vector<HYPRE_BigInt> ends((size_t) o->size);
+      o->allgather(o->ctx, &num_cpts_global[1], ends.data(), sizeof(HYPRE_BigInt));
+      return dist_build_extpi_interp(A, CF_marker, S, num_cpts_global, ends.back(), trunc_factor, max_elmts, P_ptr);
    }
    hypre_CSRMatrix *Ad = A->diag;
    const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
@@ -883,11 +886,7 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
                                                hypre_ParCSRMatrix **RAP_ptr)
 {
    MPI_Comm comm = A->comm;
-   if (comm_size(comm) > 1)
-   {
-      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildCoarseOperatorKT: distributed setup is not available yet");
-      return hypre_error_flag;
-   }
+   if (comm_size(comm) > 1) { return dist_build_coarse_operator(RT, A, P, keepTranspose, RAP_ptr); }
    hypre_CSRMatrix *R = nullptr;
    hypre_CSRMatrixTranspose(RT->diag, &R, 1);
    const HYPRE_Int nc = R->num_rows, nf = A->diag->num_rows;

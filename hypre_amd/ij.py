@@ -18,7 +18,7 @@ class IJOptions:
 
     def __init__(self, **kw):
         self.n = (10, 10, 10)
-        self.P = None                 # (P, Q, R); default (nprocs, 1, 1)
+        self.P = None                 # (P, Q, R); default (1, nprocs, 1)
         self.problem = "laplacian"    # laplacian | 27pt | difconv
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
@@ -101,7 +101,7 @@ def stencil_values(opt):
 
 def build_matrix(opt, comm=0, rank=0, nprocs=1):
     """Rank (p,q,r) = (id % P, (id / P) % Q, id / (P*Q))   (test/ij.c:9693-9695)."""
-    P, Q, R = opt.P if opt.P else (nprocs, 1, 1)
+    P, Q, R = opt.P if opt.P else (1, nprocs, 1)     # test/ij.c BuildParLaplacian: P = 1, Q = num_procs, R = 1
     if P * Q * R != nprocs:
         raise ValueError("P*Q*R must equal the number of ranks")
     p, q, r = rank % P, (rank // P) % Q, rank // (P * Q)

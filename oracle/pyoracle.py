@@ -312,6 +312,84 @@ def amg_from_solvers(solvers, num_threads=1):
                user_relax_type=d.user_relax_type)
 
 
+def export_par(h):
+    """Picklable numpy view of one rank's block of a hypre_ParCSRMatrix."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    if not isinstance(h, C.POINTER(B.ParCSRMatrix)):
+        h = C.cast(h, C.POINTER(B.ParCSRMatrix))
+    m = h.contents
+    di, dj, da = B.csr_to_arrays(m.diag)
+    oi, oj, oa = B.csr_to_arrays(m.offd)
+    nco = m.offd.contents.num_cols
+    cmap = np.array([m.col_map_offd[k] for k in range(nco)], dtype=np.int64)
+    return dict(di=di, dj=dj, da=da, oi=oi, oj=oj, oa=oa, cmap=cmap, nrows=m.diag.contents.num_rows,
+                ncols=m.diag.contents.num_cols, nco=nco, rs=(int(m.row_starts[0]), int(m.row_starts[1])),
+                cs=(int(m.col_starts[0]), int(m.col_starts[1])))
+
+
+def par_from_exports(parts):
+    blocks, rs, cs = [], [], []
+    for d in parts:
+        rn = np.nonzero(np.diff(d["oi"]))[0].astype(np.int32)
+        with_rn = rn if (0 < len(rn) < d["nrows"]) else None
+        blocks.append((Csr(d["nrows"], d["ncols"], d["di"], d["dj"], d["da"]),
+                       Csr(d["nrows"], d["nco"], d["oi"], d["oj"], d["oa"], with_rn), d["cmap"]))
+        rs.append(d["rs"][0]); cs.append(d["cs"][0])
+    rs.append(parts[-1]["rs"][1]); cs.append(parts[-1]["cs"][1])
+    return Par(blocks, rs, cs)
+
+
+def export_solver(s):
+    """This rank's share of the hierarchy as plain numpy (for gathering to one process)."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    L = B.load_library()
+    nl = L.hypre_amd_BoomerAMGGetNumLevels(s)
+    out = dict(num_levels=nl, A=[], P=[], cf=[], l1=[])
+    for l in range(nl):
+        out["A"].append(export_par(L.hypre_amd_BoomerAMGGetA(s, l)))
+        if l < nl - 1:
+            out["P"].append(export_par(L.hypre_amd_BoomerAMGGetP(s, l)))
+        cfp = L.hypre_amd_BoomerAMGGetCFMarker(s, l)
+        if cfp:
+            ia = C.cast(cfp, C.POINTER(B.IntArray)).contents
+            out["cf"].append(B.fetch(ia.data, ia.size, np.int32, ia.memory_location))
+        else:
+            out["cf"].append(None)
+        lp = L.hypre_amd_BoomerAMGGetL1Norms(s, l)
+        if lp:
+            v = C.cast(lp, C.POINTER(B.Vector)).contents
+            out["l1"].append(B.fetch(v.data, v.size, np.float64, v.memory_location))
+        else:
+            out["l1"].append(None)
+    d = C.cast(s, C.POINTER(AmgDataView)).contents
+    out["sweeps"] = [L.hypre_amd_BoomerAMGGetNumGridSweeps(s, k) for k in range(4)]
+    out["types"] = [L.hypre_amd_BoomerAMGGetGridRelaxType(s, k) for k in range(4)]
+    out["rw"] = np.array([d.relax_weight[k] for k in range(nl)])
+    out["om"] = np.array([d.omega[k] for k in range(nl)])
+    out["relax_order"], out["cycle_type"], out["fcycle"] = d.relax_order, d.cycle_type, d.fcycle
+    out["max_levels"], out["user_relax_type"] = d.max_levels, d.user_relax_type
+    return out
+
+
+def amg_from_exports(parts, num_threads=1):
+    """parts: export_solver() dicts of all ranks in rank order."""
+    p0 = parts[0]
+    nl = p0["num_levels"]
+    A_levels = [par_from_exports([p["A"][l] for p in parts]) for l in range(nl)]
+    P_levels = [par_from_exports([p["P"][l] for p in parts]) for l in range(nl - 1)]
+    cfs, l1s = [], []
+    for l in range(nl):
+        c = [p["cf"][l] for p in parts]
+        cfs.append(np.concatenate(c) if all(x is not None for x in c) else None)
+        v = [p["l1"][l] for p in parts]
+        l1s.append(np.concatenate(v) if all(x is not None for x in v) else None)
+    return Amg(A_levels, P_levels, cfs, l1s, p0["sweeps"], p0["types"], relax_order=p0["relax_order"],
+               relax_weight=p0["rw"], omega=p0["om"], cycle_type=p0["cycle_type"], fcycle=p0["fcycle"],
+               num_threads=num_threads, max_levels=p0["max_levels"], user_relax_type=p0["user_relax_type"])
+
+
 class AmgDataView(C.Structure):
     """Leading members of hypre_ParAMGData (include/hypre_amd_parcsr_ls.h) up to omega."""
     _fields_ = [("setup", C.c_void_p), ("solve", C.c_void_p), ("destroy", C.c_void_p), ("memory_location", C.c_int),

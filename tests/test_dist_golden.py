@@ -1,0 +1,40 @@
+"""CPU, multi-process (gloo): the reference's multi-rank regression goldens
+(test/TEST_ij/{default,smoother,solvers}.saved) reproduced by the library's DISTRIBUTED
+host setup (halo exchange, ghost-row fetch, distributed ext+i interpolation and RAP over
+a callback communicator) + the CPU oracle's solve on the gathered hierarchy."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "ij_saved.json")))
+_port = [29700]
+
+
+def run_ranks(nranks, case, timeout=240):
+    _port[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_port[0]), os.path.join(HERE, "dist_worker.py"),
+           json.dumps({"options": case["options"]})]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(lines[-1][len("RESULT "):])
+
+
+@pytest.mark.parametrize("name", sorted(k for k, v in GOLD.items() if v.get("ranks", 1) > 1))
+def test_multi_rank_goldens(name):
+    case = GOLD[name]
+    out = run_ranks(case["ranks"], case)
+    exp = case["expect"]
+    if "iterations" in exp:
+        assert out["iterations"] == exp["iterations"]
+    if "rel_resid" in exp:
+        assert abs(out["rel_resid"] - exp["rel_resid"]) <= 5e-7 * exp["rel_resid"]
+    for key in ("conv_factor", "grid", "operator"):
+        if key in exp:
+            assert abs(out[key] - exp[key]) < 5.1e-7, (key, out[key], exp[key])

@@ -33,7 +33,8 @@ def _run(lib, oracle, case):
         its, rel, conv, hist = amg.solve(b, x, tol=opt.tol, max_iter=opt.mg_max_iter)
         out.update(iterations=its, rel_resid=rel, conv_factor=(hist[-1] / hist[0]) ** (1.0 / its))
     else:
-        its, rel, conv = amg.pcg(b, x, tol=opt.tol, max_iter=opt.max_iter, two_norm=opt.two_norm)
+        its, rel, conv = amg.pcg(b, x, tol=opt.tol, max_iter=opt.max_iter, two_norm=opt.two_norm,
+                                 precond_cycles=opt.precon_cycles)
         out.update(iterations=its, rel_resid=rel)
     lib.HYPRE_BoomerAMGDestroy(s)
     return out
