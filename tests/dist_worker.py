@@ -25,7 +25,8 @@ def main():
     comm = distributed.create_callback_comm(dist, rank, world)
     opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
-    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_HOST)
+    device = bool(case.get("device", 0))
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE if device else B.HYPRE_MEMORY_HOST)
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
     B.check()
     g, o = C.c_double(), C.c_double()
@@ -39,6 +40,49 @@ def main():
 
     b, x = ij.build_rhs_host(opt, A, rank=rank, allreduce=allsum)
     mine = dict(h=O.export_solver(s), b=b, x=x)
+    if device:
+        # the product path: distributed solve on the GPU (two ranks may share one card in the
+        # test; halo traffic goes through the callback communicator, staged over the host)
+        Am = A.contents
+        first, nglob = int(Am.row_starts[0]), int(Am.global_num_rows)
+        L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+        if b is None:
+            ones = B.parvec_from_numpy(np.ones(len(x)), comm=comm, global_size=nglob, first=first)
+            db = B.parvec_from_numpy(np.zeros(len(x)), comm=comm, global_size=nglob, first=first)
+            L.hypre_ParCSRMatrixMatvec(1.0, A, ones, 0.0, db)
+        else:
+            db = B.parvec_from_numpy(b, comm=comm, global_size=nglob, first=first)
+        dx = B.parvec_from_numpy(x, comm=comm, global_size=nglob, first=first)
+        # y = A x and z = A^T y through the distributed device products, for the oracle to check
+        xt = np.cos(np.arange(first, first + len(x)) * 0.37)
+        dxt = B.parvec_from_numpy(xt, comm=comm, global_size=nglob, first=first)
+        dy = B.parvec_from_numpy(np.zeros(len(x)), comm=comm, global_size=nglob, first=first)
+        dz = B.parvec_from_numpy(np.ones(len(x)), comm=comm, global_size=nglob, first=first)
+        L.hypre_ParCSRMatrixMatvec(2.0, A, dxt, 0.0, dy)
+        L.hypre_ParCSRMatrixMatvecT(1.0, A, dy, -0.5, dz)
+        dot = L.hypre_ParVectorInnerProd(dxt, dy)
+        if opt.solver == 0:
+            L.HYPRE_BoomerAMGSolve(s, A, db, dx)
+            its, rel = C.c_int(), C.c_double()
+            L.HYPRE_BoomerAMGGetNumIterations(s, C.byref(its))
+            L.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+        else:
+            L.HYPRE_BoomerAMGSetTol(s, 0.0)
+            L.HYPRE_BoomerAMGSetMaxIter(s, opt.precon_cycles)
+            pcg = C.c_void_p()
+            L.HYPRE_ParCSRPCGCreate(comm, C.byref(pcg))
+            L.HYPRE_PCGSetTol(pcg, opt.tol)
+            L.HYPRE_PCGSetMaxIter(pcg, opt.max_iter)
+            L.HYPRE_PCGSetTwoNorm(pcg, opt.two_norm)
+            L.HYPRE_PCGSetPrecond(pcg, C.cast(L.HYPRE_BoomerAMGSolve, C.c_void_p), None, s)
+            L.HYPRE_ParCSRPCGSetup(pcg, A, db, dx)
+            L.HYPRE_ParCSRPCGSolve(pcg, A, db, dx)
+            its, rel = C.c_int(), C.c_double()
+            L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
+            L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
+        B.check()
+        mine.update(dev_its=its.value, dev_rel=rel.value, dev_x=B.parvec_to_numpy(dx), xt=xt,
+                    dev_y=B.parvec_to_numpy(dy), dev_z=B.parvec_to_numpy(dz), dev_dot=dot)
     parts = [None] * world if rank == 0 else None
     dist.gather_object(mine, parts, dst=0)
     if rank == 0:
@@ -59,6 +103,21 @@ def main():
             its, rel, conv = amg.pcg(bg, xg, tol=opt.tol, max_iter=opt.max_iter, two_norm=opt.two_norm,
                                      precond_cycles=opt.precon_cycles)
             out.update(iterations=its, rel_resid=rel)
+        if device:
+            A0 = amg.A_levels[0]
+            xt = np.concatenate([p["xt"] for p in parts])
+            yr = np.zeros(n)
+            O.par_matvec(2.0, A0, xt, 0.0, yr, yr)
+            zr = np.ones(n)
+            O.par_matvecT(1.0, A0, yr, -0.5, zr)
+            yd = np.concatenate([p["dev_y"] for p in parts])
+            zd = np.concatenate([p["dev_z"] for p in parts])
+            xd = np.concatenate([p["dev_x"] for p in parts])
+            out.update(dev_iterations=parts[0]["dev_its"], dev_rel_resid=parts[0]["dev_rel"],
+                       matvec_err=float(np.max(np.abs(yd - yr)) / np.max(np.abs(yr))),
+                       matvecT_err=float(np.max(np.abs(zd - zr)) / np.max(np.abs(zr))),
+                       dot_err=float(abs(parts[0]["dev_dot"] - float(np.dot(xt, yr))) / abs(float(np.dot(xt, yr)))),
+                       x_err=float(np.max(np.abs(xd - xg)) / np.max(np.abs(xg))))
         print("RESULT " + json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()

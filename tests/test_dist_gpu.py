@@ -1,0 +1,31 @@
+"""GPU, two ranks sharing the card (gloo as the transport, halo buffers staged over the
+host): the distributed DEVICE path — pack kernel, overlapped interior product, ghost
+product, transpose product with scatter-add, distributed cycle, coarse gather — against
+the CPU oracle running the same hierarchy as virtual ranks.  (The RCCL transport itself
+needs one GPU per rank and is exercised by bench.py --gpus N.)"""
+import pytest
+
+from test_dist_golden import GOLD, run_ranks
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["smoother.out.10", "smoother.out.9", "solvers.out.21", "default.out.1"])
+def test_two_or_three_ranks_on_device(name):
+    case = dict(GOLD[name])
+    out = run_ranks(case["ranks"], {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1})
+    exp = case["expect"]
+    assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
+    assert out["dev_iterations"] == out["iterations"]
+    assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
+    assert out["x_err"] < 1e-9
+    if "iterations" in exp:
+        assert out["dev_iterations"] == exp["iterations"]
+        assert abs(out["dev_rel_resid"] - exp["rel_resid"]) <= 5e-7 * exp["rel_resid"]
+
+
+def test_pcg_three_ranks_on_device():
+    case = dict(GOLD["solvers.out.19"])
+    out = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1})
+    assert out["dev_iterations"] == case["expect"]["iterations"] == out["iterations"]
+    assert abs(out["dev_rel_resid"] - case["expect"]["rel_resid"]) <= 5e-7 * case["expect"]["rel_resid"]
