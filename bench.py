@@ -62,11 +62,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     dist = None
+    # HYPRE_AMD_BENCH_TRANSPORT=gloo: rehearsal mode (ranks may share one GPU, halo traffic staged
+    # over the host through torch.distributed/gloo).  Default: RCCL over xGMI, one GPU per rank.
+    transport = os.environ.get("HYPRE_AMD_BENCH_TRANSPORT", "rccl")
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if transport == "gloo":
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from hypre_amd import binding as B, ij
     L = B.load_library()          # raises when the HIP library is missing: no fallback exists
@@ -76,7 +83,10 @@ def main():
     comm = 0
     if world > 1:
         from hypre_amd import distributed
-        comm = distributed.create_rccl_comm(dist, rank, world)
+        if transport == "gloo":
+            comm = distributed.create_callback_comm(dist, rank, world)
+        else:
+            comm = distributed.create_rccl_comm(dist, rank, world)
 
     P, Q, R = proc_grid(world)
     n1 = args.n
@@ -121,7 +131,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if transport == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     B.check()
