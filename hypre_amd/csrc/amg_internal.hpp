@@ -46,6 +46,9 @@ void dev_par_matvecT(HYPRE_Complex alpha, hypre_ParCSRMatrix *A, const double *x
 void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_marker, int relax_points,
                       double w, const double *d, const double *u_in, double *u_out);
 
+hypre_ParCSRCommHandle *dev_halo_begin(hypre_ParCSRMatrix *A, const double *x_local);
+void dev_halo_end(hypre_ParCSRCommHandle *h);
+
 // distributed setup pieces (par_amg_setup_dist.cpp)
 HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
                                   HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts,

@@ -127,6 +127,7 @@ void spmv_default_flags(SpmvArgs &a);   // fills stream_nt / xcd_map from the tu
 
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);
+void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s);
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
                         int *d_tile_k, hipStream_t s);
 int  device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s);

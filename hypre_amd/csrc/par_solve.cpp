@@ -87,14 +87,10 @@ void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_mark
    if (n <= 0) { return; }
    HYPRE_Int nprocs;
    hypre_MPI_Comm_size(A->comm, &nprocs);
-   if (nprocs > 1 && A->offd->num_cols > 0)
-   {
-      // r = w f - w A u (with halo), then the update; two passes but still no copy-back
-      double *r = u_out;          // use the output buffer as residual scratch
-      dev_par_matvec(-w, A, u_in, w, f, r);
-      launch_jacobi_update(u_in, r, d, cf_marker, relax_points, u_out, (size_t) n, s);
-      return;
-   }
+   // distributed: start the halo of u_in, run the fused interior sweep while it
+   // travels, then fold the ghost couplings into the boundary rows
+   //    u_out[row] -= w * (A_offd u_ghost)[row] / d[row]        (halo-sized pass)
+   hypre_ParCSRCommHandle *ch = nprocs > 1 ? dev_halo_begin(A, u_in) : nullptr;
    SpmvPlan *plan = get_plan(diag);
    SpmvArgs a{};
    a.Ai = diag->i; a.Aj = diag->j; a.Aa = diag->data; a.Aa32 = nullptr;
@@ -103,6 +99,18 @@ void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_mark
    a.alpha = w; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_WHOLE; a.row_offset = 0;
    spmv_default_flags(a);
    launch_spmv(plan, a, (relax_points != 0 && cf_marker) ? OP_JACOBI_CF : OP_JACOBI, s);
+   dev_halo_end(ch);
+   hypre_CSRMatrix *offd = A->offd;
+   if (nprocs > 1 && offd->num_cols > 0 && offd->num_nonzeros > 0)
+   {
+      SpmvArgs o{};
+      o.Ai = offd->i; o.Aj = offd->j; o.Aa = offd->data; o.Aa32 = nullptr;
+      o.x = A->comm_pkg->tmp_data; o.y = u_out; o.d = d;
+      o.marker = (relax_points != 0) ? cf_marker : nullptr; o.marker_val = relax_points;
+      o.alpha = -w;
+      if (offd->rownnz) { launch_spmv_rownnz(offd->rownnz, offd->num_rownnz, o, s); }
+      else { launch_spmv_allrows_update(offd->num_rows, o, s); }
+   }
 }
 
 }  // namespace hamd

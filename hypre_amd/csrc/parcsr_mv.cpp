@@ -533,6 +533,33 @@ static void ensure_pkg_device(hypre_ParCSRCommPkg *pkg, HYPRE_Int num_cols_offd)
    if (!pkg->tmp_data && num_cols_offd) { pkg->tmp_data = hypre_TAlloc(HYPRE_Complex, num_cols_offd, HYPRE_MEMORY_DEVICE); }
 }
 
+}  // extern "C"
+
+namespace hamd {
+// Start the owner -> ghost exchange of a device vector (collective over A's
+// communicator).  Ghost values land in A->comm_pkg->tmp_data once dev_halo_end
+// has made the compute stream wait for them.  Returns nullptr on one rank.
+hypre_ParCSRCommHandle *dev_halo_begin(hypre_ParCSRMatrix *A, const double *x_local)
+{
+   HYPRE_Int nprocs;
+   hypre_MPI_Comm_size(A->comm, &nprocs);
+   if (nprocs <= 1) { return nullptr; }
+   if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+   hypre_ParCSRCommPkg *pkg = A->comm_pkg;
+   if (!pkg->num_sends && !pkg->num_recvs) { return nullptr; }
+   ensure_pkg_device(pkg, A->offd->num_cols);
+   const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
+   launch_gather(x_local, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
+   return hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data, HYPRE_MEMORY_DEVICE, pkg->tmp_data);
+}
+void dev_halo_end(hypre_ParCSRCommHandle *h)
+{
+   if (h) { hypre_ParCSRCommHandleDestroy(h); }
+}
+}  // namespace hamd
+
+extern "C" {
+
 // ===========================================================================
 // ParCSR SpMV
 // ===========================================================================
@@ -558,40 +585,21 @@ HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlaceDevice(HYPRE_Complex alpha, hypre_Pa
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
 
-   hypre_ParCSRCommHandle *ch = nullptr;
+   // x halo: pack on the compute stream, grouped send/recv on the comm stream
+   hypre_ParCSRCommHandle *ch = hamd::dev_halo_begin(A, xl->data);
    hypre_Vector x_ghost{};
    if (nprocs > 1 && num_cols_offd > 0)
    {
-      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
-      hypre_ParCSRCommPkg *pkg = A->comm_pkg;
-      ensure_pkg_device(pkg, num_cols_offd);
-      const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
-      launch_gather(xl->data, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
-      ch = hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data,
-                                           HYPRE_MEMORY_DEVICE, pkg->tmp_data);
-      x_ghost.data = pkg->tmp_data;
+      x_ghost.data = A->comm_pkg->tmp_data;
       x_ghost.size = num_cols_offd;
       x_ghost.num_vectors = 1; x_ghost.vecstride = num_cols_offd; x_ghost.idxstride = 1;
       x_ghost.memory_location = HYPRE_MEMORY_DEVICE;
-   }
-   else if (nprocs > 1)
-   {
-      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }   // collective: every rank takes part
-      if (A->comm_pkg->num_sends)
-      {
-         hypre_ParCSRCommPkg *pkg = A->comm_pkg;
-         ensure_pkg_device(pkg, 0);
-         const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
-         launch_gather(xl->data, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
-         ch = hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data,
-                                              HYPRE_MEMORY_DEVICE, pkg->tmp_data);
-      }
    }
 
    // interior product, overlapped with the exchange
    hypre_CSRMatrixMatvecDevice(0, alpha, diag, xl, beta, bl, yl, 0);
 
-   if (ch) { hypre_ParCSRCommHandleDestroy(ch); }
+   hamd::dev_halo_end(ch);
    if (num_cols_offd > 0 && x_ghost.data)
    {
       hypre_CSRMatrixMatvecDevice(0, alpha, offd, &x_ghost, 1.0, yl, yl, 0);

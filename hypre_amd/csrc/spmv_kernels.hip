@@ -335,8 +335,10 @@ void spmv_wave_kernel(SpmvArgs p, int num_rows)
    }
 }
 
-// y[row] += alpha * (A x)[row] over the listed non-empty rows only (offd blocks:
-// seq_mv/csr_matvec.c:381-670 rownnz path).  8 lanes per listed row.
+// y[row] += alpha * (A x)[row] (./ d[row] when d is given, only rows with
+// marker == marker_val when a marker is given) over the listed non-empty rows
+// (offd blocks: seq_mv/csr_matvec.c:381-670 rownnz path); rownnz == nullptr
+// means all rows.  8 lanes per row.
 __global__ __launch_bounds__(SPMV_THREADS)
 void spmv_rownnz_kernel(SpmvArgs p, const int *__restrict__ rownnz, int num_rownnz)
 {
@@ -346,7 +348,7 @@ void spmv_rownnz_kernel(SpmvArgs p, const int *__restrict__ rownnz, int num_rown
    int row = 0;
    if (g < num_rownnz)
    {
-      row = rownnz[g];
+      row = rownnz ? rownnz[g] : g;
       const int s = p.Ai[row], e = p.Ai[row + 1];
       for (int k = s + sub; k < e; k += 8)
       {
@@ -355,7 +357,13 @@ void spmv_rownnz_kernel(SpmvArgs p, const int *__restrict__ rownnz, int num_rown
       }
    }
    sum = subwave_sum<8>(sum);
-   if (g < num_rownnz && sub == 0) { p.y[row] += p.alpha * sum; }
+   if (g < num_rownnz && sub == 0)
+   {
+      if (p.marker && p.marker[row] != p.marker_val) { return; }
+      double upd = p.alpha * sum;
+      if (p.d) { upd /= p.d[row]; }
+      p.y[row] += upd;
+   }
 }
 
 // ---------------------------------------------------------------------------
@@ -482,6 +490,13 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, args, s); break;
       case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, args, s); break;
    }
+}
+
+void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s)
+{
+   if (num_rows <= 0) { return; }
+   const int grid = (num_rows * 8 + SPMV_THREADS - 1) / SPMV_THREADS;
+   hipLaunchKernelGGL(spmv_rownnz_kernel, dim3(grid), dim3(SPMV_THREADS), 0, s, args, (const int *) nullptr, num_rows);
 }
 
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s)
