@@ -155,6 +155,20 @@ def main():
     spmv_gbs = spmv_bytes / spmv_ms / 1e6
     cycle_bytes = L.hypre_amd_BoomerAMGCycleBytes(s)
     B.check()
+    # HBM traffic per launch cannot be read from inside the process; it is taken from the committed
+    # rocprofv3 --pmc pass over this same kernel and matrix (profiles/), when the workload matches.
+    traffic = None
+    traffic_src = None
+    try:
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_spmv_pmc_summary.json"))
+        if pmc_files:
+            with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as fh:
+                pmc = json.load(fh)
+            if int(pmc.get("algorithmic_bytes_per_launch", -1)) == int(spmv_bytes):
+                traffic = pmc["hbm_traffic_bytes_per_launch"]
+                traffic_src = "profiles/" + pmc_files[-1]
+    except OSError:
+        pass
 
     # ---- CPU baseline: the oracle's V-cycle on the same hierarchy, one core -------------
     cpu = None
@@ -191,7 +205,8 @@ def main():
                        "operator_complexity": o.value, "setup_seconds": setup_s},
             "roofline": {"bound": "hbm", "kernel": "spmv_tiled_kernel<AXPBY> (fine-level y = A x)",
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},
             "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
                        "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,

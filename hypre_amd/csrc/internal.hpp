@@ -120,8 +120,9 @@ struct SpmvArgs
    HYPRE_Complex        alpha, beta;
    int                  fill;     // HYPRE_SPMV_FILL_*
    int                  row_offset;
+   int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
    int                  stream_nt;   // non-temporal loads for the (col,val) streams
-   int                  xcd_map;     // XCD-contiguous tile order
+   int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
 };
 void spmv_default_flags(SpmvArgs &a);   // fills stream_nt / xcd_map from the tuning knobs
 

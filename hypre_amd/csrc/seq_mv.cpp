@@ -22,13 +22,13 @@ namespace hamd {
 // Tuning knobs (A/B-testable without rebuilding): HYPRE_AMD_SPMV_NT, HYPRE_AMD_SPMV_XCD.
 void spmv_default_flags(SpmvArgs &a)
 {
-   static int nt = -1, xcd = -1;
+   static int nt = -1, xcd = 0;
    if (nt < 0)
    {
       const char *e = getenv("HYPRE_AMD_SPMV_NT");
-      nt = e ? atoi(e) : 0;   // measured on MI355X: plain loads 4.70 TB/s vs nt 4.38 TB/s (256^3 7-pt)
+      nt = e ? atoi(e) : 0;   // measured on MI355X (256^3 7-pt): non-temporal stream loads are ~7 % slower than plain ones
       e = getenv("HYPRE_AMD_SPMV_XCD");
-      xcd = e ? atoi(e) : 0;   // measured: dispatch order 4.70 TB/s vs XCD-contiguous 4.37 TB/s
+      xcd = e ? atoi(e) : 0;   // measured: dispatch order 4.96 TB/s, chunks of 4..28 tiles per XCD the same, contiguous eighths 4.59 TB/s
    }
    a.stream_nt = nt; a.xcd_map = xcd;
 }

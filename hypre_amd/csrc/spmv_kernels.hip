@@ -28,35 +28,6 @@ typedef int    v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float  v4f __attribute__((ext_vector_type(4)));
 
-// The (col, val) streams are read exactly once: load them with the
-// non-temporal policy so they do not push the re-used x window out of L2.
-template <bool NT>
-__device__ __forceinline__ int4 load_cols(const int *p)
-{
-   v4i v;
-   if (NT) { v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p)); } else { v = *reinterpret_cast<const v4i *>(p); }
-   return make_int4(v.x, v.y, v.z, v.w);
-}
-template <bool NT>
-__device__ __forceinline__ void load_vals(const double *p, double &a, double &b, double &c, double &d)
-{
-   v2d lo, hi;
-   if (NT)
-   {
-      lo = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p));
-      hi = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p + 2));
-   }
-   else { lo = *reinterpret_cast<const v2d *>(p); hi = *reinterpret_cast<const v2d *>(p + 2); }
-   a = lo.x; b = lo.y; c = hi.x; d = hi.y;
-}
-template <bool NT>
-__device__ __forceinline__ void load_vals32(const float *p, double &a, double &b, double &c, double &d)
-{
-   v4f v;
-   if (NT) { v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)); } else { v = *reinterpret_cast<const v4f *>(p); }
-   a = v.x; b = v.y; c = v.z; d = v.w;
-}
-
 __device__ __forceinline__ double wave_sum64(double v)
 {
 #pragma unroll
@@ -136,104 +107,15 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double 
 
 constexpr int RP_CAP = 640;      // row pointers staged in LDS per tile
 
-template <int OP, bool F32, bool HASFILL, bool NT>
-__global__ __launch_bounds__(SPMV_THREADS)
-void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
-                       int num_tiles, int prod_elems)
+// Per-row reduction of the products parked in LDS and the row epilogue.
+// prod[k - ka] holds entry k of the tile, rp[rr] the row pointer of row r0 + rr
+// (the first RP_CAP + 1 of them), ops the epilogue operands of row r0 + tid.
+template <int OP, bool HASFILL>
+__device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows, int k0, int k1, int ka,
+                                            const double *prod, double *rowsum, const int *rp,
+                                            const RowOps &ops)
 {
-   extern __shared__ __align__(16) unsigned char smem_raw[];
-   double *prod   = reinterpret_cast<double *>(smem_raw);
-   double *rowsum = prod + prod_elems;                       // [SPMV_THREADS]
-   int    *rp     = reinterpret_cast<int *>(rowsum + SPMV_THREADS);   // [RP_CAP + 1]
-
-   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs
-   // (workgroup g -> XCD g % 8); give every XCD one contiguous eighth of the
-   // tiles.  Speed only: any placement is correct.
-   const int per_xcd = (num_tiles + 7) >> 3;
-   const int tile    = p.xcd_map ? (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int) blockIdx.x;
-   if (tile >= num_tiles) { return; }
-
-   const int r0 = tile_row[tile];
-   const int r1 = tile_row[tile + 1];
-   if (r1 <= r0) { return; }
-   const int k0 = tile_k[tile];
-   const int k1 = tile_k[tile + 1];
-   const int ka = k0 & ~3;
    const int tid = threadIdx.x;
-   const int nrows = r1 - r0;
-
-   // ---- phase 1a: issue the matrix stream (two quads per lane) --------------
-   const int kA = ka + 4 * tid;
-   const int kB = kA + 4 * SPMV_THREADS;
-   int4 cA = make_int4(0, 0, 0, 0), cB = make_int4(0, 0, 0, 0);
-   double vA0 = 0, vA1 = 0, vA2 = 0, vA3 = 0, vB0 = 0, vB1 = 0, vB2 = 0, vB3 = 0;
-   if (kA < k1)
-   {
-      cA = load_cols<NT>(p.Aj + kA);
-      if (F32) { load_vals32<NT>(p.Aa32 + kA, vA0, vA1, vA2, vA3); } else { load_vals<NT>(p.Aa + kA, vA0, vA1, vA2, vA3); }
-   }
-   if (kB < k1)
-   {
-      cB = load_cols<NT>(p.Aj + kB);
-      if (F32) { load_vals32<NT>(p.Aa32 + kB, vB0, vB1, vB2, vB3); } else { load_vals<NT>(p.Aa + kB, vB0, vB1, vB2, vB3); }
-   }
-
-   // ---- phase 0: row pointers -> LDS, this lane's epilogue operands -> registers
-   for (int t = tid; t <= nrows && t <= RP_CAP; t += SPMV_THREADS) { rp[t] = p.Ai[r0 + t]; }
-   RowOps ops;
-   ops.b = 0.0; ops.d = 1.0; ops.x = 0.0; ops.m = 0;
-   if (tid < nrows) { ops = load_row_ops<OP>(p, r0 + tid); }
-
-   // ---- phase 1b: gather x, stage products ----------------------------------
-   if (kA < k1)
-   {
-      double *dst = prod + (kA - ka);
-      if (kA >= k0 && kA + 4 <= k1)
-      {
-         const double x0 = p.x[cA.x], x1 = p.x[cA.y], x2 = p.x[cA.z], x3 = p.x[cA.w];
-         *reinterpret_cast<double2 *>(dst)     = make_double2(vA0 * x0, vA1 * x1);
-         *reinterpret_cast<double2 *>(dst + 2) = make_double2(vA2 * x2, vA3 * x3);
-      }
-      else
-      {
-         if (kA     >= k0 && kA     < k1) { dst[0] = vA0 * p.x[cA.x]; }
-         if (kA + 1 >= k0 && kA + 1 < k1) { dst[1] = vA1 * p.x[cA.y]; }
-         if (kA + 2 >= k0 && kA + 2 < k1) { dst[2] = vA2 * p.x[cA.z]; }
-         if (kA + 3 >= k0 && kA + 3 < k1) { dst[3] = vA3 * p.x[cA.w]; }
-      }
-   }
-   if (kB < k1)
-   {
-      double *dst = prod + (kB - ka);
-      if (kB + 4 <= k1)
-      {
-         const double x0 = p.x[cB.x], x1 = p.x[cB.y], x2 = p.x[cB.z], x3 = p.x[cB.w];
-         *reinterpret_cast<double2 *>(dst)     = make_double2(vB0 * x0, vB1 * x1);
-         *reinterpret_cast<double2 *>(dst + 2) = make_double2(vB2 * x2, vB3 * x3);
-      }
-      else
-      {
-         if (kB     < k1) { dst[0] = vB0 * p.x[cB.x]; }
-         if (kB + 1 < k1) { dst[1] = vB1 * p.x[cB.y]; }
-         if (kB + 2 < k1) { dst[2] = vB2 * p.x[cB.z]; }
-         if (kB + 3 < k1) { dst[3] = vB3 * p.x[cB.w]; }
-      }
-   }
-   // tail of a tile whose last row runs past 2 quads per lane
-   for (int k = kB + 4 * SPMV_THREADS; k < k1; k += 4 * SPMV_THREADS)
-   {
-      const int4 c = load_cols<NT>(p.Aj + k);
-      double v0, v1, v2, v3;
-      if (F32) { load_vals32<NT>(p.Aa32 + k, v0, v1, v2, v3); } else { load_vals<NT>(p.Aa + k, v0, v1, v2, v3); }
-      double *dst = prod + (k - ka);
-      if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
-      if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
-      if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
-      if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
-   }
-   __syncthreads();
-
-   // ---- phase 2: per-row reduction ------------------------------------------
    const int avg = (k1 - k0) / nrows;
    if (avg <= 12)
    {
@@ -306,6 +188,175 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
       __syncthreads();
       if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, rowsum[tid], ops); }
    }
+}
+
+
+// The slice of the (col, val) streams one lane holds in registers: two quads.
+// Loads are issued unconditionally (lanes past the tile's end re-read its first
+// quad) so that no register merge forces a wait right behind the loads.
+struct TileStream
+{
+   v4i cA, cB;
+   v2d vA01, vA23, vB01, vB23;     // fp64 values
+   v4f fA, fB;                     // fp32 values (mixed precision)
+};
+
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const void *p)
+{
+   if (NT) { return __builtin_nontemporal_load(reinterpret_cast<const T *>(p)); }
+   return *reinterpret_cast<const T *>(p);
+}
+
+// issue the stream loads of the tile whose entries are [k0, k1), ka = k0 & ~3
+template <bool F32, bool NT>
+__device__ __forceinline__ void stream_issue(const SpmvArgs &p, int ka, int k1, TileStream &s)
+{
+   const int kA = ka + 4 * (int) threadIdx.x;
+   const int kB = kA + 4 * SPMV_THREADS;
+   const int qA = min(kA < k1 ? kA : ka, p.last_quad);
+   const int qB = min(kB < k1 ? kB : ka, p.last_quad);
+   s.cA = stream_load<NT, v4i>(p.Aj + qA);
+   s.cB = stream_load<NT, v4i>(p.Aj + qB);
+   if (F32)
+   {
+      s.fA = stream_load<NT, v4f>(p.Aa32 + qA);
+      s.fB = stream_load<NT, v4f>(p.Aa32 + qB);
+   }
+   else
+   {
+      s.vA01 = stream_load<NT, v2d>(p.Aa + qA);
+      s.vA23 = stream_load<NT, v2d>(p.Aa + qA + 2);
+      s.vB01 = stream_load<NT, v2d>(p.Aa + qB);
+      s.vB23 = stream_load<NT, v2d>(p.Aa + qB + 2);
+   }
+}
+
+// gather x for the entries held in s, park the products in LDS (prod[k - ka])
+template <bool F32, bool NT>
+__device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1, int ka, const TileStream &s,
+                                               double *prod)
+{
+   const int kA = ka + 4 * (int) threadIdx.x;
+   const int kB = kA + 4 * SPMV_THREADS;
+   double vA0, vA1, vA2, vA3, vB0, vB1, vB2, vB3;
+   if (F32)
+   {
+      vA0 = s.fA.x; vA1 = s.fA.y; vA2 = s.fA.z; vA3 = s.fA.w;
+      vB0 = s.fB.x; vB1 = s.fB.y; vB2 = s.fB.z; vB3 = s.fB.w;
+   }
+   else
+   {
+      vA0 = s.vA01.x; vA1 = s.vA01.y; vA2 = s.vA23.x; vA3 = s.vA23.y;
+      vB0 = s.vB01.x; vB1 = s.vB01.y; vB2 = s.vB23.x; vB3 = s.vB23.y;
+   }
+   if (kA < k1)
+   {
+      double *dst = prod + (kA - ka);
+      if (kA >= k0 && kA + 4 <= k1)
+      {
+         const double x0 = p.x[s.cA.x], x1 = p.x[s.cA.y], x2 = p.x[s.cA.z], x3 = p.x[s.cA.w];
+         *reinterpret_cast<double2 *>(dst)     = make_double2(vA0 * x0, vA1 * x1);
+         *reinterpret_cast<double2 *>(dst + 2) = make_double2(vA2 * x2, vA3 * x3);
+      }
+      else
+      {
+         if (kA     >= k0 && kA     < k1) { dst[0] = vA0 * p.x[s.cA.x]; }
+         if (kA + 1 >= k0 && kA + 1 < k1) { dst[1] = vA1 * p.x[s.cA.y]; }
+         if (kA + 2 >= k0 && kA + 2 < k1) { dst[2] = vA2 * p.x[s.cA.z]; }
+         if (kA + 3 >= k0 && kA + 3 < k1) { dst[3] = vA3 * p.x[s.cA.w]; }
+      }
+   }
+   if (kB < k1)
+   {
+      double *dst = prod + (kB - ka);
+      if (kB + 4 <= k1)
+      {
+         const double x0 = p.x[s.cB.x], x1 = p.x[s.cB.y], x2 = p.x[s.cB.z], x3 = p.x[s.cB.w];
+         *reinterpret_cast<double2 *>(dst)     = make_double2(vB0 * x0, vB1 * x1);
+         *reinterpret_cast<double2 *>(dst + 2) = make_double2(vB2 * x2, vB3 * x3);
+      }
+      else
+      {
+         if (kB     < k1) { dst[0] = vB0 * p.x[s.cB.x]; }
+         if (kB + 1 < k1) { dst[1] = vB1 * p.x[s.cB.y]; }
+         if (kB + 2 < k1) { dst[2] = vB2 * p.x[s.cB.z]; }
+         if (kB + 3 < k1) { dst[3] = vB3 * p.x[s.cB.w]; }
+      }
+   }
+   // tail of a tile whose last row runs past 2 quads per lane
+   for (int k = kB + 4 * SPMV_THREADS; k < k1; k += 4 * SPMV_THREADS)
+   {
+      const v4i c = stream_load<NT, v4i>(p.Aj + k);
+      double v0, v1, v2, v3;
+      if (F32) { const v4f f = stream_load<NT, v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
+      else
+      {
+         const v2d lo = stream_load<NT, v2d>(p.Aa + k), hi = stream_load<NT, v2d>(p.Aa + k + 2);
+         v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+      }
+      double *dst = prod + (k - ka);
+      if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
+      if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
+      if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
+      if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
+   }
+}
+
+// epilogue operands of row r0 + tid, clamped into the tile so the loads are unconditional
+template <int OP>
+__device__ __forceinline__ RowOps tile_row_ops(const SpmvArgs &p, int r0, int nrows)
+{
+   const int rr = min((int) threadIdx.x, nrows - 1);
+   return load_row_ops<OP>(p, max(r0 + rr, 0));
+}
+
+// One workgroup per tile, in dispatch order (or a re-mapped order, see xcd_map).
+template <int OP, bool F32, bool HASFILL, bool NT>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
+                       int num_tiles, int prod_elems, int rowsum_elems)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *prod   = reinterpret_cast<double *>(smem_raw);
+   double *rowsum = prod + prod_elems;                                 // [rowsum_elems]
+   int    *rp     = reinterpret_cast<int *>(rowsum + rowsum_elems);    // [RP_CAP + 1]
+
+   // Workgroups are dealt round-robin over the 8 XCDs (workgroup g -> XCD g % 8),
+   // each XCD with its own L2.  xcd_map > 0: every XCD takes chunks of xcd_map
+   // consecutive tiles; xcd_map < 0: one contiguous eighth of the tiles per XCD.
+   // Speed only: any placement is correct.
+   int tile = (int) blockIdx.x;
+   if (p.xcd_map > 0)
+   {
+      const int g = blockIdx.x >> 3, c = blockIdx.x & 7, C = p.xcd_map;
+      tile = (g / C) * (8 * C) + c * C + (g % C);
+   }
+   else if (p.xcd_map < 0)
+   {
+      tile = (blockIdx.x & 7) * ((num_tiles + 7) >> 3) + (blockIdx.x >> 3);
+   }
+   if (tile >= num_tiles) { return; }
+
+   const int r0 = tile_row[tile];
+   const int r1 = tile_row[tile + 1];
+   if (r1 <= r0) { return; }
+   const int k0 = tile_k[tile];
+   const int k1 = tile_k[tile + 1];
+   const int ka = k0 & ~3;
+   const int tid = threadIdx.x;
+   const int nrows = r1 - r0;
+
+   // matrix stream first, then row pointers -> LDS and this lane's epilogue
+   // operands -> registers, so that their latency hides under the stream's
+   TileStream S;
+   stream_issue<F32, NT>(p, ka, k1, S);
+   for (int t = tid; t <= nrows && t <= RP_CAP; t += SPMV_THREADS) { rp[t] = p.Ai[r0 + t]; }
+   const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
+
+   stream_consume<F32, NT>(p, k0, k1, ka, S, prod);
+   __syncthreads();
+   tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, ops);
 }
 
 // ---------------------------------------------------------------------------
@@ -426,22 +477,22 @@ int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+static inline size_t tiled_lds_bytes(const SpmvPlan *plan, int &rowsum_elems)
+{
+   // row sums pass through LDS only on the multi-lane paths (mean row length of a tile > 12)
+   rowsum_elems = plan->max_row_nnz > 12 ? SPMV_THREADS : 0;
+   return sizeof(double) * (size_t) (plan->prod_elems + rowsum_elems) + sizeof(int) * (size_t) (RP_CAP + 4);
+}
+
 template <int OP, bool F32, bool FILL, bool NT>
 static void launch_tiled_nt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
-   const int grid = ((plan->num_tiles + 7) / 8) * 8;
-   const int prod_elems = plan->prod_elems;
-   const size_t lds = sizeof(double) * (size_t) (prod_elems + SPMV_THREADS) + sizeof(int) * (size_t) (RP_CAP + 4);
-   static bool attr_set = false;
-   if (!attr_set)
-   {
-      // allow > 64 KiB of dynamic LDS should a plan ever ask for it
-      (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&spmv_tiled_kernel<OP, F32, FILL, NT>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr_set = true;
-   }
+   int rowsum_elems;
+   const size_t lds = tiled_lds_bytes(plan, rowsum_elems);
+   const int unit = a.xcd_map > 0 ? 8 * a.xcd_map : 8;
+   const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
    hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL, NT>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
-                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, prod_elems);
+                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, plan->prod_elems, rowsum_elems);
 }
 
 template <int OP, bool F32, bool FILL>
@@ -483,12 +534,14 @@ static void launch_spmv_op(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t 
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s)
 {
    if (plan->num_rows <= 0) { return; }
+   SpmvArgs a = args;
+   a.last_quad = (plan->nnz > 0 ? (int) (plan->nnz - 1) : 0) & ~3;
    switch (op)
    {
-      case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, args, s); break;
-      case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, args, s); break;
-      case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, args, s); break;
-      case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, args, s); break;
+      case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, a, s); break;
+      case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, a, s); break;
+      case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, a, s); break;
+      case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, a, s); break;
    }
 }
 
