@@ -5,8 +5,10 @@
  * compared against; nothing under hypre_amd/ links, imports or calls it.  Only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
  *
- * It restates, in plain single-threaded C and in the reference's own loop and
- * summation order, the algorithms of (paths relative to /root/reference/src):
+ * It restates, in plain C and in the reference's own loop and summation order
+ * (single-threaded by default; oracle_set_num_threads() turns on OpenMP over the
+ * independent row loops for the timed CPU baseline, with bit-identical results),
+ * the algorithms of (paths relative to /root/reference/src):
  *   seq_mv/csr_matvec.c:22-857        y = alpha*A*x + beta*b (all alpha/beta branches, rownnz path)
  *   seq_mv/csr_matvec.c:914-1140      y = alpha*A^T*x + beta*y
  *   parcsr_mv/par_csr_matvec.c:21-232,288-520   ParCSR Matvec / MatvecT
@@ -39,6 +41,15 @@
 
 #include "oracle.h"
 
+/* Worker threads of the row-parallel loops (the reference's HYPRE_SMP_SCHEDULE =
+ * schedule(static) over rows, csr_matvec.c:677-678, par_relax.c:262-266).  Every
+ * row is still summed by one thread in stored order, so the results do not
+ * depend on the thread count. */
+static int g_threads = 1;
+void oracle_set_num_threads(int n) { g_threads = n > 1 ? n : 1; }
+int  oracle_get_num_threads(void) { return g_threads; }
+#define ROW_PARALLEL _Pragma("omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)")
+
 /* ------------------------------------------------------------------------- */
 /* sequential CSR products                                                    */
 /* ------------------------------------------------------------------------- */
@@ -53,8 +64,8 @@ int oracle_csr_matvec(double alpha, const ocsr *A, const double *x, int x_size,
    const double *Aa = A->a;
    const int num_rows = A->nrows - offset;
    const int num_cols = A->ncols;
-   int ierr = 0, i, jj, m;
-   double temp, tempx;
+   int ierr = 0, i;
+   double temp;
    b += offset; y += offset; b_size -= offset; y_size -= offset;
 
    if (num_cols != x_size) { ierr = 1; }
@@ -63,7 +74,8 @@ int oracle_csr_matvec(double alpha, const ocsr *A, const double *x, int x_size,
 
    if (alpha == 0.0)
    {
-      for (i = 0; i < num_rows; i++) { y[i] = beta * b[i]; }
+      ROW_PARALLEL
+      for (int r = 0; r < num_rows; r++) { y[r] = beta * b[r]; }
       return ierr;
    }
    double *x_tmp = NULL;
@@ -82,36 +94,73 @@ int oracle_csr_matvec(double alpha, const ocsr *A, const double *x, int x_size,
       else if (temp == -1.0) { for (i = 0; i < num_rows; i++) { y[i] = (alpha == 1.0) ? -b[i] : (alpha == -1.0 ? b[i] : -alpha * b[i]); } }
       else if (temp == 1.0)  { for (i = 0; i < num_rows; i++) { y[i] = (alpha == 1.0) ? b[i] : (alpha == -1.0 ? -b[i] : alpha * b[i]); } }
       else                   { for (i = 0; i < num_rows; i++) { y[i] = (alpha == 1.0) ? b[i] * temp : (alpha == -1.0 ? -b[i] * temp : b[i] * beta); } }
-      for (i = 0; i < A->num_rownnz; i++)
+      ROW_PARALLEL
+      for (int r = 0; r < A->num_rownnz; r++)
       {
-         m = A->rownnz[i];
-         tempx = 0.0;
-         if (alpha == -1.0) { for (jj = Ai[m]; jj < Ai[m + 1]; jj++) { tempx -= Aa[jj] * x[Aj[jj]]; } }
-         else               { for (jj = Ai[m]; jj < Ai[m + 1]; jj++) { tempx += Aa[jj] * x[Aj[jj]]; } }
-         if (alpha != 1.0 && alpha != -1.0) { tempx = alpha * tempx; }
-         if (temp == 0.0) { y[m] = tempx; } else { y[m] += tempx; }
+         const int mr = A->rownnz[r];
+         double tx = 0.0;
+         if (alpha == -1.0) { for (int q = Ai[mr]; q < Ai[mr + 1]; q++) { tx -= Aa[q] * x[Aj[q]]; } }
+         else               { for (int q = Ai[mr]; q < Ai[mr + 1]; q++) { tx += Aa[q] * x[Aj[q]]; } }
+         if (alpha != 1.0 && alpha != -1.0) { tx = alpha * tx; }
+         if (temp == 0.0) { y[mr] = tx; } else { y[mr] += tx; }
       }
    }
    else
    {
       /* csr_matvec.c:671-849 */
-      for (i = 0; i < num_rows; i++)
+      ROW_PARALLEL
+      for (int r = 0; r < num_rows; r++)
       {
-         double bterm;
+         double bterm, tx = 0.0;
          if (temp == 0.0)       { bterm = 0.0; }
-         else if (temp == -1.0) { bterm = (alpha == 1.0) ? -b[i] : (alpha == -1.0 ? b[i] : -alpha * b[i]); }
-         else if (temp == 1.0)  { bterm = (alpha == 1.0) ? b[i] : (alpha == -1.0 ? -b[i] : alpha * b[i]); }
-         else                   { bterm = (alpha == 1.0) ? b[i] * temp : (alpha == -1.0 ? -b[i] * temp : b[i] * beta); }
-         tempx = 0.0;
-         if (alpha == -1.0) { for (jj = Ai[i]; jj < Ai[i + 1]; jj++) { tempx -= Aa[jj] * x[Aj[jj]]; } }
-         else               { for (jj = Ai[i]; jj < Ai[i + 1]; jj++) { tempx += Aa[jj] * x[Aj[jj]]; } }
-         if (alpha != 1.0 && alpha != -1.0) { tempx = alpha * tempx; }
-         if (temp == 0.0) { y[i] = tempx; }
-         else { y[i] = bterm; y[i] += tempx; }
+         else if (temp == -1.0) { bterm = (alpha == 1.0) ? -b[r] : (alpha == -1.0 ? b[r] : -alpha * b[r]); }
+         else if (temp == 1.0)  { bterm = (alpha == 1.0) ? b[r] : (alpha == -1.0 ? -b[r] : alpha * b[r]); }
+         else                   { bterm = (alpha == 1.0) ? b[r] * temp : (alpha == -1.0 ? -b[r] * temp : b[r] * beta); }
+         if (alpha == -1.0) { for (int q = Ai[r]; q < Ai[r + 1]; q++) { tx -= Aa[q] * x[Aj[q]]; } }
+         else               { for (int q = Ai[r]; q < Ai[r + 1]; q++) { tx += Aa[q] * x[Aj[q]]; } }
+         if (alpha != 1.0 && alpha != -1.0) { tx = alpha * tx; }
+         if (temp == 0.0) { y[r] = tx; }
+         else { y[r] = bterm; y[r] += tx; }
       }
    }
    free(x_tmp);
    return ierr;
+}
+
+/* Stable transpose (counting sort: row c of A^T lists the rows of A holding column c
+ * in ascending order), cached per matrix for the threaded baseline.  Summing row c
+ * of A^T front to back adds the same products in the same order as the sequential
+ * scatter loop below, so both forms give identical bits. */
+typedef struct { const ocsr *key; const int *ki; int *i, *j; double *a; } otrans;
+static otrans g_trans[64];
+static int    g_ntrans = 0;
+static const otrans *get_transpose(const ocsr *A)
+{
+   for (int t = 0; t < g_ntrans; t++) { if (g_trans[t].key == A && g_trans[t].ki == A->i) { return &g_trans[t]; } }
+   if (g_ntrans == 64) { return NULL; }
+   const int nr = A->nrows, nc = A->ncols, nnz = A->i[nr];
+   otrans *T = &g_trans[g_ntrans];
+   T->i = (int *) calloc((size_t) nc + 2, sizeof(int));
+   T->j = (int *) malloc(sizeof(int) * (size_t) (nnz > 0 ? nnz : 1));
+   T->a = (double *) malloc(sizeof(double) * (size_t) (nnz > 0 ? nnz : 1));
+   for (int k = 0; k < nnz; k++) { T->i[A->j[k] + 2]++; }
+   for (int c = 0; c < nc; c++) { T->i[c + 2] += T->i[c + 1]; }
+   for (int r = 0; r < nr; r++)
+   {
+      for (int k = A->i[r]; k < A->i[r + 1]; k++)
+      {
+         const int pos = T->i[A->j[k] + 1]++;
+         T->j[pos] = r; T->a[pos] = A->a[k];
+      }
+   }
+   T->key = A; T->ki = A->i;
+   g_ntrans++;
+   return T;
+}
+void oracle_drop_transposes(void)
+{
+   for (int t = 0; t < g_ntrans; t++) { free(g_trans[t].i); free(g_trans[t].j); free(g_trans[t].a); }
+   g_ntrans = 0;
 }
 
 /* csr_matvec.c:914-1140 (single-thread branch) */
@@ -136,6 +185,19 @@ int oracle_csr_matvecT(double alpha, const ocsr *A, const double *x, int x_size,
       x = x_tmp;
    }
    const double temp = beta / alpha;
+   const otrans *T = (g_threads > 1) ? get_transpose(A) : NULL;
+   if (T)
+   {
+      ROW_PARALLEL
+      for (int c = 0; c < num_cols; c++)
+      {
+         double v = (temp == 1.0) ? y[c] : (temp == 0.0 ? 0.0 : y[c] * temp);
+         for (int k = T->i[c]; k < T->i[c + 1]; k++) { v += T->a[k] * x[T->j[k]]; }
+         y[c] = (alpha != 1.0) ? v * alpha : v;
+      }
+      free(x_tmp);
+      return ierr;
+   }
    if (temp != 1.0)
    {
       if (temp == 0.0) { for (i = 0; i < num_cols; i++) { y[i] = 0.0; } }
@@ -161,12 +223,14 @@ double oracle_inner_prod(const double *x, const double *y, long long n)
 }
 void oracle_axpy(double alpha, const double *x, double *y, long long n)
 {
+   ROW_PARALLEL
    for (long long i = 0; i < n; i++) { y[i] += alpha * x[i]; }
 }
 void oracle_scale(double alpha, double *y, long long n)
 {
    if (alpha == 1.0) { return; }
    if (alpha == 0.0) { for (long long i = 0; i < n; i++) { y[i] = 0.0; } return; }
+   ROW_PARALLEL
    for (long long i = 0; i < n; i++) { y[i] *= alpha; }
 }
 
@@ -346,7 +410,9 @@ static void jacobi_core(const ocsr *D, const ocsr *O, const double *f, const int
 {
    const int n = D->nrows;
    const double omw = 1.0 - w;
+   ROW_PARALLEL
    for (int i = 0; i < n; i++) { vtemp[i] = u[i]; }
+   ROW_PARALLEL
    for (int i = 0; i < n; i++)
    {
       const double di = l1 ? l1[i] : D->a[D->i[i]];
@@ -462,6 +528,7 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
       /* par_relax.c:1178-1254: Vtemp = w f - w A u (or w f when u is known zero); u += Vtemp ./ l1 */
       if (*all_zeros)
       {
+         ROW_PARALLEL
          for (long long i = 0; i < ntot; i++) { vtemp[i] = f[i]; }
          oracle_scale(w, vtemp, ntot);
       }
@@ -469,6 +536,7 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
       {
          oracle_par_matvec(-w, A, u, w, f, vtemp);
       }
+      ROW_PARALLEL
       for (long long i = 0; i < ntot; i++)
       {
          if (relax_points == 0 || cf_marker[i] == relax_points) { u[i] += vtemp[i] / l1[i]; }
@@ -701,6 +769,7 @@ int oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros)
          /* go down: u_c = 0, r = f - A u, f_c = R^T r   (par_cycle.c:650-727) */
          const int fine = level, coarse = level + 1;
          const long long nc = amg->A[coarse].row_starts[amg->A[coarse].nranks];
+         ROW_PARALLEL
          for (long long i = 0; i < nc; i++) { U[coarse][i] = 0.0; }
          all_zeros[coarse] = 1;
          oracle_par_matvec(-1.0, &amg->A[fine], U[fine], 1.0, F[fine], vtemp);

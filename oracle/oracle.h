@@ -44,6 +44,12 @@ typedef struct
    int       num_threads;        /* OpenMP thread count the hybrid smoothers emulate */
 } oamg;
 
+/* OpenMP threads of the independent row loops (timed CPU baseline); results are
+ * the same bits for any count.  oracle_drop_transposes frees the transposes the
+ * threaded A^T x caches. */
+void   oracle_set_num_threads(int n);
+int    oracle_get_num_threads(void);
+void   oracle_drop_transposes(void);
 int    oracle_csr_matvec(double alpha, const ocsr *A, const double *x, int x_size, double beta,
                          const double *b, int b_size, double *y, int y_size, int offset);
 int    oracle_csr_matvecT(double alpha, const ocsr *A, const double *x, int x_size, double beta,

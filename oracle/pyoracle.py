@@ -52,6 +52,10 @@ def load():
         build()
     L = C.CDLL(LIB)
     P = C.POINTER
+    L.oracle_set_num_threads.restype = None
+    L.oracle_set_num_threads.argtypes = [C.c_int]
+    L.oracle_get_num_threads.restype = C.c_int
+    L.oracle_drop_transposes.restype = None
     L.oracle_csr_matvec.restype = C.c_int
     L.oracle_csr_matvec.argtypes = [C.c_double, P(OCSR), RealP, C.c_int, C.c_double, RealP, C.c_int, RealP,
                                     C.c_int, C.c_int]
@@ -85,6 +89,15 @@ def load():
                                  RealP, IntP]
     _lib = L
     return L
+
+
+def set_num_threads(n):
+    """OpenMP threads of the independent row loops (bit-identical results for any count)."""
+    load().oracle_set_num_threads(int(n))
+
+
+def drop_transposes():
+    load().oracle_drop_transposes()
 
 
 def _ip(a):

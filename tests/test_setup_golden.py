@@ -53,3 +53,27 @@ def test_single_rank_goldens(lib, oracle, name):
     for key in ("conv_factor", "grid", "operator"):
         if key in exp:
             assert abs(out[key] - exp[key]) < 5.1e-7, (key, out[key], exp[key])
+
+
+def test_oracle_thread_count_does_not_change_bits(lib, oracle):
+    """The timed CPU baseline runs the oracle's row loops under OpenMP: same bits as one thread."""
+    from hypre_amd import binding as B, ij
+    opt = ij.IJOptions(n=(14, 13, 12), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=18, num_sweeps=1)
+    A = ij.build_matrix(opt)
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_HOST)
+    lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+    B.check()
+    amg = oracle.amg_from_solvers([s])
+    n = amg.A_levels[0].nrows
+    f = np.random.default_rng(3).uniform(-1, 1, n)
+    outs = []
+    for threads in (1, 3):
+        oracle.set_num_threads(threads)
+        u = np.zeros(n)
+        amg.cycle(f, u, u_all_zeros=True)
+        amg.cycle(f, u, u_all_zeros=False)
+        outs.append(u)
+    oracle.set_num_threads(1)
+    oracle.drop_transposes()
+    lib.HYPRE_BoomerAMGDestroy(s)
+    assert np.array_equal(outs[0], outs[1])
