@@ -74,7 +74,9 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            # nccl (= RCCL) for device tensors; gloo beside it only so that the ranks can agree on
+            # the fallback below through host tensors should the RCCL communicator be unusable
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
 
     from hypre_amd import binding as B, ij
     L = B.load_library()          # raises when the HIP library is missing: no fallback exists
@@ -87,7 +89,24 @@ def main():
         if transport == "gloo":
             comm = distributed.create_callback_comm(dist, rank, world)
         else:
-            comm = distributed.create_rccl_comm(dist, rank, world)
+            import torch
+            ok = 1
+            try:
+                comm = distributed.create_rccl_comm(dist, rank, world)
+                if L.hypre_amd_CommSelfTest(comm, 1 << 16) != 0:
+                    ok = 0
+                B.check()
+            except Exception as exc:                  # noqa: BLE001 - any failure means "no RCCL transport"
+                print("rank %d: RCCL communicator unusable (%s)" % (rank, exc), file=sys.stderr, flush=True)
+                L.HYPRE_ClearAllErrors()
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                # loud, and recorded in the JSON line: halo traffic staged over the host instead of xGMI
+                print("rank %d: falling back to the host-staged gloo transport" % rank, file=sys.stderr, flush=True)
+                transport = "gloo-fallback"
+                comm = distributed.create_callback_comm(dist, rank, world)
 
     P, Q, R = proc_grid(world)
     n1 = args.n
@@ -118,7 +137,10 @@ def main():
         if dist is not None:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
+            if transport == "rccl":
+                dist.barrier()
+            else:
+                dist.all_reduce(torch.zeros(1))      # host-side barrier over gloo
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -132,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if transport == "gloo" else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     B.check()
@@ -213,6 +235,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%dx%d 7-pt Laplacian, %d rank(s) %dx%dx%d, PMIS + ext+i(4) + l1-Jacobi V(1,1)"
                                    % (n1 * P, n1 * Q, n1 * R, world, P, Q, R),
+                       "transport": transport if world > 1 else "none",
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s},
             "roofline": {"bound": "hbm", "kernel": "spmv_tiled_kernel<AXPBY> (fine-level y = A x)",
@@ -225,7 +248,8 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        if transport == "rccl":
+            dist.barrier()
         dist.destroy_process_group()
 
 

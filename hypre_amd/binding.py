@@ -135,6 +135,7 @@ PROTOTYPES = {
     "hypre_amd_CommCreateRCCL": (Int, [C.c_void_p, C.c_int, C.c_int]),
     "hypre_MPI_Comm_rank": (Int, [Int, IntP]),
     "hypre_MPI_Comm_size": (Int, [Int, IntP]),
+    "hypre_amd_CommSelfTest": (Int, [Int, Int]),
     "hypre_MPI_Barrier": (Int, [Int]),
     # seq_mv
     "hypre_CSRMatrixCreate": (CSRp, [Int, Int, Int]),

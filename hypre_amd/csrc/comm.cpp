@@ -226,6 +226,70 @@ MPI_Comm hypre_amd_CommCreateRCCL(const void *id_bytes, int rank, int size)
    return hypre_amd_CommCreate(&ops);
 }
 
+// Round trip over every entry of a communicator's table: a ring shift of a byte
+// pattern (host buffers, then device buffers when the provider takes them), a
+// sum all-reduce and an all-gather, each checked against the expected answer.
+// Returns the number of failed checks (0 = healthy).  Collective.
+HYPRE_Int hypre_amd_CommSelfTest(MPI_Comm comm, HYPRE_Int nbytes)
+{
+   const hypre_amd_CommOps *o = hamd::comm_ops(comm);
+   if (!o) { return 1; }
+   if (!o->exchange || !o->allreduce_sum || !o->allgather) { return o->size > 1 ? 1 : 0; }
+   const int    rank = o->rank, size = o->size;
+   const size_t n = nbytes > 0 ? (size_t) nbytes : 1;
+   int          next = (rank + 1) % size, prev = (rank + size - 1) % size;
+   int          fails = 0;
+   auto pattern = [](int r, size_t i) { return (unsigned char) ((i * 131u + 7u * (unsigned) r + 1u) & 255u); };
+
+   std::vector<unsigned char> hs(n), hr(n, 0);
+   for (size_t i = 0; i < n; i++) { hs[i] = pattern(rank, i); }
+   {
+      void *sb = hs.data(), *rb = hr.data();
+      size_t nb = n;
+      if (o->exchange(o->ctx, 1, &next, &sb, &nb, 1, &prev, &rb, &nb, 0, nullptr)) { fails++; }
+      for (size_t i = 0; i < n; i++) { if (hr[i] != pattern(prev, i)) { fails++; break; } }
+   }
+   if (o->device_buffers && hamd::ensure_device())
+   {
+      hipStream_t s = hamd::handle().comm_stream;
+      unsigned char *ds = nullptr, *dr = nullptr;
+      if (hipMalloc((void **) &ds, n) != hipSuccess || hipMalloc((void **) &dr, n) != hipSuccess) { return fails + 1; }
+      (void) hipMemcpyAsync(ds, hs.data(), n, hipMemcpyHostToDevice, s);
+      (void) hipMemsetAsync(dr, 0, n, s);
+      void *sb = ds, *rb = dr;
+      size_t nb = n;
+      if (o->exchange(o->ctx, 1, &next, &sb, &nb, 1, &prev, &rb, &nb, 1, s)) { fails++; }
+      std::fill(hr.begin(), hr.end(), 0);
+      (void) hipMemcpyAsync(hr.data(), dr, n, hipMemcpyDeviceToHost, s);
+      if (hipStreamSynchronize(s) != hipSuccess) { fails++; }
+      for (size_t i = 0; i < n; i++) { if (hr[i] != pattern(prev, i)) { fails++; break; } }
+
+      double h2[2] = {1.0, (double) rank}, *d2 = (double *) ds;
+      if (n >= sizeof(h2))
+      {
+         (void) hipMemcpyAsync(d2, h2, sizeof(h2), hipMemcpyHostToDevice, s);
+         if (o->allreduce_sum(o->ctx, d2, 2, 1, s)) { fails++; }
+         (void) hipMemcpyAsync(h2, d2, sizeof(h2), hipMemcpyDeviceToHost, s);
+         if (hipStreamSynchronize(s) != hipSuccess) { fails++; }
+         if (h2[0] != (double) size || h2[1] != 0.5 * size * (size - 1)) { fails++; }
+      }
+      (void) hipFree(ds);
+      (void) hipFree(dr);
+   }
+   {
+      double h2[2] = {1.0, (double) rank};
+      if (o->allreduce_sum(o->ctx, h2, 2, 0, nullptr)) { fails++; }
+      if (h2[0] != (double) size || h2[1] != 0.5 * size * (size - 1)) { fails++; }
+   }
+   {
+      std::vector<int> all((size_t) size, -1);
+      int mine = 1000 + rank;
+      if (o->allgather(o->ctx, &mine, all.data(), sizeof(int))) { fails++; }
+      for (int r = 0; r < size; r++) { if (all[(size_t) r] != 1000 + r) { fails++; break; } }
+   }
+   return fails;
+}
+
 HYPRE_Int hypre_MPI_Comm_rank(MPI_Comm comm, HYPRE_Int *rank)
 {
    const hypre_amd_CommOps *o = hamd::comm_ops(comm);

@@ -65,6 +65,12 @@ HYPRE_Int hypre_amd_CommDestroy(MPI_Comm comm);
 HYPRE_Int hypre_amd_RCCLGetUniqueId(void *id_out);
 MPI_Comm  hypre_amd_CommCreateRCCL(const void *id, int rank, int size);
 
+/* Collective health check of a communicator (no reference counterpart; the
+ * reference trusts MPI): ring shift of nbytes through exchange() with host and,
+ * if the provider takes them, device buffers, a sum all-reduce and an
+ * all-gather, each verified.  Returns the number of failed checks. */
+HYPRE_Int hypre_amd_CommSelfTest(MPI_Comm comm, HYPRE_Int nbytes);
+
 HYPRE_Int hypre_MPI_Comm_rank(MPI_Comm comm, HYPRE_Int *rank);
 HYPRE_Int hypre_MPI_Comm_size(MPI_Comm comm, HYPRE_Int *size);
 HYPRE_Int hypre_MPI_Barrier(MPI_Comm comm);

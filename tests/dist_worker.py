@@ -23,6 +23,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     L = B.load_library()
     comm = distributed.create_callback_comm(dist, rank, world)
+    if L.hypre_amd_CommSelfTest(comm, 4099) != 0:
+        raise SystemExit("communicator self-test failed on rank %d" % rank)
     opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
     device = bool(case.get("device", 0))

@@ -29,3 +29,22 @@ def test_pcg_three_ranks_on_device():
     out = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1})
     assert out["dev_iterations"] == case["expect"]["iterations"] == out["iterations"]
     assert abs(out["dev_rel_resid"] - case["expect"]["rel_resid"]) <= 5e-7 * case["expect"]["rel_resid"]
+
+
+def test_rccl_provider_single_rank_round_trip():
+    """The RCCL provider on the one GPU a test box has: a size-1 communicator whose ring shift is a
+    send-to-self / recv-from-self pair inside one ncclGroup, plus all-reduce and all-gather, with
+    host-staged and device buffers (hypre_amd_CommSelfTest)."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    L = B.load_library()
+    ident = (C.c_ubyte * 128)()
+    L.hypre_amd_RCCLGetUniqueId(C.cast(ident, C.c_void_p))
+    B.check()
+    comm = L.hypre_amd_CommCreateRCCL(C.cast(ident, C.c_void_p), 0, 1)
+    B.check()
+    assert comm > 0
+    assert L.hypre_amd_CommSelfTest(comm, 1 << 16) == 0
+    assert L.hypre_amd_CommSelfTest(comm, 24) == 0
+    B.check()
+    L.hypre_amd_CommDestroy(comm)
