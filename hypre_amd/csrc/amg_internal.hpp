@@ -56,6 +56,28 @@ HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, h
 HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
                                      HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr);
 
+// operands of one directional hybrid Gauss-Seidel / SOR sweep (gs_kernels.hip)
+struct GsArgs
+{
+   const HYPRE_Int *Di, *Dj; const HYPRE_Complex *Da;     // diag block
+   const HYPRE_Int *Oi, *Oj; const HYPRE_Complex *Oa;     // offd block (Oi == nullptr: none)
+   const double *f;
+   const int    *cf; int relax_points;
+   const double *l1;           // smoother diagonal, or nullptr for the stored diagonal
+   double       *u;
+   const double *uold;         // u when this directional sweep started
+   const double *vtemp;        // u when the relaxation call started
+   const double *vext;         // ghost values of that state
+   int    dir;                 // +1 forward, -1 backward
+   int    skip_diag, non_scale;
+   double w, omega;
+   int    n, threads;
+   const int *rows;            // rows ordered by level
+};
+void launch_gs_level(const GsArgs &a, int start, int count, hipStream_t s);
+void launch_gs_multilevel(const GsArgs &a, const int *d_lev_start, int lev_begin, int lev_end, hipStream_t s);
+void drop_gs_schedule(const hypre_CSRMatrix *A);
+
 void launch_jacobi_update(const double *u_in, const double *r, const double *d, const int *marker, int mval,
                           double *u_out, size_t n, hipStream_t s);
 void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStream_t s);

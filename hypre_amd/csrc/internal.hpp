@@ -58,6 +58,9 @@ struct Handle
    size_t                d_reduce_len  = 0;
    double               *h_reduce      = nullptr;  // pinned, 16 doubles
    int                   num_cus       = 256;
+   // OpenMP thread count the hybrid Gauss-Seidel sweeps emulate (row blocks of
+   // hypre_partition1D; 1 = one block per rank); set by the cycle from the solver
+   int                   gs_threads    = 1;
 };
 Handle &handle();
 const hypre_amd_CommOps *comm_ops(MPI_Comm comm);   // nullptr for an invalid handle

@@ -186,21 +186,6 @@ HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, h
    return hypre_error_flag;
 }
 
-HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f,
-                                                      HYPRE_Int *cf_marker, HYPRE_Int relax_points,
-                                                      HYPRE_Real relax_weight, HYPRE_Real omega,
-                                                      HYPRE_Real *l1_norms, hypre_ParVector *u,
-                                                      hypre_ParVector *Vtemp, hypre_ParVector *Ztemp,
-                                                      HYPRE_Int GS_order, HYPRE_Int Symm)
-{
-   (void) A; (void) f; (void) cf_marker; (void) relax_points; (void) relax_weight; (void) omega;
-   (void) l1_norms; (void) u; (void) Vtemp; (void) Ztemp; (void) GS_order; (void) Symm;
-   hypre_error_w_msg(HYPRE_ERROR_GENERIC,
-                     "hybrid Gauss-Seidel (relax 3/4/6/8/13/14/88/89) is not available on the device yet: "
-                     "use relax 18/7/0 (Jacobi family) or 11/12 (two-stage Gauss-Seidel)");
-   return hypre_error_flag;
-}
-
 HYPRE_Int hypre_BoomerAMGRelax(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
                                HYPRE_Int relax_type, HYPRE_Int relax_points, HYPRE_Real relax_weight,
                                HYPRE_Real omega, HYPRE_Real *l1_norms, hypre_ParVector *u,
@@ -246,9 +231,26 @@ HYPRE_Int hypre_BoomerAMGRelax(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_
       case 12:
          hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(A, f, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, 2);
          break;
-      case 3: case 4: case 6: case 8: case 13: case 14: case 88: case 89:
-         hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u,
-                                                     Vtemp, Ztemp, 1, 0);
+      // hybrid Gauss-Seidel / SOR family (par_relax.c:1256-1377): plain 3 forward, 4 backward,
+      // 6 symmetric; l1-scaled 13 forward, 14 backward, 8/88 symmetric, 89 = 13 then 14
+      case 3:
+         hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, nullptr, u, Vtemp, Ztemp, 1, 0);
+         break;
+      case 4:
+         hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, nullptr, u, Vtemp, Ztemp, -1, 0);
+         break;
+      case 6:
+         hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, nullptr, u, Vtemp, Ztemp, 1, 1);
+         break;
+      case 8: case 88: case 13: case 14: case 89:
+         if (!l1_norms)
+         {
+            hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGRelax: the l1 Gauss-Seidel variants need l1_norms");
+            break;
+         }
+         if (relax_type == 8 || relax_type == 88) { hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, 1, 1); }
+         if (relax_type == 13 || relax_type == 89) { hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, 1, 0); }
+         if (relax_type == 14 || relax_type == 89) { hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, -1, 0); }
          break;
       default:
          hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGRelax: relax_type is outside the scope of this library");
@@ -406,6 +408,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    hipStream_t s = stream();
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
+   handle().gs_threads = pv->emulated_threads;
 
    // alternate solution buffers (allocated on the first cycle, reused afterwards)
    if ((int) pv->u_alt.size() != L) { pv->u_alt.assign((size_t) L, nullptr); pv->u_alt_len.assign((size_t) L, 0); }

@@ -49,8 +49,11 @@ static void free_plan(SpmvPlan *p)
    delete p;
 }
 
+void drop_gs_schedule(const hypre_CSRMatrix *A);    // par_relax_gs.cpp
+
 void drop_plan(hypre_CSRMatrix *A)
 {
+   drop_gs_schedule(A);
    auto &t = plan_table();
    auto it = t.find(A);
    if (it != t.end())

@@ -69,6 +69,34 @@ def test_single_sweep(gpu_lib, oracle, relax_type, relax_points, w, zero, level)
     lib.HYPRE_BoomerAMGDestroy(s)
 
 
+@pytest.mark.parametrize("relax_type", [3, 4, 6, 8, 13, 14, 88, 89])
+@pytest.mark.parametrize("relax_points,w,omega", [(0, 1.0, 1.0), (1, 1.0, 1.0), (-1, 1.0, 1.0), (0, 0.8, 1.2), (1, 0.9, 1.0)])
+@pytest.mark.parametrize("level", [0, 1])
+def test_hybrid_gauss_seidel_sweep_is_the_sequential_sweep(gpu_lib, oracle, relax_type, relax_points, w, omega, level):
+    """Level-scheduled device sweep == the oracle's in-order row loop, bit for bit (same row
+    sums in stored order, no fused multiply-add), for every member of the hybrid GS/SOR family."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    opt, A0, s = _setup(lib, n=(9, 8, 7), relax_type=relax_type, coarsen_type=8, relax_order=1 if relax_points else 0)
+    A, cf, l1 = _level(lib, s, level)
+    amg = oracle.amg_from_solvers([s])
+    n = amg.A_levels[level].nrows
+    f = rand_vector(n, 3)
+    u0 = rand_vector(n, 4)
+    du, df = B.parvec_from_numpy(u0), B.parvec_from_numpy(f)
+    dv, dz = B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(np.zeros(n))
+    uses_l1 = relax_type in (8, 13, 14, 88, 89)
+    err = lib.hypre_BoomerAMGRelax(A, df, cf, relax_type, relax_points, w, omega, l1 if uses_l1 else None, du, dv, dz)
+    B.check()
+    assert err == 0
+    u = B.parvec_to_numpy(du)
+    ur = u0.copy()
+    oracle.relax(amg.A_levels[level], f, amg.cf[level], relax_type, relax_points, w, omega,
+                 amg.l1[level] if uses_l1 else None, ur)
+    assert np.array_equal(u, ur), float(np.max(np.abs(u - ur)))
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
 @pytest.mark.parametrize("kw", [
     dict(relax_type=18, coarsen_type=8),
     dict(relax_type=18, coarsen_type=8, relax_order=1),
@@ -80,12 +108,18 @@ def test_single_sweep(gpu_lib, oracle, relax_type, relax_points, w, zero, level)
     dict(relax_type=11, coarsen_type=8),
     dict(relax_type=12, coarsen_type=8),
     dict(relax_type=18, coarsen_type=8, problem="27pt"),
+    dict(relax_type=6, coarsen_type=8),
+    dict(relax_type=3, coarsen_type=10, relax_order=1),
+    dict(relax_type=8, coarsen_type=8),
+    dict(relax_type=13, coarsen_type=10, num_threads=3),
+    dict(relax_type=89, coarsen_type=8, problem="27pt"),
+    dict(relax_type=-1, coarsen_type=10),
 ])
 def test_one_cycle_matches_oracle(gpu_lib, oracle, kw):
     from hypre_amd import binding as B
     lib = gpu_lib
     opt, A, s = _setup(lib, n=(12, 11, 10), **kw)
-    amg = oracle.amg_from_solvers([s])
+    amg = oracle.amg_from_solvers([s], num_threads=opt.num_threads)
     n = amg.A_levels[0].nrows
     f = rand_vector(n, 5)
     for zero in (True, False):

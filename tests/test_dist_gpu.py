@@ -10,7 +10,8 @@ from test_dist_golden import GOLD, run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["smoother.out.10", "smoother.out.9", "solvers.out.21", "default.out.1"])
+@pytest.mark.parametrize("name", ["smoother.out.10", "smoother.out.9", "solvers.out.21", "default.out.1",
+                                  "smoother.out.0", "smoother.out.3", "smoother.out.11", "smoother.out.11.2"])
 def test_two_or_three_ranks_on_device(name):
     case = dict(GOLD[name])
     out = run_ranks(case["ranks"], {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1})
@@ -22,6 +23,9 @@ def test_two_or_three_ranks_on_device(name):
     if "iterations" in exp:
         assert out["dev_iterations"] == exp["iterations"]
         assert abs(out["dev_rel_resid"] - exp["rel_resid"]) <= 5e-7 * exp["rel_resid"]
+    if "conv_factor" in exp:
+        # same iteration count and final residual as the oracle, whose factor is pinned on the CPU side
+        assert abs(out["conv_factor"] - exp["conv_factor"]) < 5.1e-7
 
 
 def test_pcg_three_ranks_on_device():
