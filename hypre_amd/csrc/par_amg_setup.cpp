@@ -1062,6 +1062,89 @@ HYPRE_Int hypre_ParCSRComputeL1Norms(hypre_ParCSRMatrix *A, HYPRE_Int option, HY
    return hypre_error_flag;
 }
 
+// Smoother diagonals when the hybrid sweeps run in num_threads row blocks
+// (ams.c:4535-4915): a diag-block entry whose column lies in another thread's
+// block is treated like a ghost coupling (options 4 and 6), sums accumulate in
+// stored order, and the sign flip looks at the first entry of the row.
+HYPRE_Int hypre_ParCSRComputeL1NormsThreads(hypre_ParCSRMatrix *A, HYPRE_Int option, HYPRE_Int num_threads,
+                                            HYPRE_Int *cf_marker, HYPRE_Real **l1_norm_ptr)
+{
+   hypre_CSRMatrix *D = A->diag, *O = A->offd;
+   if (D->memory_location != HYPRE_MEMORY_HOST)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRComputeL1NormsThreads: setup-time routine, expects host matrices");
+      return hypre_error_flag;
+   }
+   if (option != 1 && option != 4 && option != 5 && option != 6)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRComputeL1NormsThreads: option not supported");
+      return hypre_error_flag;
+   }
+   const HYPRE_Int n = D->num_rows, nco = O->num_cols;
+   if (num_threads < 1) { num_threads = 1; }
+   HYPRE_Real *l1 = hypre_TAlloc(HYPRE_Real, std::max(n, 1), HYPRE_MEMORY_HOST);
+   std::vector<HYPRE_Int> cf_offd;
+   const HYPRE_Int *cfo = nullptr;
+   if (cf_marker && nco)
+   {
+      cf_offd.resize((size_t) nco);
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      halo_forward<HYPRE_Int>(A->comm_pkg, cf_marker, cf_offd.data());
+      cfo = cf_offd.data();
+   }
+   bool zero_norm = false;
+   for (HYPRE_Int k = 0; k < num_threads; k++)
+   {
+      const HYPRE_Int size = n / num_threads, rest = n - size * num_threads;
+      const HYPRE_Int ns = k < rest ? k * size + k : k * size + rest;
+      const HYPRE_Int ne = k < rest ? (k + 1) * size + k + 1 : (k + 1) * size + rest;
+#pragma omp parallel for schedule(static)
+      for (HYPRE_Int i = ns; i < ne; i++)
+      {
+         if (option == 5)
+         {
+            l1[i] = D->data[D->i[i]];
+            if (l1[i] == 0.0) { l1[i] = 1.0; }
+            continue;
+         }
+         const bool use_cf = cf_marker != nullptr;
+         const HYPRE_Int cfd = use_cf ? cf_marker[i] : 0;
+         HYPRE_Real s = 0.0, dg = 0.0;
+         for (HYPRE_Int j = D->i[i]; j < D->i[i + 1]; j++)
+         {
+            const HYPRE_Int ii = D->j[j];
+            if (use_cf && cfd != cf_marker[ii]) { continue; }
+            if (option == 1) { s += std::fabs(D->data[j]); continue; }
+            if (ii == i)
+            {
+               dg = std::fabs(D->data[j]);
+               if (option == 4) { s += dg; }
+            }
+            else if (ii < ns || ii >= ne) { s += 0.5 * std::fabs(D->data[j]); }
+         }
+         if (nco)
+         {
+            for (HYPRE_Int j = O->i[i]; j < O->i[i + 1]; j++)
+            {
+               if (use_cf && cfd != cfo[O->j[j]]) { continue; }
+               s += (option == 1 ? 1.0 : 0.5) * std::fabs(O->data[j]);
+            }
+         }
+         if (option == 4) { if (s <= (4.0 / 3.0) * dg) { s = dg; } }
+         if (option == 6) { s = (dg + s + std::sqrt(dg * dg + s * s)) * 0.5; }
+         if (option < 5 && D->data[D->i[i]] < 0) { s = -s; }
+         l1[i] = s;
+      }
+   }
+   if (option < 5)
+   {
+      for (HYPRE_Int i = 0; i < n; i++) { if (std::fabs(l1[i]) == 0.0) { zero_norm = true; break; } }
+      if (zero_norm) { hypre_error_in_arg(1); }
+   }
+   *l1_norm_ptr = l1;
+   return hypre_error_flag;
+}
+
 // ===========================================================================
 // coarsest level: dense copy of the operator (par_gauss_elim.c:25-300)
 // ===========================================================================
@@ -1288,17 +1371,24 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          auto any = [&](int a, int b, int c, int e) { return gt[1] == a || gt[1] == b || gt[1] == c || gt[1] == e ||
                                                             gt[2] == a || gt[2] == b || gt[2] == c || gt[2] == e; };
          auto last_is = [&](int a, int b, int c, int e) { return gt[3] == a || gt[3] == b || gt[3] == c || gt[3] == e; };
-         if (!last && any(8, 89, 13, 14)) { hypre_ParCSRComputeL1Norms(Al, 4, cf, &l1); }
-         else if (last && last_is(8, 89, 13, 14)) { hypre_ParCSRComputeL1Norms(Al, 4, nullptr, &l1); }
-         if (!last && (gt[1] == 88 || gt[2] == 88)) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 6, cf, &l1); }
-         else if (last && gt[3] == 88) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 6, nullptr, &l1); }
-         if (!last && (gt[1] == 18 || gt[2] == 18)) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 1, cf, &l1); }
-         else if (last && gt[3] == 18) { hypre_Free(l1, HYPRE_MEMORY_HOST); hypre_ParCSRComputeL1Norms(Al, 1, nullptr, &l1); }
+         // ams.c:541-548: the host routine switches to the thread-block variant when OpenMP has > 1 thread
+         const int gs_threads = ((AmgPrivate *) d->amd_private)->emulated_threads;
+         auto l1_norms = [&](hypre_ParCSRMatrix *M, HYPRE_Int option, HYPRE_Int *cfm, HYPRE_Real **out)
+         {
+            if (gs_threads > 1) { hypre_ParCSRComputeL1NormsThreads(M, option, gs_threads, cfm, out); }
+            else { hypre_ParCSRComputeL1Norms(M, option, cfm, out); }
+         };
+         if (!last && any(8, 89, 13, 14)) { l1_norms(Al, 4, cf, &l1); }
+         else if (last && last_is(8, 89, 13, 14)) { l1_norms(Al, 4, nullptr, &l1); }
+         if (!last && (gt[1] == 88 || gt[2] == 88)) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 6, cf, &l1); }
+         else if (last && gt[3] == 88) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 6, nullptr, &l1); }
+         if (!last && (gt[1] == 18 || gt[2] == 18)) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 1, cf, &l1); }
+         else if (last && gt[3] == 18) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 1, nullptr, &l1); }
          if (gt[1] == 7 || gt[2] == 7 || (gt[3] == 7 && last) || gt[1] == 11 || gt[2] == 11 || (gt[3] == 11 && last) ||
              gt[1] == 12 || gt[2] == 12 || (gt[3] == 12 && last))
          {
             hypre_Free(l1, HYPRE_MEMORY_HOST);
-            hypre_ParCSRComputeL1Norms(Al, 5, nullptr, &l1);
+            l1_norms(Al, 5, nullptr, &l1);
          }
          if (l1)
          {

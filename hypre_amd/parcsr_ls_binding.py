@@ -70,6 +70,7 @@ PROTOTYPES = {
     "hypre_BoomerAMGInterpTruncation": (Int, [ParCSRp, Real, Int]),
     "hypre_BoomerAMGBuildCoarseOperatorKT": (Int, [ParCSRp, ParCSRp, ParCSRp, Int, C.POINTER(C.c_void_p)]),
     "hypre_ParCSRComputeL1Norms": (Int, [ParCSRp, Int, IntP, C.POINTER(RealP)]),
+    "hypre_ParCSRComputeL1NormsThreads": (Int, [ParCSRp, Int, Int, IntP, C.POINTER(RealP)]),
     "hypre_BoomerAMGRelax": (Int, [ParCSRp, ParVecp, IntP, Int, Int, Real, Real, RealP, ParVecp, ParVecp, ParVecp]),
     "hypre_BoomerAMGRelaxIF": (Int, [ParCSRp, ParVecp, IntP, Int, Int, Int, Real, Real, RealP, ParVecp, ParVecp,
                                      ParVecp]),

@@ -226,6 +226,9 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
                                                hypre_ParCSRMatrix **RAP_ptr);
 HYPRE_Int hypre_ParCSRComputeL1Norms(hypre_ParCSRMatrix *A, HYPRE_Int option, HYPRE_Int *cf_marker,
                                      HYPRE_Real **l1_norm_ptr);
+/* parcsr_ls/ams.c:4535-4915: the variant the host routine switches to under OpenMP (options 1, 4, 5, 6) */
+HYPRE_Int hypre_ParCSRComputeL1NormsThreads(hypre_ParCSRMatrix *A, HYPRE_Int option, HYPRE_Int num_threads,
+                                            HYPRE_Int *cf_marker, HYPRE_Real **l1_norm_ptr);
 
 /* ---- the hot path ---- */
 HYPRE_Int hypre_BoomerAMGRelax(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,

@@ -166,11 +166,9 @@ def test_amg_solve_iterations_match_oracle(gpu_lib, oracle, kw):
     lib.HYPRE_BoomerAMGDestroy(s)
 
 
-def test_golden_fsai103_pcg_relax7_on_device(gpu_lib):
-    """TEST_ij/fsai.saved:89-91 — `ij -n 10 10 10 -solver 1 -rlx 7`: 22 iterations, 7.480945e-09."""
+def _pcg_on_device(lib, **kw):
     from hypre_amd import binding as B, ij
-    lib = gpu_lib
-    opt, A, s = _setup(lib, n=(10, 10, 10), solver=1, relax_type=7)
+    opt, A, s = _setup(lib, solver=1, **kw)
     lib.HYPRE_BoomerAMGSetTol(s, 0.0)
     lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
     b, x0 = ij.build_rhs_host(opt, A)
@@ -187,10 +185,25 @@ def test_golden_fsai103_pcg_relax7_on_device(gpu_lib):
     lib.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
     lib.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
     B.check()
-    assert its.value == 22
-    assert abs(rel.value - 7.480945e-09) <= 1e-6 * 7.480945e-09
     lib.HYPRE_ParCSRPCGDestroy(pcg)
     lib.HYPRE_BoomerAMGDestroy(s)
+    return its.value, rel.value
+
+
+def test_golden_fsai103_pcg_relax7_on_device(gpu_lib):
+    """TEST_ij/fsai.saved:89-91 — `ij -n 10 10 10 -solver 1 -rlx 7`: 22 iterations, 7.480945e-09."""
+    its, rel = _pcg_on_device(gpu_lib, n=(10, 10, 10), relax_type=7)
+    assert its == 22
+    assert abs(rel - 7.480945e-09) <= 1e-6 * 7.480945e-09
+
+
+def test_survey_c1_default_smoothers_on_device(gpu_lib):
+    """BASELINE config C1: `ij -laplacian -n 64 64 64 -solver 1` with the CPU defaults
+    (HMIS, ext+i, hybrid l1-GS 13 down / 14 up in the 8 thread blocks of the reference's OpenMP run):
+    8 PCG iterations, final relative residual 7.176874e-09 — here with every sweep on the GPU."""
+    its, rel = _pcg_on_device(gpu_lib, n=(64, 64, 64), num_threads=8)
+    assert its == 8
+    assert abs(rel - 7.176874e-09) <= 5e-7 * 7.176874e-09
 
 
 def test_golden_default0_relax0_on_device(gpu_lib):
