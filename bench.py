@@ -31,6 +31,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per dimension PER GPU (weak scaling)")
+    # the default is BASELINE config C2/C3; the switches below select the other device configs
+    ap.add_argument("--problem", choices=["laplacian", "27pt", "difconv"], default="laplacian")
+    ap.add_argument("--relax", type=int, default=18, help="smoother (18 l1-Jacobi, 11/12 two-stage GS, 13 l1-GS ...)")
+    ap.add_argument("--mixed", action="store_true", help="fp32 matrix values inside the cycle (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (capped by affinity)")
@@ -111,10 +115,14 @@ def main():
     P, Q, R = proc_grid(world)
     n1 = args.n
     opt = ij.IJOptions(n=(n1 * P, n1 * Q, n1 * R), P=(P, Q, R), coarsen_type=8, interp_type=6, P_max_elmts=4,
-                       relax_type=18, num_sweeps=1)
+                       relax_type=args.relax, num_sweeps=1, problem=args.problem)
+    if args.problem == "difconv":
+        opt.c, opt.a = (1.0, 1.0, 0.001), (0.0, 0.0, 0.0)       # anisotropic diffusion (config C5)
     t0 = time.time()
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+    if args.mixed:
+        L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
     B.check()
     L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
@@ -198,7 +206,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle as O
-        amg = O.amg_from_solvers([s])
+        amg = O.amg_from_solvers([s], mixed_precision=args.mixed)
         f = np.ones(nloc)
         ur = np.zeros(nloc)
 
@@ -228,13 +236,19 @@ def main():
     if rank == 0:
         g, o = C.c_double(), C.c_double()
         L.hypre_amd_BoomerAMGGetComplexities(s, C.byref(g), C.byref(o))
+        stencil = {"laplacian": "7-pt Laplacian", "27pt": "27-pt Laplacian",
+                   "difconv": "7-pt anisotropic diffusion (1, 1, 0.001)"}[args.problem]
+        smoother = {18: "l1-Jacobi", 7: "Jacobi", 0: "weighted Jacobi", 11: "two-stage GS (1 inner)",
+                    12: "two-stage GS (2 inner)"}.get(args.relax, "relax %d" % args.relax)
+        arith = "fp32 matrix values / fp64 vectors" if args.mixed else "fp64"
         out = {
-            "metric": "BoomerAMG V-cycle DOF/s (256^3 7-pt Laplacian per GPU, l1-Jacobi V(1,1), fp64)",
+            "metric": "BoomerAMG V-cycle DOF/s (%d^3 %s per GPU, %s V(1,1), %s)" % (n1, stencil, smoother, arith),
             "value": dof_per_s, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d 7-pt Laplacian, %d rank(s) %dx%dx%d, PMIS + ext+i(4) + l1-Jacobi V(1,1)"
-                                   % (n1 * P, n1 * Q, n1 * R, world, P, Q, R),
+            "config": {"workload": "%dx%dx%d %s, %d rank(s) %dx%dx%d, PMIS + ext+i(4) + %s V(1,1)%s"
+                                   % (n1 * P, n1 * Q, n1 * R, stencil, world, P, Q, R, smoother,
+                                      ", fp32 matrix values in the cycle" if args.mixed else ""),
                        "transport": transport if world > 1 else "none",
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s},

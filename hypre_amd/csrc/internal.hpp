@@ -61,6 +61,9 @@ struct Handle
    // OpenMP thread count the hybrid Gauss-Seidel sweeps emulate (row blocks of
    // hypre_partition1D; 1 = one block per rank); set by the cycle from the solver
    int                   gs_threads    = 1;
+   // mixed precision (set by the cycle from the solver): SpMV-class kernels read fp32 copies
+   // of the matrix values
+   bool                  fp32_values   = false;
 };
 Handle &handle();
 const hypre_amd_CommOps *comm_ops(MPI_Comm comm);   // nullptr for an invalid handle

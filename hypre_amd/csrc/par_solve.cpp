@@ -409,6 +409,8 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
    handle().gs_threads = pv->emulated_threads;
+   const bool saved_fp32 = handle().fp32_values;
+   handle().fp32_values = pv->mixed_precision;
 
    // alternate solution buffers (allocated on the first cycle, reused afterwards)
    if ((int) pv->u_alt.size() != L) { pv->u_alt.assign((size_t) L, nullptr); pv->u_alt_len.assign((size_t) L, 0); }
@@ -575,6 +577,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    }
    U_array[0]->all_zeros = 0;
    (void) ztemp;
+   handle().fp32_values = saved_fp32;
    handle().sync_compute = saved_sync;
    maybe_sync();
    return err;

@@ -536,6 +536,18 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    if (plan->num_rows <= 0) { return; }
    SpmvArgs a = args;
    a.last_quad = (plan->nnz > 0 ? (int) (plan->nnz - 1) : 0) & ~3;
+   if (handle().fp32_values && !a.Aa32 && plan->nnz > 0)
+   {
+      // mixed precision: matrix values stream as fp32 (converted once per matrix), vectors and
+      // accumulation stay fp64
+      SpmvPlan *mp = const_cast<SpmvPlan *>(plan);
+      if (!mp->a32)
+      {
+         HIP_CHECK(hipMalloc((void **) &mp->a32, sizeof(float) * (((size_t) plan->nnz + 3) & ~(size_t) 3)));
+         launch_f64_to_f32(plan->a, mp->a32, (size_t) plan->nnz, s);
+      }
+      a.Aa32 = mp->a32;
+   }
    switch (op)
    {
       case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, a, s); break;

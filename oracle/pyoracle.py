@@ -265,9 +265,11 @@ def relax(A, f, cf_marker, relax_type, relax_points, w, omega, l1, u, num_thread
 # ---------------------------------------------------------------------------
 # bridges from the product's objects (fetched through the C ABI) to oracle structs
 # ---------------------------------------------------------------------------
-def par_from_handles(handles):
+def par_from_handles(handles, fp32_diag_values=False):
     """handles: list (one per rank, rank order) of hypre_ParCSRMatrix pointers
-    (ctypes POINTER(ParCSRMatrix) or raw addresses) living in this process."""
+    (ctypes POINTER(ParCSRMatrix) or raw addresses) living in this process.
+    fp32_diag_values: round the diag-block values to fp32 (the product's mixed-precision mode streams
+    fp32 copies of those values and accumulates in fp64, which is this matrix in exact arithmetic)."""
     import ctypes as C
     from hypre_amd import binding as B
     blocks, rs, cs = [], [], []
@@ -277,6 +279,8 @@ def par_from_handles(handles):
             h = C.cast(h, C.POINTER(B.ParCSRMatrix))
         m = h.contents
         di, dj, da = B.csr_to_arrays(m.diag)
+        if fp32_diag_values:
+            da = da.astype(np.float32).astype(np.float64)
         oi, oj, oa = B.csr_to_arrays(m.offd)
         nco = m.offd.contents.num_cols
         cmap = np.array([m.col_map_offd[k] for k in range(nco)], dtype=np.int64)
@@ -291,17 +295,21 @@ def par_from_handles(handles):
     return Par(blocks, rs, cs)
 
 
-def amg_from_solvers(solvers, num_threads=1):
-    """Build the oracle's hierarchy from one product solver per (virtual) rank."""
+def amg_from_solvers(solvers, num_threads=1, mixed_precision=False):
+    """Build the oracle's hierarchy from one product solver per (virtual) rank.
+    mixed_precision: model the product's fp32-matrix-value mode (operators and interpolation of every
+    level but the coarsest, whose dense solve stays fp64)."""
     import ctypes as C
     from hypre_amd import binding as B
     L = B.load_library()
     nl = L.hypre_amd_BoomerAMGGetNumLevels(solvers[0])
     A_levels, P_levels, cfs, l1s = [], [], [], []
     for l in range(nl):
-        A_levels.append(par_from_handles([L.hypre_amd_BoomerAMGGetA(s, l) for s in solvers]))
+        A_levels.append(par_from_handles([L.hypre_amd_BoomerAMGGetA(s, l) for s in solvers],
+                                         fp32_diag_values=mixed_precision and l < nl - 1))
         if l < nl - 1:
-            P_levels.append(par_from_handles([L.hypre_amd_BoomerAMGGetP(s, l) for s in solvers]))
+            P_levels.append(par_from_handles([L.hypre_amd_BoomerAMGGetP(s, l) for s in solvers],
+                                             fp32_diag_values=mixed_precision))
         cf_parts, l1_parts = [], []
         for s in solvers:
             cfp = L.hypre_amd_BoomerAMGGetCFMarker(s, l)

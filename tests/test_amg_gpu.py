@@ -166,9 +166,62 @@ def test_amg_solve_iterations_match_oracle(gpu_lib, oracle, kw):
     lib.HYPRE_BoomerAMGDestroy(s)
 
 
-def _pcg_on_device(lib, **kw):
+@pytest.mark.parametrize("kw", [
+    dict(relax_type=18, coarsen_type=8),
+    dict(relax_type=18, coarsen_type=8, relax_order=1),
+    dict(relax_type=7, coarsen_type=10, relax_wt=0.8),
+    dict(relax_type=18, coarsen_type=8, problem="difconv", c=(1.0, 1.0, 0.001), a=(0.0, 0.0, 0.0)),
+    dict(relax_type=18, coarsen_type=8, problem="27pt", cycle_type=2),
+])
+def test_mixed_precision_cycle(gpu_lib, oracle, kw):
+    """BASELINE config C5's arithmetic: matrix values streamed as fp32, vectors, accumulation,
+    smoother diagonals and the coarse solve in fp64.  That is the fp64 cycle of the hierarchy whose
+    operator / interpolation values are rounded to fp32, so the oracle on that hierarchy is matched to
+    1e-11 (summation association only); against the unrounded fp64 cycle the difference is fp32-sized."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    opt, A, s = _setup(lib, n=(12, 11, 10), **kw)
+    lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    amg32 = oracle.amg_from_solvers([s], mixed_precision=True)
+    amg64 = oracle.amg_from_solvers([s])
+    n = amg64.A_levels[0].nrows
+    f = rand_vector(n, 5)
+    for zero in (True, False):
+        u0 = np.zeros(n) if zero else rand_vector(n, 6)
+        du, df = B.parvec_from_numpy(u0), B.parvec_from_numpy(f)
+        if zero:
+            lib.hypre_ParVectorSetZeros(du)
+        lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+        lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+        lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+        B.check()
+        u = B.parvec_to_numpy(du)
+        u32, u64 = u0.copy(), u0.copy()
+        amg32.cycle(f, u32, u_all_zeros=zero)
+        amg64.cycle(f, u64, u_all_zeros=zero)
+        scale = np.max(np.abs(u64))
+        assert np.max(np.abs(u - u32)) <= 1e-11 * scale, (kw, zero)
+        d64 = np.max(np.abs(u - u64)) / scale
+        assert 0.0 < d64 <= 1e-5, (kw, zero, d64)
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+def test_mixed_precision_preconditioner_keeps_pcg_convergence(gpu_lib, oracle):
+    """Anisotropic diffusion (ij -difconv -c 1 1 0.001), AMG in mixed precision as the PCG
+    preconditioner: PCG itself is fp64, converges to the same tolerance within one iteration of the
+    all-fp64 run."""
+    kw = dict(n=(20, 20, 20), problem="difconv", c=(1.0, 1.0, 0.001), a=(0.0, 0.0, 0.0), relax_type=18, coarsen_type=8)
+    its64, rel64 = _pcg_on_device(gpu_lib, **kw)
+    its32, rel32 = _pcg_on_device(gpu_lib, mixed=True, **kw)
+    assert abs(its32 - its64) <= 1
+    assert rel32 < 1e-8 and rel64 < 1e-8
+
+
+def _pcg_on_device(lib, mixed=False, **kw):
     from hypre_amd import binding as B, ij
     opt, A, s = _setup(lib, solver=1, **kw)
+    if mixed:
+        lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
     lib.HYPRE_BoomerAMGSetTol(s, 0.0)
     lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
     b, x0 = ij.build_rhs_host(opt, A)
