@@ -127,10 +127,10 @@ struct SpmvArgs
    int                  fill;     // HYPRE_SPMV_FILL_*
    int                  row_offset;
    int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
-   int                  stream_nt;   // non-temporal loads for the (col,val) streams
+   int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
 };
-void spmv_default_flags(SpmvArgs &a);   // fills stream_nt / xcd_map from the tuning knobs
+void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);

@@ -19,18 +19,20 @@ using namespace hamd;
 // ===========================================================================
 namespace hamd {
 
-// Tuning knobs (A/B-testable without rebuilding): HYPRE_AMD_SPMV_NT, HYPRE_AMD_SPMV_XCD.
+// Tuning knobs (A/B-testable without rebuilding): HYPRE_AMD_SPMV_GT, HYPRE_AMD_SPMV_XCD.
 void spmv_default_flags(SpmvArgs &a)
 {
-   static int nt = -1, xcd = 0;
-   if (nt < 0)
+   static int gt = -1, xcd = 0;
+   if (gt < 0)
    {
-      const char *e = getenv("HYPRE_AMD_SPMV_NT");
-      nt = e ? atoi(e) : 0;   // measured on MI355X (256^3 7-pt): non-temporal stream loads are ~7 % slower than plain ones
+      const char *e = getenv("HYPRE_AMD_SPMV_GT");
+      // measured on MI355X, 256^3 hierarchy: level 0 (7/row) 4.82 -> 5.01 TB/s, level 1 (29/row)
+      // 3.76 -> 4.15 TB/s, level 2 (70/row) 3.17 -> 3.41 TB/s: fewer cache lines per gather instruction
+      gt = e ? atoi(e) : 1;
       e = getenv("HYPRE_AMD_SPMV_XCD");
       xcd = e ? atoi(e) : 0;   // measured: dispatch order 4.96 TB/s, chunks of 4..28 tiles per XCD the same, contiguous eighths 4.59 TB/s
    }
-   a.stream_nt = nt; a.xcd_map = xcd;
+   a.gather_t = gt; a.xcd_map = xcd;
 }
 
 static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> &plan_table()

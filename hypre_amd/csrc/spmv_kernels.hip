@@ -201,39 +201,38 @@ struct TileStream
    v4f fA, fB;                     // fp32 values (mixed precision)
 };
 
-template <bool NT, typename T>
+template <typename T>
 __device__ __forceinline__ T stream_load(const void *p)
 {
-   if (NT) { return __builtin_nontemporal_load(reinterpret_cast<const T *>(p)); }
    return *reinterpret_cast<const T *>(p);
 }
 
 // issue the stream loads of the tile whose entries are [k0, k1), ka = k0 & ~3
-template <bool F32, bool NT>
+template <bool F32>
 __device__ __forceinline__ void stream_issue(const SpmvArgs &p, int ka, int k1, TileStream &s)
 {
    const int kA = ka + 4 * (int) threadIdx.x;
    const int kB = kA + 4 * SPMV_THREADS;
    const int qA = min(kA < k1 ? kA : ka, p.last_quad);
    const int qB = min(kB < k1 ? kB : ka, p.last_quad);
-   s.cA = stream_load<NT, v4i>(p.Aj + qA);
-   s.cB = stream_load<NT, v4i>(p.Aj + qB);
+   s.cA = stream_load<v4i>(p.Aj + qA);
+   s.cB = stream_load<v4i>(p.Aj + qB);
    if (F32)
    {
-      s.fA = stream_load<NT, v4f>(p.Aa32 + qA);
-      s.fB = stream_load<NT, v4f>(p.Aa32 + qB);
+      s.fA = stream_load<v4f>(p.Aa32 + qA);
+      s.fB = stream_load<v4f>(p.Aa32 + qB);
    }
    else
    {
-      s.vA01 = stream_load<NT, v2d>(p.Aa + qA);
-      s.vA23 = stream_load<NT, v2d>(p.Aa + qA + 2);
-      s.vB01 = stream_load<NT, v2d>(p.Aa + qB);
-      s.vB23 = stream_load<NT, v2d>(p.Aa + qB + 2);
+      s.vA01 = stream_load<v2d>(p.Aa + qA);
+      s.vA23 = stream_load<v2d>(p.Aa + qA + 2);
+      s.vB01 = stream_load<v2d>(p.Aa + qB);
+      s.vB23 = stream_load<v2d>(p.Aa + qB + 2);
    }
 }
 
 // gather x for the entries held in s, park the products in LDS (prod[k - ka])
-template <bool F32, bool NT>
+template <bool F32>
 __device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1, int ka, const TileStream &s,
                                                double *prod)
 {
@@ -287,12 +286,79 @@ __device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1
    // tail of a tile whose last row runs past 2 quads per lane
    for (int k = kB + 4 * SPMV_THREADS; k < k1; k += 4 * SPMV_THREADS)
    {
-      const v4i c = stream_load<NT, v4i>(p.Aj + k);
+      const v4i c = stream_load<v4i>(p.Aj + k);
       double v0, v1, v2, v3;
-      if (F32) { const v4f f = stream_load<NT, v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
+      if (F32) { const v4f f = stream_load<v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
       else
       {
-         const v2d lo = stream_load<NT, v2d>(p.Aa + k), hi = stream_load<NT, v2d>(p.Aa + k + 2);
+         const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
+         v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+      }
+      double *dst = prod + (k - ka);
+      if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
+      if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
+      if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
+      if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
+   }
+}
+
+// Same result, different lane <-> entry pairing for the gathers.  A lane streams
+// 4 consecutive entries (one 16-byte load per array), so the k-th gather of a wave
+// touches every 4th entry of a 256-entry chunk: the x lines of up to 256/rowlen rows.
+// Here the wave passes its column indices through LDS so that gather c covers the 64
+// consecutive entries 64c..64c+63 of the chunk (the x lines of a few neighbouring rows
+// only), parks the gathered x values in LDS in entry order, and every lane reads back
+// the 4 it owns.  All of it happens inside the wave's own 2 KB of the product area:
+// no workgroup barrier.  Slots outside the tile's [k0, k1) gather x[0] and their products are
+// never read.
+template <bool F32>
+__device__ __forceinline__ void stream_consume_gt(const SpmvArgs &p, int k0, int k1, int ka, const TileStream &s,
+                                                  double *prod)
+{
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+   for (int half = 0; half < 2; half++)
+   {
+      double *chunk = prod + half * (4 * SPMV_THREADS) + 256 * wave;     // entries ka + half*1024 + 256*wave ...
+      int    *ci = reinterpret_cast<int *>(chunk);
+      *reinterpret_cast<v4i *>(ci + 4 * lane) = half ? s.cB : s.cA;
+      __builtin_amdgcn_wave_barrier();
+      // entries outside [k0, k1) may lie past the end of the arrays (the tail of the last
+      // 16-byte quad holds no entry): their "columns" must not be dereferenced
+      const int e0 = ka + half * (4 * SPMV_THREADS) + 256 * wave + lane;
+      const int c0 = (e0       >= k0 && e0       < k1) ? ci[lane]       : 0;
+      const int c1 = (e0 + 64  >= k0 && e0 + 64  < k1) ? ci[64 + lane]  : 0;
+      const int c2 = (e0 + 128 >= k0 && e0 + 128 < k1) ? ci[128 + lane] : 0;
+      const int c3 = (e0 + 192 >= k0 && e0 + 192 < k1) ? ci[192 + lane] : 0;
+      const double x0 = p.x[c0], x1 = p.x[c1], x2 = p.x[c2], x3 = p.x[c3];
+      __builtin_amdgcn_wave_barrier();
+      chunk[lane] = x0; chunk[64 + lane] = x1; chunk[128 + lane] = x2; chunk[192 + lane] = x3;
+      __builtin_amdgcn_wave_barrier();
+      const v2d xa = *reinterpret_cast<const v2d *>(chunk + 4 * lane);
+      const v2d xb = *reinterpret_cast<const v2d *>(chunk + 4 * lane + 2);
+      v2d lo, hi;
+      if (F32)
+      {
+         const v4f f = half ? s.fB : s.fA;
+         lo.x = (double) f.x * xa.x; lo.y = (double) f.y * xa.y; hi.x = (double) f.z * xb.x; hi.y = (double) f.w * xb.y;
+      }
+      else
+      {
+         const v2d v01 = half ? s.vB01 : s.vA01, v23 = half ? s.vB23 : s.vA23;
+         lo = v01 * xa; hi = v23 * xb;
+      }
+      *reinterpret_cast<v2d *>(chunk + 4 * lane)     = lo;
+      *reinterpret_cast<v2d *>(chunk + 4 * lane + 2) = hi;
+   }
+   // tail of a tile whose last row runs past 2 quads per lane
+   for (int k = ka + 8 * SPMV_THREADS + 4 * (int) threadIdx.x; k < k1; k += 4 * SPMV_THREADS)
+   {
+      const v4i c = stream_load<v4i>(p.Aj + k);
+      double v0, v1, v2, v3;
+      if (F32) { const v4f f = stream_load<v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
+      else
+      {
+         const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
          v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
       }
       double *dst = prod + (k - ka);
@@ -312,7 +378,7 @@ __device__ __forceinline__ RowOps tile_row_ops(const SpmvArgs &p, int r0, int nr
 }
 
 // One workgroup per tile, in dispatch order (or a re-mapped order, see xcd_map).
-template <int OP, bool F32, bool HASFILL, bool NT>
+template <int OP, bool F32, bool HASFILL, bool GT>
 __global__ __launch_bounds__(SPMV_THREADS)
 void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
                        int num_tiles, int prod_elems, int rowsum_elems)
@@ -338,23 +404,26 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    }
    if (tile >= num_tiles) { return; }
 
+   // The tile's entries [k0, k1) start inside [tile*TILE, tile*TILE + longest row): the first
+   // TILE entries from tile*TILE on are requested before the tile's bounds are known, so the
+   // matrix stream is in flight while the bounds, then the row pointers and this lane's
+   // epilogue operands arrive.  Entries before k0 belong to the previous tile and are dropped;
+   // entries past tile*TILE + TILE (the spill of the last row) are picked up by the tail loop.
+   const int ka = tile * SPMV_TILE;
+   TileStream S;
+   stream_issue<F32>(p, ka, 0x7fffffff, S);
+
    const int r0 = tile_row[tile];
    const int r1 = tile_row[tile + 1];
    if (r1 <= r0) { return; }
    const int k0 = tile_k[tile];
    const int k1 = tile_k[tile + 1];
-   const int ka = k0 & ~3;
    const int tid = threadIdx.x;
    const int nrows = r1 - r0;
-
-   // matrix stream first, then row pointers -> LDS and this lane's epilogue
-   // operands -> registers, so that their latency hides under the stream's
-   TileStream S;
-   stream_issue<F32, NT>(p, ka, k1, S);
    for (int t = tid; t <= nrows && t <= RP_CAP; t += SPMV_THREADS) { rp[t] = p.Ai[r0 + t]; }
    const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
 
-   stream_consume<F32, NT>(p, k0, k1, ka, S, prod);
+   if (GT) { stream_consume_gt<F32>(p, k0, k1, ka, S, prod); } else { stream_consume<F32>(p, k0, k1, ka, S, prod); }
    __syncthreads();
    tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, ops);
 }
@@ -484,22 +553,22 @@ static inline size_t tiled_lds_bytes(const SpmvPlan *plan, int &rowsum_elems)
    return sizeof(double) * (size_t) (plan->prod_elems + rowsum_elems) + sizeof(int) * (size_t) (RP_CAP + 4);
 }
 
-template <int OP, bool F32, bool FILL, bool NT>
-static void launch_tiled_nt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+template <int OP, bool F32, bool FILL, bool GT>
+static void launch_tiled_gt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
    int rowsum_elems;
    const size_t lds = tiled_lds_bytes(plan, rowsum_elems);
    const int unit = a.xcd_map > 0 ? 8 * a.xcd_map : 8;
    const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
-   hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL, NT>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
+   hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL, GT>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
                       plan->d_tile_row, plan->d_tile_k, plan->num_tiles, plan->prod_elems, rowsum_elems);
 }
 
 template <int OP, bool F32, bool FILL>
 static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
-   if (a.stream_nt) { launch_tiled_nt<OP, F32, FILL, true>(plan, a, s); }
-   else { launch_tiled_nt<OP, F32, FILL, false>(plan, a, s); }
+   if (a.gather_t) { launch_tiled_gt<OP, F32, FILL, true>(plan, a, s); }
+   else { launch_tiled_gt<OP, F32, FILL, false>(plan, a, s); }
 }
 
 template <int OP>
