@@ -101,6 +101,8 @@ PROTOTYPES = {
     # utilities
     "hypre_error_handler": (None, [C.c_char_p, Int, Int, C.c_char_p]),
     "HYPRE_GetError": (Int, []),
+    "HYPRE_CheckError": (Int, [Int, Int]),
+    "HYPRE_ClearError": (Int, [Int]),
     "HYPRE_ClearAllErrors": (Int, []),
     "HYPRE_GetErrorArg": (Int, []),
     "hypre_amd_LastErrorMessage": (C.c_char_p, []),

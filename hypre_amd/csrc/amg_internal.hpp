@@ -2,6 +2,7 @@
 #pragma once
 #include "internal.hpp"
 #include "hypre_amd_parcsr_ls.h"
+#include <utility>
 #include <vector>
 
 namespace hamd {
@@ -11,6 +12,9 @@ struct AmgPrivate
 {
    int  emulated_threads = 1;      // thread count the thread-partitioned host loops emulate
    bool mixed_precision  = false;
+   // per-level overrides of the smoother weights (HYPRE_BoomerAMGSetLevelRelaxWt / SetLevelOuterWt),
+   // applied over the uniform values when setup fills relax_weight[] / omega[]
+   std::vector<std::pair<int, double>> level_relax_wt, level_outer_wt;
 
    // second solution buffer per level: Jacobi-type sweeps are out-of-place
    // (u_new is written while u_old is gathered), so every level ping-pongs

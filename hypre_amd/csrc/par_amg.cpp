@@ -188,8 +188,36 @@ HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver s, HYPRE_Int v, HYPRE_In
    return hypre_error_flag;
 }
 HYPRE_Int HYPRE_BoomerAMGSetRelaxOrder(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->relax_order = v; return hypre_error_flag; }
-HYPRE_Int HYPRE_BoomerAMGSetRelaxWt(HYPRE_Solver s, HYPRE_Real v) { AMG_DATA(s, d); d->user_relax_weight = v; return hypre_error_flag; }
-HYPRE_Int HYPRE_BoomerAMGSetOuterWt(HYPRE_Solver s, HYPRE_Real v) { AMG_DATA(s, d); d->outer_wt = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetRelaxWt(HYPRE_Solver s, HYPRE_Real v)
+{
+   // par_amg.c:2436-2463: the uniform value replaces every level's weight, earlier level overrides included
+   AMG_DATA(s, d);
+   d->user_relax_weight = v;
+   ((AmgPrivate *) d->amd_private)->level_relax_wt.clear();
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_BoomerAMGSetOuterWt(HYPRE_Solver s, HYPRE_Real v)
+{
+   AMG_DATA(s, d);
+   d->outer_wt = v;
+   ((AmgPrivate *) d->amd_private)->level_outer_wt.clear();
+   return hypre_error_flag;
+}
+// par_amg.c:2466-2495, 2590-2620: weight of one level (level < max_levels, else HYPRE_ERROR_ARG on argument 3)
+HYPRE_Int HYPRE_BoomerAMGSetLevelRelaxWt(HYPRE_Solver s, HYPRE_Real v, HYPRE_Int level)
+{
+   AMG_DATA(s, d);
+   if (level > d->max_levels - 1 || level < 0) { hypre_error_in_arg(3); return hypre_error_flag; }
+   ((AmgPrivate *) d->amd_private)->level_relax_wt.emplace_back((int) level, (double) v);
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_BoomerAMGSetLevelOuterWt(HYPRE_Solver s, HYPRE_Real v, HYPRE_Int level)
+{
+   AMG_DATA(s, d);
+   if (level > d->max_levels - 1 || level < 0) { hypre_error_in_arg(3); return hypre_error_flag; }
+   ((AmgPrivate *) d->amd_private)->level_outer_wt.emplace_back((int) level, (double) v);
+   return hypre_error_flag;
+}
 HYPRE_Int HYPRE_BoomerAMGSetPrintLevel(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->print_level = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGSetLogging(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->logging = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver s, HYPRE_Int *v)
@@ -220,6 +248,11 @@ HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver s, HYPRE_Real *grid, H
    }
    return hypre_error_flag;
 }
+
+// operations of the last cycle as the reference counts them (par_cycle.c:413-430); divided by the
+// fine operator's nonzeros this is the "cycle" complexity the reference prints
+HYPRE_Int hypre_amd_BoomerAMGGetCycleOpCount(HYPRE_Solver s, HYPRE_Real *count)
+{ AMG_DATA(s, d); if (count) { *count = d->cycle_op_count; } return hypre_error_flag; }
 
 HYPRE_Int hypre_amd_BoomerAMGGetNumLevels(HYPRE_Solver s) { return s ? ((hypre_ParAMGData *) s)->num_levels : 0; }
 hypre_ParCSRMatrix *hypre_amd_BoomerAMGGetA(HYPRE_Solver s, HYPRE_Int l)

@@ -1226,6 +1226,11 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    d->relax_weight = (HYPRE_Real *) calloc((size_t) max_levels, sizeof(HYPRE_Real));
    d->omega = (HYPRE_Real *) calloc((size_t) max_levels, sizeof(HYPRE_Real));
    for (int l = 0; l < max_levels; l++) { d->relax_weight[l] = d->user_relax_weight; d->omega[l] = d->outer_wt; }
+   {
+      AmgPrivate *pvw = (AmgPrivate *) d->amd_private;
+      for (auto &lw : pvw->level_relax_wt) { if (lw.first < max_levels) { d->relax_weight[lw.first] = lw.second; } }
+      for (auto &lw : pvw->level_outer_wt) { if (lw.first < max_levels) { d->omega[lw.first] = lw.second; } }
+   }
 
    // the setup works on host copies; a device-resident A is cloned once
    std::vector<hypre_ParCSRMatrix *> hostA((size_t) max_levels, nullptr);

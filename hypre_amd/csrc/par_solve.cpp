@@ -437,6 +437,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    double *vtemp = d->Vtemp->local_vector->data;
    double *ztemp = d->Ztemp->local_vector->data;
    const bool old_version = d->grid_relax_points != nullptr;
+   double cycle_op_count = d->cycle_op_count;
 
    while (not_finished)
    {
@@ -460,6 +461,13 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
          int relax_points = 0, relax_local = d->relax_order;
          if (L == 1 && d->max_levels > 1) { relax_points = 0; relax_local = 0; }
          else if (old_version) { relax_points = d->grid_relax_points[cycle_param][j]; }
+         // par_cycle.c:413-430: the reference's ("VERY sloppy") operation count behind the printed cycle complexity
+         if (old_version && level < L - 1)
+         {
+            if (relax_points == 1) { cycle_op_count += A[level + 1]->d_num_nonzeros; }
+            else if (relax_points == -1) { cycle_op_count += A[level]->d_num_nonzeros - A[level + 1]->d_num_nonzeros; }
+         }
+         else { cycle_op_count += A[level]->d_num_nonzeros; }
          if (is_ge_type(relax_type))
          {
             // the dense solve reads F[level] and writes the home vector
@@ -576,6 +584,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       launch_copy(lv[0].home, lv[0].cur, (size_t) A[0]->diag->num_rows, s);
    }
    U_array[0]->all_zeros = 0;
+   d->cycle_op_count = cycle_op_count;
    (void) ztemp;
    handle().fp32_values = saved_fp32;
    handle().sync_compute = saved_sync;

@@ -28,6 +28,14 @@ extern "C" const char *hypre_amd_LastErrorMessage(void) { return g_last_msg.c_st
 extern "C" HYPRE_Int HYPRE_GetError(void) { return hypre_error_flag; }
 extern "C" HYPRE_Int HYPRE_ClearAllErrors(void) { hypre_error_flag = 0; g_last_msg.clear(); return 0; }
 extern "C" HYPRE_Int HYPRE_GetErrorArg(void) { return (hypre_error_flag >> 3) & 31; }
+// utilities/error.c:221-225: clear the given bits (the value returned is the masked flag after clearing)
+extern "C" HYPRE_Int HYPRE_ClearError(HYPRE_Int hypre_error_code)
+{
+   hypre_error_flag &= ~hypre_error_code;
+   return (hypre_error_flag & hypre_error_code);
+}
+// utilities/error.c:161-164
+extern "C" HYPRE_Int HYPRE_CheckError(HYPRE_Int hypre_ierr, HYPRE_Int hypre_error_code) { return hypre_ierr & hypre_error_code; }
 
 namespace hamd {
 

@@ -49,6 +49,10 @@ class IJOptions:
         self.precon_cycles = 1
         self.keep_transpose = 1
         self.num_threads = 1
+        self.ns_down = self.ns_up = self.ns_coarse = -1   # -ns_down / -ns_up / -ns_coarse
+        self.level_w = None           # -wl  value level
+        self.level_ow = None          # -owl value level
+        self.mixed = False            # fp32 matrix values inside the cycle (extension)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown ij option %r" % k)
@@ -178,5 +182,171 @@ def create_amg(opt, memory_location=DEVICE):
     L.HYPRE_BoomerAMGSetMaxRowSum(s, opt.max_row_sum)
     L.HYPRE_BoomerAMGSetMaxIter(s, opt.mg_max_iter)
     L.HYPRE_BoomerAMGSetKeepTranspose(s, opt.keep_transpose)
+    for k, sweeps in ((1, opt.ns_down), (2, opt.ns_up), (3, opt.ns_coarse)):
+        if sweeps > -1:
+            L.HYPRE_BoomerAMGSetCycleNumSweeps(s, sweeps, k)
+    if opt.level_w is not None:
+        L.HYPRE_BoomerAMGSetLevelRelaxWt(s, opt.level_w[0], opt.level_w[1])
+    if opt.level_ow is not None:
+        L.HYPRE_BoomerAMGSetLevelOuterWt(s, opt.level_ow[0], opt.level_ow[1])
+    if opt.mixed:
+        L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
     B.check()
     return s
+
+
+# ---------------------------------------------------------------------------
+# command line of the reference driver (test/ij.c:521-2260), in-scope subset
+# ---------------------------------------------------------------------------
+# flag -> (attribute, converter, number of values); tuples of floats/ints for multi-valued flags
+_VALUE_FLAGS = {
+    "-solver": ("solver", int, 1), "-rlx": ("relax_type", int, 1), "-rlx_down": ("relax_down", int, 1),
+    "-rlx_up": ("relax_up", int, 1), "-rlx_coarse": ("relax_coarse", int, 1), "-ns": ("num_sweeps", int, 1),
+    "-ns_down": ("ns_down", int, 1), "-ns_up": ("ns_up", int, 1), "-ns_coarse": ("ns_coarse", int, 1),
+    "-w": ("relax_wt", float, 1), "-ow": ("outer_wt", float, 1), "-CF": ("relax_order", int, 1),
+    "-mu": ("cycle_type", int, 1), "-th": ("strong_threshold", float, 1), "-mxrs": ("max_row_sum", float, 1),
+    "-tr": ("trunc_factor", float, 1), "-Pmx": ("P_max_elmts", int, 1), "-interptype": ("interp_type", int, 1),
+    "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
+    "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
+    "-precon_cycles": ("precon_cycles", int, 1),
+    "-n": ("n", int, 3), "-P": ("P", int, 3), "-c": ("c", float, 3), "-a": ("a", float, 3),
+    # extensions of this driver (no reference counterpart)
+    "-amd_threads": ("num_threads", int, 1),
+}
+_SWITCH_FLAGS = {
+    "-laplacian": ("problem", "laplacian"), "-27pt": ("problem", "27pt"), "-difconv": ("problem", "difconv"),
+    "-rhsrand": ("rhs", "rand"), "-rhsisone": ("rhs", "one"), "-xisone": ("rhs", "xisone"),
+    "-pmis": ("coarsen_type", 8), "-pmis1": ("coarsen_type", 9), "-hmis": ("coarsen_type", 10),
+    "-fmg": ("fcycle", 1), "-amd_mixed": ("mixed", True),
+}
+
+
+def parse_cli(argv):
+    """Reference `ij` flags -> IJOptions.  Flags outside the scope of this library are an error, never
+    silently dropped."""
+    opt = IJOptions()
+    i = 0
+    while i < len(argv):
+        flag = argv[i]
+        if flag in _SWITCH_FLAGS:
+            attr, val = _SWITCH_FLAGS[flag]
+            setattr(opt, attr, val)
+            i += 1
+        elif flag in _VALUE_FLAGS:
+            attr, conv, count = _VALUE_FLAGS[flag]
+            vals = [conv(v) for v in argv[i + 1:i + 1 + count]]
+            if len(vals) != count:
+                raise SystemExit("ij: %s needs %d value(s)" % (flag, count))
+            setattr(opt, attr, vals[0] if count == 1 else tuple(vals))
+            i += 1 + count
+        elif flag in ("-wl", "-owl"):
+            val, lev = float(argv[i + 1]), int(argv[i + 2])
+            if lev > -1:        # test/ij.c:4543-4550 applies the level weight only for level > -1
+                setattr(opt, "level_w" if flag == "-wl" else "level_ow", (val, lev))
+            i += 3
+        else:
+            raise SystemExit("ij: option %s is outside the scope of this driver" % flag)
+    if opt.solver not in (0, 1):
+        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG)" % opt.solver)
+    return opt
+
+
+def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
+    """test/ij.c: build the problem, set up, solve on the device, print the driver's closing lines."""
+    import sys
+    out = out or sys.stdout
+    L = B.load_library()
+    A = build_matrix(opt, comm=comm, rank=rank, nprocs=nprocs)
+    s = create_amg(opt, memory_location=DEVICE)
+    L.HYPRE_BoomerAMGSetup(s, A, None, None)
+    B.check()
+    L.hypre_ParCSRMatrixMigrate(A, DEVICE)
+    Am = A.contents
+    first, nglob = int(Am.row_starts[0]), int(Am.global_num_rows)
+    b, x0 = build_rhs_host(opt, A, rank=rank, allreduce=allreduce)
+    dx = B.parvec_from_numpy(x0, comm=comm, global_size=nglob, first=first)
+    if b is None:
+        ones = B.parvec_from_numpy(np.ones(len(x0)), comm=comm, global_size=nglob, first=first)
+        db = B.parvec_from_numpy(np.zeros(len(x0)), comm=comm, global_size=nglob, first=first)
+        L.hypre_ParCSRMatrixMatvec(1.0, A, ones, 0.0, db)
+    else:
+        db = B.parvec_from_numpy(b, comm=comm, global_size=nglob, first=first)
+    its, rel = C.c_int(), C.c_double()
+    lines = []
+    if opt.solver == 0:
+        # ||b - A x0|| for the average convergence factor (par_amg_solve.c:237-256, 347-355)
+        r0 = B.parvec_from_numpy(np.zeros(len(x0)), comm=comm, global_size=nglob, first=first)
+        L.hypre_ParCSRMatrixMatvecOutOfPlace(-1.0, A, dx, 1.0, db, r0)
+        L.hypre_ParVectorInnerProd.restype = C.c_double
+        nrm0 = float(np.sqrt(L.hypre_ParVectorInnerProd(r0, r0)))
+        nrmb = float(np.sqrt(L.hypre_ParVectorInnerProd(db, db)))
+        L.HYPRE_BoomerAMGSolve(s, A, db, dx)
+        L.HYPRE_BoomerAMGGetNumIterations(s, C.byref(its))
+        L.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+        g, o, cyc = C.c_double(), C.c_double(), C.c_double()
+        L.hypre_amd_BoomerAMGGetComplexities(s, C.byref(g), C.byref(o))
+        L.hypre_amd_BoomerAMGGetCycleOpCount(s, C.byref(cyc))
+        resid = rel.value * (nrmb if nrmb != 0.0 else 1.0)
+        conv = (resid / nrm0) ** (1.0 / its.value) if its.value > 0 and nrm0 != 0.0 else 1.0
+        nnz0 = float(Am.d_num_nonzeros)
+        lines += ["", " Average Convergence Factor = %f" % conv, "",
+                  "     Complexity:    grid = %f" % g.value,
+                  "                operator = %f" % o.value,
+                  "                   cycle = %f" % (cyc.value / nnz0 if nnz0 else 0.0), "", "", "",
+                  "BoomerAMG Iterations = %d" % its.value,
+                  "Final Relative Residual Norm = %e" % rel.value, ""]
+    else:
+        L.HYPRE_BoomerAMGSetTol(s, 0.0)
+        L.HYPRE_BoomerAMGSetMaxIter(s, opt.precon_cycles)
+        pcg = C.c_void_p()
+        L.HYPRE_ParCSRPCGCreate(comm, C.byref(pcg))
+        L.HYPRE_PCGSetTol(pcg, opt.tol)
+        L.HYPRE_PCGSetMaxIter(pcg, opt.max_iter)
+        L.HYPRE_PCGSetTwoNorm(pcg, opt.two_norm)
+        L.HYPRE_PCGSetPrecond(pcg, C.cast(L.HYPRE_BoomerAMGSolve, C.c_void_p), None, s)
+        L.HYPRE_ParCSRPCGSetup(pcg, A, db, dx)
+        L.HYPRE_ParCSRPCGSolve(pcg, A, db, dx)
+        L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
+        L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
+        L.HYPRE_ParCSRPCGDestroy(pcg)
+        lines += ["", "Iterations = %d" % its.value, "Final Relative Residual Norm = %e" % rel.value, ""]
+    L.HYPRE_ClearError(256)          # HYPRE_ERROR_CONV is reported through the iteration count, as the driver does
+    B.check()
+    L.HYPRE_BoomerAMGDestroy(s)
+    if rank == 0:
+        out.write("\n".join(lines) + "\n")
+        out.flush()
+    return its.value, rel.value
+
+
+def main(argv=None):
+    """`python -m hypre_amd.ij <reference ij flags>`; under torch.distributed.run one rank per process
+    (ranks may share a GPU: the halo then travels over gloo, staged through the host)."""
+    import os
+    import sys
+    argv = sys.argv[1:] if argv is None else argv
+    opt = parse_cli(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        run(opt)
+        return 0
+    import torch
+    import torch.distributed as dist
+    from . import distributed
+    dist.init_process_group(backend="gloo")
+    rank = dist.get_rank()
+
+    def allsum(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    comm = distributed.create_callback_comm(dist, rank, world)
+    run(opt, comm=comm, rank=rank, nprocs=world, allreduce=allsum)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

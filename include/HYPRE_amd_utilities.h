@@ -84,6 +84,9 @@ void hypre_error_handler(const char *filename, HYPRE_Int line, HYPRE_Int ierr, c
 HYPRE_Int HYPRE_GetError(void);
 HYPRE_Int HYPRE_ClearAllErrors(void);
 HYPRE_Int HYPRE_GetErrorArg(void);
+/* utilities/error.c:161-164, 221-225 */
+HYPRE_Int HYPRE_CheckError(HYPRE_Int hypre_ierr, HYPRE_Int hypre_error_code);
+HYPRE_Int HYPRE_ClearError(HYPRE_Int hypre_error_code);
 /* last message passed to hypre_error_w_msg (empty string if none) */
 const char *hypre_amd_LastErrorMessage(void);
 

@@ -177,6 +177,9 @@ HYPRE_Int HYPRE_BoomerAMGSetCycleRelaxType(HYPRE_Solver solver, HYPRE_Int relax_
 HYPRE_Int HYPRE_BoomerAMGSetRelaxOrder(HYPRE_Solver solver, HYPRE_Int relax_order);
 HYPRE_Int HYPRE_BoomerAMGSetRelaxWt(HYPRE_Solver solver, HYPRE_Real relax_weight);
 HYPRE_Int HYPRE_BoomerAMGSetOuterWt(HYPRE_Solver solver, HYPRE_Real omega);
+/* parcsr_ls/HYPRE_parcsr_amg.c:560-600 -> par_amg.c:2466,2590: weight of one level, overriding the uniform value */
+HYPRE_Int HYPRE_BoomerAMGSetLevelRelaxWt(HYPRE_Solver solver, HYPRE_Real relax_weight, HYPRE_Int level);
+HYPRE_Int HYPRE_BoomerAMGSetLevelOuterWt(HYPRE_Solver solver, HYPRE_Real omega, HYPRE_Int level);
 HYPRE_Int HYPRE_BoomerAMGSetPrintLevel(HYPRE_Solver solver, HYPRE_Int print_level);
 HYPRE_Int HYPRE_BoomerAMGSetLogging(HYPRE_Solver solver, HYPRE_Int logging);
 HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
@@ -193,6 +196,8 @@ HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_th
 HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on);
 /* grid / operator complexity of the last setup */
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
+/* par_amg_solve.c:391-401: operation count of the last cycle (the reference's cycle complexity = this / nnz(A_0)) */
+HYPRE_Int hypre_amd_BoomerAMGGetCycleOpCount(HYPRE_Solver solver, HYPRE_Real *count);
 /* algorithmic HBM bytes of one cycle on the current hierarchy (SURVEY §8d formula) */
 HYPRE_Real hypre_amd_BoomerAMGCycleBytes(HYPRE_Solver solver);
 /* level accessors for tests / the oracle harness */
