@@ -82,6 +82,12 @@ void launch_gs_level(const GsArgs &a, int start, int count, hipStream_t s);
 void launch_gs_multilevel(const GsArgs &a, const int *d_lev_start, int lev_begin, int lev_end, hipStream_t s);
 void drop_gs_schedule(const hypre_CSRMatrix *A);
 
+// fused elementwise passes of the Chebyshev smoother (cheby_kernels.hip)
+void launch_cheby_start(const double *f, const double *t, const double *ds, double c, bool last, double *u,
+                        double *orig, double *r, double *tmp, size_t n, hipStream_t s);
+void launch_cheby_step(const double *r, const double *v, const double *ds, const double *orig, double mult, bool last,
+                       double *u, double *tmp, size_t n, hipStream_t s);
+
 void launch_jacobi_update(const double *u_in, const double *r, const double *d, const int *marker, int mval,
                           double *u_out, size_t n, hipStream_t s);
 void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStream_t s);

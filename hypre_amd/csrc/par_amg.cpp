@@ -54,6 +54,8 @@ HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver)
    for (int k = 0; k < 4; k++) { d->num_grid_sweeps[k] = 1; }
    // SetCycleRelaxType(13,1), (14,2), (9,3) on a fresh array initialised to {3,3,3,9}
    d->grid_relax_type[0] = 3; d->grid_relax_type[1] = 13; d->grid_relax_type[2] = 14; d->grid_relax_type[3] = 9;
+   // par_amg.c:273-277
+   d->cheby_order = 2; d->cheby_variant = 0; d->cheby_scale = 1; d->cheby_eig_est = 10; d->cheby_fraction = 0.3;
    d->amd_private = new AmgPrivate();
    *solver = (HYPRE_Solver) d;
    return hypre_error_flag;
@@ -89,6 +91,18 @@ void amg_free_hierarchy(hypre_ParAMGData *d)
       for (int l = 0; l < L; l++) { hypre_SeqVectorDestroy(d->l1_norms[l]); }
       free(d->l1_norms); d->l1_norms = nullptr;
    }
+   if (d->cheby_ds)
+   {
+      for (int l = 0; l < L; l++) { hypre_SeqVectorDestroy(d->cheby_ds[l]); }
+      free(d->cheby_ds); d->cheby_ds = nullptr;
+   }
+   if (d->cheby_coefs)
+   {
+      for (int l = 0; l < L; l++) { hypre_Free(d->cheby_coefs[l], HYPRE_MEMORY_HOST); }
+      free(d->cheby_coefs); d->cheby_coefs = nullptr;
+   }
+   free(d->max_eig_est); d->max_eig_est = nullptr;
+   free(d->min_eig_est); d->min_eig_est = nullptr;
    hypre_ParVectorDestroy(d->Vtemp); d->Vtemp = nullptr;
    hypre_ParVectorDestroy(d->Ztemp); d->Ztemp = nullptr;
    hypre_ParVectorDestroy(d->Rtemp); d->Rtemp = nullptr;
@@ -224,6 +238,22 @@ HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver s, HYPRE_Int *v)
 { AMG_DATA(s, d); *v = d->num_iterations; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v)
 { AMG_DATA(s, d); *v = d->rel_resid_norm; return hypre_error_flag; }
+
+// par_amg.c:4583-4670
+HYPRE_Int HYPRE_BoomerAMGSetChebyOrder(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->cheby_order = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetChebyFraction(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); if (v <= 0.0 || v > 1.0) { hypre_error_in_arg(2); return hypre_error_flag; } d->cheby_fraction = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetChebyEigEst(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; } d->cheby_eig_est = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetChebyVariant(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->cheby_variant = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetChebyScale(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->cheby_scale = v; return hypre_error_flag; }
+HYPRE_Int hypre_amd_BoomerAMGGetChebyOrderScale(HYPRE_Solver s, HYPRE_Int *order, HYPRE_Int *scale)
+{ AMG_DATA(s, d); if (order) { *order = d->cheby_order; } if (scale) { *scale = d->cheby_scale; } return hypre_error_flag; }
+HYPRE_Real *hypre_amd_BoomerAMGGetChebyCoefs(HYPRE_Solver s, HYPRE_Int l)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && d->cheby_coefs && l >= 0 && l < d->num_levels) ? d->cheby_coefs[l] : nullptr; }
+hypre_Vector *hypre_amd_BoomerAMGGetChebyDS(HYPRE_Solver s, HYPRE_Int l)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && d->cheby_ds && l >= 0 && l < d->num_levels) ? d->cheby_ds[l] : nullptr; }
 
 HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver s, HYPRE_MemoryLocation loc)
 { AMG_DATA(s, d); d->memory_location = loc; return hypre_error_flag; }

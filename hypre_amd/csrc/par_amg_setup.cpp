@@ -1405,10 +1405,49 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       }
    }
 
-   // work vectors sized for the finest level
+   // Chebyshev smoothing (par_amg_setup.c:3273-3285, 3510-3550): spectrum estimate, polynomial
+   // coefficients and the scaling vector of every level that is smoothed with relax 16
+   const bool uses_cheby = d->grid_relax_type[0] == 16 || d->grid_relax_type[1] == 16 ||
+                           d->grid_relax_type[2] == 16 || d->grid_relax_type[3] == 16;
+   if (uses_cheby)
+   {
+      const HYPRE_Int *gt = d->grid_relax_type;
+      d->max_eig_est = (HYPRE_Real *) calloc((size_t) num_levels, sizeof(HYPRE_Real));
+      d->min_eig_est = (HYPRE_Real *) calloc((size_t) num_levels, sizeof(HYPRE_Real));
+      d->cheby_ds = (hypre_Vector **) calloc((size_t) num_levels, sizeof(void *));
+      d->cheby_coefs = (HYPRE_Real **) calloc((size_t) num_levels, sizeof(void *));
+      for (int j = 0; j < num_levels; j++)
+      {
+         const bool last = (j == num_levels - 1);
+         if (!(gt[1] == 16 || gt[2] == 16 || (gt[3] == 16 && last))) { continue; }
+         hypre_ParCSRMatrix *Al = hostA[(size_t) j];
+         HYPRE_Real max_eig = 0.0, min_eig = 0.0, *coefs = nullptr, *ds = nullptr;
+         if (d->cheby_eig_est) { hypre_ParCSRMaxEigEstimateCG(Al, d->cheby_scale, d->cheby_eig_est, &max_eig, &min_eig); }
+         else { hypre_ParCSRMaxEigEstimate(Al, d->cheby_scale, &max_eig, &min_eig); }
+         d->max_eig_est[j] = max_eig;
+         d->min_eig_est[j] = min_eig;
+         hypre_ParCSRRelax_Cheby_Setup(Al, max_eig, min_eig, d->cheby_fraction, d->cheby_order, d->cheby_scale,
+                                       d->cheby_variant, &coefs, &ds);
+         d->cheby_coefs[j] = coefs;
+         if (ds)
+         {
+            d->cheby_ds[j] = hypre_SeqVectorCreate(Al->diag->num_rows);
+            d->cheby_ds[j]->data = ds;
+            d->cheby_ds[j]->memory_location = HYPRE_MEMORY_HOST;
+            hypre_SeqVectorInitialize_v2(d->cheby_ds[j], HYPRE_MEMORY_HOST);
+         }
+      }
+   }
+
+   // work vectors sized for the finest level (par_amg_setup.c:846-880: Chebyshev needs two more)
    d->Vtemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
    d->Ztemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
    d->Rtemp = nullptr; d->Ptemp = nullptr;
+   if (uses_cheby)
+   {
+      d->Ptemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
+      d->Rtemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
+   }
 
    // algorithmic bytes of one V(1,1) cycle on this hierarchy: per level below the
    // coarsest 2 passes over A plus one over P and one over P^T
@@ -1446,6 +1485,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
             hypre_ParVectorMigrate(d->U_array[l], HYPRE_MEMORY_DEVICE);
          }
          if (d->l1_norms[l]) { hypre_SeqVectorMigrate(d->l1_norms[l], HYPRE_MEMORY_DEVICE); }
+         if (d->cheby_ds && d->cheby_ds[l]) { hypre_SeqVectorMigrate(d->cheby_ds[l], HYPRE_MEMORY_DEVICE); }
          if (d->CF_marker_array[l])
          {
             hypre_IntArray *a = d->CF_marker_array[l];
@@ -1457,6 +1497,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       }
       hypre_ParVectorMigrate(d->Vtemp, HYPRE_MEMORY_DEVICE);
       hypre_ParVectorMigrate(d->Ztemp, HYPRE_MEMORY_DEVICE);
+      if (d->Ptemp) { hypre_ParVectorMigrate(d->Ptemp, HYPRE_MEMORY_DEVICE); }
+      if (d->Rtemp) { hypre_ParVectorMigrate(d->Rtemp, HYPRE_MEMORY_DEVICE); }
       if (A_on_device) { hypre_ParCSRMatrixDestroy(hostA[0]); }
    }
    else

@@ -505,6 +505,32 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
                zeros[(size_t) level] = 0;
             }
          }
+         else if (relax_type == 16)
+         {
+            // Chebyshev polynomial smoothing (par_cycle.c:529-537), in place on the current buffer
+            if (!d->cheby_coefs || !d->cheby_coefs[level] || !d->Ptemp || !d->Rtemp)
+            {
+               hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCycle: relax 16 on a level the setup did not prepare for it");
+               err = 1;
+            }
+            else
+            {
+               hypre_Vector uv; hypre_ParVector up;
+               wrap(&uv, u.cur, n);
+               wrap_par(&up, &uv, A[level]->comm, A[level]->global_num_rows);
+               up.all_zeros = zeros[(size_t) level];
+               hypre_ParVectorSetLocalSize(d->Vtemp, n);
+               hypre_ParVectorSetLocalSize(d->Ztemp, n);
+               hypre_ParVectorSetLocalSize(d->Ptemp, n);
+               hypre_ParVectorSetLocalSize(d->Rtemp, n);
+               hypre_ParCSRRelax_Cheby_Solve(A[level], F_array[level],
+                                             d->cheby_ds && d->cheby_ds[level] ? d->cheby_ds[level]->data : nullptr,
+                                             d->cheby_coefs[level], d->cheby_order, d->cheby_scale, d->cheby_variant,
+                                             &up, d->Vtemp, d->Ztemp, d->Ptemp, d->Rtemp);
+               zeros[(size_t) level] = 0;
+               if (hypre_error_flag) { err = 1; }
+            }
+         }
          else
          {
             // in-place smoothers go through the public entry on a view of the current buffer

@@ -53,6 +53,11 @@ class IJOptions:
         self.level_w = None           # -wl  value level
         self.level_ow = None          # -owl value level
         self.mixed = False            # fp32 matrix values inside the cycle (extension)
+        self.cheby_order = 2          # -cheby_order    (test/ij.c:330-336 defaults)
+        self.cheby_eig_est = 10       # -cheby_eig_est
+        self.cheby_variant = 0        # -cheby_variant
+        self.cheby_scale = 1          # -cheby_scale
+        self.cheby_fraction = 0.3     # -cheby_fraction
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown ij option %r" % k)
@@ -191,6 +196,11 @@ def create_amg(opt, memory_location=DEVICE):
         L.HYPRE_BoomerAMGSetLevelOuterWt(s, opt.level_ow[0], opt.level_ow[1])
     if opt.mixed:
         L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    L.HYPRE_BoomerAMGSetChebyOrder(s, opt.cheby_order)
+    L.HYPRE_BoomerAMGSetChebyFraction(s, opt.cheby_fraction)
+    L.HYPRE_BoomerAMGSetChebyEigEst(s, opt.cheby_eig_est)
+    L.HYPRE_BoomerAMGSetChebyVariant(s, opt.cheby_variant)
+    L.HYPRE_BoomerAMGSetChebyScale(s, opt.cheby_scale)
     B.check()
     return s
 
@@ -209,6 +219,9 @@ _VALUE_FLAGS = {
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
     "-precon_cycles": ("precon_cycles", int, 1),
+    "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
+    "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
+    "-cheby_fraction": ("cheby_fraction", float, 1),
     "-n": ("n", int, 3), "-P": ("P", int, 3), "-c": ("c", float, 3), "-a": ("a", float, 3),
     # extensions of this driver (no reference counterpart)
     "-amd_threads": ("num_threads", int, 1),

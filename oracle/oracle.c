@@ -16,6 +16,7 @@
  *   parcsr_ls/par_relax.c:691-945 + par_relax.h:13-457   hybrid GS / SOR family (3,4,6,8,13,14,88,89)
  *   parcsr_ls/par_relax.c:1178-1254   Jacobi through SpMV (relax 7, 18)
  *   parcsr_ls/par_relax.c:1506-1588   two-stage Gauss-Seidel (relax 11, 12)
+ *   parcsr_ls/par_cheby.c:224-400     Chebyshev polynomial smoothing (relax 16)
  *   parcsr_ls/par_relax_interface.c:20-56  CF-ordered double pass
  *   parcsr_ls/ams.c:527-830           smoother diagonals ("l1 norms", options 1,4,5,6)
  *   utilities/gselim.h + parcsr_ls/par_gauss_elim.c:457-697   coarsest-level dense solve
@@ -614,6 +615,50 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
    return err;
 }
 
+/* par_cheby.c:224-400 (hypre_ParCSRRelax_Cheby_SolveHost): u += p(A)(f - A u), Horner form,
+ * optionally for D^-1/2 A D^-1/2.  coefs has order + 1 entries of which the first `order` are used. */
+int oracle_cheby_solve(const opar *A, const double *f, const double *ds, const double *coefs, int order,
+                       int scale, double *u)
+{
+   const long long n = A->row_starts[A->nranks];
+   if (order > 4) { order = 4; }
+   if (order < 1) { order = 1; }
+   const int cheby_order = order - 1;
+   double *r = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+   double *v = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+   double *orig = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+   double *tmp = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+   if (!scale)
+   {
+      for (long long i = 0; i < n; i++) { r[i] = f[i]; }
+      oracle_par_matvec(-1.0, A, u, 1.0, r, r);
+      for (long long i = 0; i < n; i++) { orig[i] = u[i]; u[i] = r[i] * coefs[cheby_order]; }
+      for (int i = cheby_order - 1; i >= 0; i--)
+      {
+         oracle_par_matvec(1.0, A, u, 0.0, v, v);
+         const double mult = coefs[i];
+         for (long long j = 0; j < n; j++) { u[j] = mult * r[j] + v[j]; }
+      }
+      for (long long i = 0; i < n; i++) { u[i] = orig[i] + u[i]; }
+   }
+   else
+   {
+      oracle_par_matvec(-1.0, A, u, 0.0, tmp, tmp);
+      for (long long j = 0; j < n; j++) { r[j] = ds[j] * (f[j] + tmp[j]); }
+      for (long long j = 0; j < n; j++) { orig[j] = u[j]; u[j] = r[j] * coefs[cheby_order]; }
+      for (int i = cheby_order - 1; i >= 0; i--)
+      {
+         for (long long j = 0; j < n; j++) { tmp[j] = ds[j] * u[j]; }
+         oracle_par_matvec(1.0, A, tmp, 0.0, v, v);
+         const double mult = coefs[i];
+         for (long long j = 0; j < n; j++) { u[j] = mult * r[j] + ds[j] * v[j]; }
+      }
+      for (long long j = 0; j < n; j++) { u[j] = orig[j] + ds[j] * u[j]; }
+   }
+   free(r); free(v); free(orig); free(tmp);
+   return 0;
+}
+
 /* par_relax_interface.c:20-56 */
 int oracle_relax_if(const opar *A, const double *f, const int *cf_marker, int relax_type, int relax_order,
                     int cycle_param, double w, double omega, const double *l1, double *u, double *vtemp,
@@ -743,6 +788,17 @@ int oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros)
              relax_type == 198 || relax_type == 199)
          {
             coarse_solve(A, F[level], U[level]);
+         }
+         else if (relax_type == 16)
+         {
+            /* par_cycle.c:529-537 */
+            if (!amg->cheby_coefs || !amg->cheby_coefs[level]) { err = -2; }
+            else
+            {
+               err = oracle_cheby_solve(A, F[level], amg->cheby_ds ? amg->cheby_ds[level] : NULL,
+                                        amg->cheby_coefs[level], amg->cheby_order, amg->cheby_scale, U[level]);
+               all_zeros[level] = 0;
+            }
          }
          else if (relax_type == 18)
          {

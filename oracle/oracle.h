@@ -42,6 +42,10 @@ typedef struct
    double   *omega;              /* [num_levels] */
    int       cycle_type, fcycle;
    int       num_threads;        /* OpenMP thread count the hybrid smoothers emulate */
+   /* Chebyshev smoothing, relax 16 (par_amg.h:208-217): coefficients and 1/sqrt(|a_ii|) per level, from setup */
+   int       cheby_order, cheby_scale;
+   double  **cheby_coefs;        /* [num_levels][order + 1] or NULL */
+   double  **cheby_ds;           /* [num_levels] global arrays or NULL */
 } oamg;
 
 /* OpenMP threads of the independent row loops (timed CPU baseline); results are
@@ -66,6 +70,8 @@ int    oracle_relax(const opar *A, const double *f, const int *cf_marker, int re
 int    oracle_relax_if(const opar *A, const double *f, const int *cf_marker, int relax_type, int relax_order,
                        int cycle_param, double w, double omega, const double *l1, double *u, double *vtemp,
                        int num_threads, int *all_zeros);
+int    oracle_cheby_solve(const opar *A, const double *f, const double *ds, const double *coefs, int order,
+                          int scale, double *u);
 int    oracle_gselim(double *A, double *x, int n);
 int    oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros);
 int    oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol, int min_iter, int max_iter,

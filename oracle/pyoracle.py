@@ -33,7 +33,9 @@ class OAMG(C.Structure):
                 ("U", C.POINTER(RealP)), ("vtemp", RealP), ("num_grid_sweeps", C.c_int * 4),
                 ("grid_relax_type", C.c_int * 4), ("grid_relax_points", C.POINTER(IntP)),
                 ("relax_order", C.c_int), ("user_relax_type", C.c_int), ("relax_weight", RealP),
-                ("omega", RealP), ("cycle_type", C.c_int), ("fcycle", C.c_int), ("num_threads", C.c_int)]
+                ("omega", RealP), ("cycle_type", C.c_int), ("fcycle", C.c_int), ("num_threads", C.c_int),
+                ("cheby_order", C.c_int), ("cheby_scale", C.c_int), ("cheby_coefs", C.POINTER(RealP)),
+                ("cheby_ds", C.POINTER(RealP))]
 
 
 def build():
@@ -169,7 +171,8 @@ class Amg:
 
     def __init__(self, A_levels, P_levels, cf_markers, l1_norms, num_grid_sweeps, grid_relax_type,
                  relax_order=0, relax_weight=None, omega=None, cycle_type=1, fcycle=0, num_threads=1,
-                 max_levels=25, user_relax_type=-1, grid_relax_points=None):
+                 max_levels=25, user_relax_type=-1, grid_relax_points=None, cheby=None):
+        """cheby: None or dict(order=, scale=, coefs=[per level array or None], ds=[per level array or None])."""
         L = len(A_levels)
         self.A_levels, self.P_levels = A_levels, P_levels
         self.cf = [None if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in cf_markers]
@@ -194,6 +197,13 @@ class Amg:
         self.c = OAMG(L, max_levels, self._A, self._P, self._cf, self._l1, self._F, self._U, _rp(self.vtemp),
                       (C.c_int * 4)(*num_grid_sweeps), (C.c_int * 4)(*grid_relax_type), self._grp, relax_order,
                       user_relax_type, _rp(self.rw), _rp(self.om), cycle_type, fcycle, num_threads)
+        if cheby is not None:
+            self.cheby_coefs = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in cheby["coefs"]]
+            self.cheby_ds = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in cheby["ds"]]
+            self._cc = (RealP * L)(*[_rp(v) if v is not None else None for v in self.cheby_coefs])
+            self._cd = (RealP * L)(*[_rp(v) if v is not None else None for v in self.cheby_ds])
+            self.c.cheby_order, self.c.cheby_scale = int(cheby["order"]), int(cheby["scale"])
+            self.c.cheby_coefs, self.c.cheby_ds = self._cc, self._cd
 
     def cycle(self, f, u, u_all_zeros=False):
         L = load()
@@ -295,6 +305,41 @@ def par_from_handles(handles, fp32_diag_values=False):
     return Par(blocks, rs, cs)
 
 
+def _export_cheby(s, nl):
+    """Chebyshev level data of one solver: (order, scale, [coefs or None], [ds or None])."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    L = B.load_library()
+    order, scale = C.c_int(0), C.c_int(0)
+    L.hypre_amd_BoomerAMGGetChebyOrderScale(s, C.byref(order), C.byref(scale))
+    k = min(max(order.value, 1), 4) + 1
+    coefs, ds = [], []
+    for l in range(nl):
+        cp = L.hypre_amd_BoomerAMGGetChebyCoefs(s, l)
+        coefs.append(np.array([cp[i] for i in range(k)]) if cp else None)
+        dp = L.hypre_amd_BoomerAMGGetChebyDS(s, l)
+        if dp:
+            v = C.cast(dp, C.POINTER(B.Vector)).contents
+            ds.append(B.fetch(v.data, v.size, np.float64, v.memory_location))
+        else:
+            ds.append(None)
+    if all(c is None for c in coefs):
+        return None
+    return dict(order=order.value, scale=scale.value, coefs=coefs, ds=ds)
+
+
+def _merge_cheby(parts):
+    """Per-rank Chebyshev exports -> one global description (coefficients are rank-invariant)."""
+    if not parts or any(p is None for p in parts):
+        return None
+    nl = len(parts[0]["coefs"])
+    ds = []
+    for l in range(nl):
+        v = [p["ds"][l] for p in parts]
+        ds.append(np.concatenate(v) if all(x is not None for x in v) else None)
+    return dict(order=parts[0]["order"], scale=parts[0]["scale"], coefs=parts[0]["coefs"], ds=ds)
+
+
 def amg_from_solvers(solvers, num_threads=1, mixed_precision=False):
     """Build the oracle's hierarchy from one product solver per (virtual) rank.
     mixed_precision: model the product's fp32-matrix-value mode (operators and interpolation of every
@@ -328,9 +373,10 @@ def amg_from_solvers(solvers, num_threads=1, mixed_precision=False):
     d = C.cast(s0, C.POINTER(AmgDataView)).contents
     rw = np.array([d.relax_weight[k] for k in range(nl)])
     om = np.array([d.omega[k] for k in range(nl)])
+    cheby = _merge_cheby([_export_cheby(s, nl) for s in solvers])
     return Amg(A_levels, P_levels, cfs, l1s, sweeps, types, relax_order=d.relax_order, relax_weight=rw, omega=om,
                cycle_type=d.cycle_type, fcycle=d.fcycle, num_threads=num_threads, max_levels=d.max_levels,
-               user_relax_type=d.user_relax_type)
+               user_relax_type=d.user_relax_type, cheby=cheby)
 
 
 def export_par(h):
@@ -391,6 +437,7 @@ def export_solver(s):
     out["om"] = np.array([d.omega[k] for k in range(nl)])
     out["relax_order"], out["cycle_type"], out["fcycle"] = d.relax_order, d.cycle_type, d.fcycle
     out["max_levels"], out["user_relax_type"] = d.max_levels, d.user_relax_type
+    out["cheby"] = _export_cheby(s, nl)
     return out
 
 
@@ -408,7 +455,8 @@ def amg_from_exports(parts, num_threads=1):
         l1s.append(np.concatenate(v) if all(x is not None for x in v) else None)
     return Amg(A_levels, P_levels, cfs, l1s, p0["sweeps"], p0["types"], relax_order=p0["relax_order"],
                relax_weight=p0["rw"], omega=p0["om"], cycle_type=p0["cycle_type"], fcycle=p0["fcycle"],
-               num_threads=num_threads, max_levels=p0["max_levels"], user_relax_type=p0["user_relax_type"])
+               num_threads=num_threads, max_levels=p0["max_levels"], user_relax_type=p0["user_relax_type"],
+               cheby=_merge_cheby([p.get("cheby") for p in parts]))
 
 
 class AmgDataView(C.Structure):

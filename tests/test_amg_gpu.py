@@ -114,6 +114,12 @@ def test_hybrid_gauss_seidel_sweep_is_the_sequential_sweep(gpu_lib, oracle, rela
     dict(relax_type=13, coarsen_type=10, num_threads=3),
     dict(relax_type=89, coarsen_type=8, problem="27pt"),
     dict(relax_type=-1, coarsen_type=10),
+    dict(relax_type=16, coarsen_type=8),
+    dict(relax_type=16, coarsen_type=8, cheby_order=4, cheby_fraction=0.2),
+    dict(relax_type=16, coarsen_type=10, cheby_order=3, cheby_variant=1),
+    dict(relax_type=16, coarsen_type=8, cheby_scale=0, problem="27pt"),
+    dict(relax_type=16, coarsen_type=8, cheby_eig_est=0, cheby_order=1, num_sweeps=2),
+    dict(relax_type=16, coarsen_type=8, cheby_eig_est=0, cheby_scale=0, cycle_type=2),
 ])
 def test_one_cycle_matches_oracle(gpu_lib, oracle, kw):
     from hypre_amd import binding as B

@@ -50,7 +50,7 @@ def _replay(case, timeout=600):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
-                                  "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1"])
+                                  "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
