@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libhypre_amd.so")
+# HYPRE_AMD_LIB: load another build of the same library (A/B timing of two builds in one GPU call)
+LIB_PATH = os.environ.get("HYPRE_AMD_LIB") or os.path.join(HERE, "lib", "libhypre_amd.so")
 
 HYPRE_MEMORY_HOST = 0
 HYPRE_MEMORY_DEVICE = 1

@@ -6,7 +6,9 @@
 Produces hypre_amd/lib/libhypre_amd.so (git-ignored; it travels to the GPU box
 with the repo snapshot).  hipcc cross-compiles without a GPU.
 """
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -44,11 +46,33 @@ def _compile(src, force):
             and os.path.getmtime(obj) > _newest_header()):
         return obj, False
     cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj]
+    kernels = src.endswith(".hip")
+    if kernels:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    err = r.stderr
+    if kernels:
+        # registers / scratch / occupancy of every kernel, kept beside the object for
+        # tests/test_abi.py::test_hot_kernels_keep_full_occupancy
+        rows, cur = [], None
+        for line in err.splitlines():
+            m = re.search(r"remark:\s+(Function Name|VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill): (\S+)", line)
+            if not m:
+                continue
+            if m.group(1) == "Function Name":
+                cur = {"name": m.group(2)}
+                rows.append(cur)
+            elif cur is not None:
+                cur[m.group(1).split(" [")[0]] = int(m.group(2))
+        with open(obj + ".resources.json", "w") as fh:
+            json.dump(rows, fh)
+        err = "\n".join(l for l in err.splitlines()
+                        if "kernel-resource-usage" not in l and not re.match(r"^\s*\d+ \| |^\s*\| *\^", l))
+        err = re.sub(r"\d+ warnings? generated when compiling for gfx950\.\n?", "", err + "\n") if "warning:" not in err else err
+    if err.strip():
+        sys.stderr.write(err)
     return obj, True
 
 
@@ -64,6 +88,14 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # one report for the whole library
+    report = []
+    for o in objs:
+        if os.path.exists(o + ".resources.json"):
+            with open(o + ".resources.json") as fh:
+                report += json.load(fh)
+    with open(os.path.join(LIBDIR, "kernel_resources.json"), "w") as fh:
+        json.dump(report, fh, indent=0)
     if verbose:
         print("built" if changed else "up to date", LIB)
     return LIB

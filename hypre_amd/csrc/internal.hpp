@@ -88,6 +88,7 @@ struct SpmvPlan
    const HYPRE_Complex *a = nullptr;
    int   num_rows = 0, num_cols = 0, nnz = 0;
    int   max_row_nnz = 0;
+   int   max_tile_rows = 0;          // most rows any tile holds (sizes the row-pointer / row-sum LDS)
    int   num_tiles = 0;
    int  *d_tile_row = nullptr;       // [num_tiles+1] first row of every tile
    int  *d_tile_k   = nullptr;       // [num_tiles+1] Ai[tile_row[b]]

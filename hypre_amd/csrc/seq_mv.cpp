@@ -96,6 +96,7 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
          HIP_CHECK(hipMalloc((void **) &p->d_tile_k, sizeof(int) * (size_t) (p->num_tiles + 1)));
          p->prod_elems = SPMV_TILE + ((p->max_row_nnz + 3) & ~3) + 8;
          launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
+         p->max_tile_rows = device_max_row_nnz(p->d_tile_row, p->num_tiles, s);     // max over tiles of tile_row[b+1] - tile_row[b]
       }
    }
    t[A] = p;

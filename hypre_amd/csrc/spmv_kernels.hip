@@ -105,14 +105,15 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double 
    }
 }
 
-constexpr int RP_CAP = 640;      // row pointers staged in LDS per tile
+constexpr int RP_CAP = 640;      // upper bound of the row pointers staged in LDS per tile (the plan asks for fewer
+                                 // when no tile of the matrix holds that many rows)
 
 // Per-row reduction of the products parked in LDS and the row epilogue.
 // prod[k - ka] holds entry k of the tile, rp[rr] the row pointer of row r0 + rr
-// (the first RP_CAP + 1 of them), ops the epilogue operands of row r0 + tid.
+// (the first rp_cap + 1 of them), ops the epilogue operands of row r0 + tid.
 template <int OP, bool HASFILL>
 __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows, int k0, int k1, int ka,
-                                            const double *prod, double *rowsum, const int *rp,
+                                            const double *prod, double *rowsum, const int *rp, int rp_cap,
                                             const RowOps &ops)
 {
    const int tid = threadIdx.x;
@@ -123,8 +124,8 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
       for (int rr = tid; rr < nrows; rr += SPMV_THREADS)
       {
          const int row = r0 + rr;
-         const int s = (rr     <= RP_CAP) ? rp[rr]     : p.Ai[row];
-         const int e = (rr + 1 <= RP_CAP) ? rp[rr + 1] : p.Ai[row + 1];
+         const int s = (rr     <= rp_cap) ? rp[rr]     : p.Ai[row];
+         const int e = (rr + 1 <= rp_cap) ? rp[rr + 1] : p.Ai[row + 1];
          double sum = 0.0;
          for (int k = s; k < e; k++)
          {
@@ -381,12 +382,12 @@ __device__ __forceinline__ RowOps tile_row_ops(const SpmvArgs &p, int r0, int nr
 template <int OP, bool F32, bool HASFILL, bool GT>
 __global__ __launch_bounds__(SPMV_THREADS)
 void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
-                       int num_tiles, int prod_elems, int rowsum_elems)
+                       int num_tiles, int prod_elems, int rowsum_elems, int rp_cap)
 {
    extern __shared__ __align__(16) unsigned char smem_raw[];
    double *prod   = reinterpret_cast<double *>(smem_raw);
    double *rowsum = prod + prod_elems;                                 // [rowsum_elems]
-   int    *rp     = reinterpret_cast<int *>(rowsum + rowsum_elems);    // [RP_CAP + 1]
+   int    *rp     = reinterpret_cast<int *>(rowsum + rowsum_elems);    // [rp_cap + 1]
 
    // Workgroups are dealt round-robin over the 8 XCDs (workgroup g -> XCD g % 8),
    // each XCD with its own L2.  xcd_map > 0: every XCD takes chunks of xcd_map
@@ -420,12 +421,19 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    const int k1 = tile_k[tile + 1];
    const int tid = threadIdx.x;
    const int nrows = r1 - r0;
-   for (int t = tid; t <= nrows && t <= RP_CAP; t += SPMV_THREADS) { rp[t] = p.Ai[r0 + t]; }
+   // fixed trip count (rp_cap <= RP_CAP): an open-ended loop here is unrolled into a register-hungry
+   // load pipeline that costs the kernel its eighth wave per SIMD
+#pragma unroll
+   for (int j = 0; j < (RP_CAP + SPMV_THREADS) / SPMV_THREADS; j++)
+   {
+      const int t = tid + j * SPMV_THREADS;
+      if (t <= nrows && t <= rp_cap) { rp[t] = p.Ai[r0 + t]; }
+   }
    const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
 
    if (GT) { stream_consume_gt<F32>(p, k0, k1, ka, S, prod); } else { stream_consume<F32>(p, k0, k1, ka, S, prod); }
    __syncthreads();
-   tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, ops);
+   tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
 }
 
 // ---------------------------------------------------------------------------
@@ -546,22 +554,28 @@ int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-static inline size_t tiled_lds_bytes(const SpmvPlan *plan, int &rowsum_elems)
+static inline size_t tiled_lds_bytes(const SpmvPlan *plan, int &rowsum_elems, int &rp_cap)
 {
-   // row sums pass through LDS only on the multi-lane paths (mean row length of a tile > 12)
-   rowsum_elems = plan->max_row_nnz > 12 ? SPMV_THREADS : 0;
-   return sizeof(double) * (size_t) (plan->prod_elems + rowsum_elems) + sizeof(int) * (size_t) (RP_CAP + 4);
+   // LDS beside the products is sized by the most rows any tile of this matrix holds: row pointers
+   // for all of them (up to RP_CAP), row sums only on the multi-lane paths (mean row length of a
+   // tile > 12, which also means fewer than SPMV_THREADS rows in that tile)
+   static int fit = -1;
+   if (fit < 0) { const char *e = getenv("HYPRE_AMD_SPMV_LDSFIT"); fit = e ? atoi(e) : 1; }
+   const int rows = (fit && plan->max_tile_rows > 0) ? plan->max_tile_rows : RP_CAP;
+   rp_cap = rows < RP_CAP ? rows : RP_CAP;
+   rowsum_elems = plan->max_row_nnz > 12 ? ((rows < SPMV_THREADS ? rows : SPMV_THREADS) + 1) & ~1 : 0;
+   return sizeof(double) * (size_t) (plan->prod_elems + rowsum_elems) + sizeof(int) * (size_t) (rp_cap + 4);
 }
 
 template <int OP, bool F32, bool FILL, bool GT>
 static void launch_tiled_gt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
-   int rowsum_elems;
-   const size_t lds = tiled_lds_bytes(plan, rowsum_elems);
+   int rowsum_elems, rp_cap;
+   const size_t lds = tiled_lds_bytes(plan, rowsum_elems, rp_cap);
    const int unit = a.xcd_map > 0 ? 8 * a.xcd_map : 8;
    const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
    hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL, GT>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
-                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, plan->prod_elems, rowsum_elems);
+                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap);
 }
 
 template <int OP, bool F32, bool FILL>

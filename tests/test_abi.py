@@ -86,3 +86,19 @@ def test_error_word_convention(lib):
     assert lib.HYPRE_GetErrorArg() == 2
     lib.HYPRE_ClearAllErrors()
     lib.HYPRE_BoomerAMGDestroy(s)
+
+
+def test_hot_kernels_keep_full_occupancy():
+    """Build-time guard: every tiled SpMV variant must fit 8 waves per SIMD (<= 64 VGPRs) with no scratch —
+    one innocent-looking loop once cost the family 35 registers and 11 % of its bandwidth."""
+    import json
+    path = os.path.join(ROOT, "hypre_amd", "lib", "kernel_resources.json")
+    if not os.path.exists(path):
+        pytest.skip("library not built by hypre_amd/build.py in this tree")
+    rows = json.load(open(path))
+    tiled = [r for r in rows if "spmv_tiled_kernel" in r["name"]]
+    assert len(tiled) >= 16
+    for r in tiled:
+        assert r["VGPRs"] <= 64 and r["Occupancy"] == 8, r
+    for r in rows:
+        assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, r
