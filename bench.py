@@ -186,6 +186,34 @@ def main():
     spmv_gbs = spmv_bytes / spmv_ms / 1e6
     cycle_bytes = L.hypre_amd_BoomerAMGCycleBytes(s)
     B.check()
+
+    # ---- the caller of the path: AMG-preconditioned CG to 1e-8 (BASELINE configs solve with it) ----
+    pcg_info = None
+    try:
+        pcg = C.c_void_p()
+        L.HYPRE_ParCSRPCGCreate(comm, C.byref(pcg))
+        L.HYPRE_PCGSetTol(pcg, 1.0e-8)
+        L.HYPRE_PCGSetMaxIter(pcg, 100)
+        L.HYPRE_PCGSetTwoNorm(pcg, 1)
+        L.HYPRE_PCGSetPrecond(pcg, C.cast(L.HYPRE_BoomerAMGSolve, C.c_void_p), None, s)
+        L.hypre_ParVectorSetZeros(u)
+        L.HYPRE_ParCSRPCGSetup(pcg, A, b, u)
+        fence()
+        t0 = time.perf_counter()
+        L.HYPRE_ParCSRPCGSolve(pcg, A, b, u)
+        fence()
+        pcg_s = time.perf_counter() - t0
+        its, rel = C.c_int(), C.c_double()
+        L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
+        L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
+        L.HYPRE_ParCSRPCGDestroy(pcg)
+        B.check()
+        pcg_info = {"iterations": its.value, "final_rel_resid": rel.value, "solve_ms": 1e3 * pcg_s,
+                    "ms_per_iteration": 1e3 * pcg_s / max(its.value, 1),
+                    "dof_per_s_per_iteration": nglob * max(its.value, 1) / pcg_s}
+    except Exception as exc:      # noqa: BLE001 - the headline metric above stands on its own
+        pcg_info = {"error": str(exc)}
+        L.HYPRE_ClearAllErrors()
     # HBM traffic per launch cannot be read from inside the process; it is taken from the committed
     # rocprofv3 --pmc pass over this same kernel and matrix (profiles/), when the workload matches.
     traffic = None
@@ -225,6 +253,8 @@ def main():
         cpu_s = cpu_cycles(cores, 10 * args.cpu_cycles) if cores > 1 else cpu_1
         O.set_num_threads(1)
         O.drop_transposes()
+        step()                                       # u = one cycle from zero again (the PCG run above reused u)
+        fence()
         ug = B.parvec_to_numpy(u)
         parity = float(np.max(np.abs(ug - ur)) / np.max(np.abs(ur)))
         cpu = {"value": nglob / cpu_s, "unit": "DOF/s", "cores": cores, "kind": "port",
@@ -258,6 +288,7 @@ def main():
                          "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},
             "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
                        "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS},
+            "pcg": pcg_info,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
