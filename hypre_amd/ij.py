@@ -261,6 +261,17 @@ def parse_cli(argv):
             raise SystemExit("ij: option %s is outside the scope of this driver" % flag)
     if opt.solver not in (0, 1):
         raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG)" % opt.solver)
+    if opt.interp_type not in (6, 3):
+        raise SystemExit("ij: -interptype %d is outside the scope of this driver (6 ext+i, 3 direct)" % opt.interp_type)
+    smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 16, 18, 88, 89)
+    for name in ("relax_type", "relax_down", "relax_up"):
+        if getattr(opt, name) not in smoothers:
+            raise SystemExit("ij: smoother %d is outside the scope of this driver" % getattr(opt, name))
+    if opt.relax_coarse not in smoothers + (9, 19, 98, 99):
+        raise SystemExit("ij: coarse solver %d is outside the scope of this driver" % opt.relax_coarse)
+    weights = [opt.relax_wt, opt.outer_wt] + [w[0] for w in (opt.level_w, opt.level_ow) if w is not None]
+    if any(w < 0 for w in weights):
+        raise SystemExit("ij: negative (automatically estimated) relaxation weights are outside the scope of this driver")
     return opt
 
 

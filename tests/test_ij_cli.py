@@ -29,7 +29,8 @@ def test_reference_job_line_parses_to_the_golden_options(name):
 
 def test_out_of_scope_flags_are_refused():
     from hypre_amd import ij
-    for bad in (["-agg_nl", "1"], ["-solver", "3"], ["-cljp"], ["-smtype", "6"]):
+    for bad in (["-agg_nl", "1"], ["-solver", "3"], ["-cljp"], ["-smtype", "6"], ["-interptype", "7"], ["-rlx", "15"],
+                ["-w", "-10"], ["-owl", "-10", "0"], ["-rlx_coarse", "29"]):
         with pytest.raises(SystemExit):
             ij.parse_cli(bad)
 
@@ -50,7 +51,8 @@ def _replay(case, timeout=600):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
-                                  "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24"])
+                                  "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24",
+                                  "coarsening.out.4", "interp.out.0", "matrix.out.0"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
