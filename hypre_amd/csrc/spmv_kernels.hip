@@ -4,18 +4,22 @@
 // sweep, and the two-stage Gauss-Seidel inner step (row epilogues), so a
 // smoother sweep is a single pass over the matrix.
 //
-// Tiled ("stream") kernel, one 256-thread workgroup per tile of ~2048 stored
-// entries (rows are binned into tiles by the position of their first entry):
+// Tiled ("stream") kernel, one 256-thread workgroup per tile of 2048 stored
+// entries (rows are binned into tiles by the position of their first entry),
+// eight workgroups resident per CU:
+//   phase 1  (col, val) streamed with unconditional 16-byte loads (2 x 4 entries
+//            per lane in flight), issued before the tile's bounds are known;
 //   phase 0  row pointers of the tile -> LDS, epilogue operands (b, d, x of the
-//            row each lane will finish) -> registers; issued together with the
-//            matrix stream so their latency hides under it;
-//   phase 1  (col, val) streamed with 16-byte loads (2 x 4 entries per lane in
-//            flight), x gathered, products parked in LDS;
+//            row each lane will finish) -> registers, while the stream is in flight;
+//   phase 1' every wave transposes its column indices through its own slice of
+//            LDS so that one gather instruction covers 64 consecutive entries
+//            (few x cache lines), parks the gathered x in LDS in entry order and
+//            reads back the four values it owns; products stay in LDS;
 //   phase 2  per-row reduction from LDS with 1, 8 or 32 lanes per row (chosen
 //            per tile from its mean row length), row sums of the multi-lane
 //            paths go through LDS so that the epilogue is one coalesced pass.
-// Tiles are handed to workgroups so that each XCD works on one contiguous
-// eighth of the matrix: neighbouring tiles share their x window in that XCD's L2.
+// Tiles go to workgroups in dispatch order (XCD-aware placements were measured
+// and do not pay: see spmv_default_flags).
 //
 // Replaces (behaviourally) seq_mv/csr_spmv_device.c:35-260 of the reference,
 // which uses K lanes per row chosen from the matrix-wide average row length,
