@@ -76,9 +76,16 @@ double *reduce_scratch(size_t n);        // >= n doubles of device scratch
 // SpMV plan: rows are binned into fixed-nnz tiles ("row blocks").  Tile b owns
 // the rows whose first stored entry lies in [b*TILE, (b+1)*TILE).
 // ---------------------------------------------------------------------------
-constexpr int SPMV_TILE    = 2048;   // nnz per tile
+#ifndef HYPRE_AMD_SPMV_TILE_NNZ          // experiment hooks: -DHYPRE_AMD_SPMV_TILE_NNZ=.. -DHYPRE_AMD_SPMV_WG=..
+#define HYPRE_AMD_SPMV_TILE_NNZ 2048
+#endif
+#ifndef HYPRE_AMD_SPMV_WG
+#define HYPRE_AMD_SPMV_WG 256
+#endif
+constexpr int SPMV_TILE    = HYPRE_AMD_SPMV_TILE_NNZ;   // nnz per tile (8 per lane)
 constexpr int SPMV_MAXROW  = 1024;   // longest row the tiled path accepts
-constexpr int SPMV_THREADS = 256;
+constexpr int SPMV_THREADS = HYPRE_AMD_SPMV_WG;
+static_assert(SPMV_TILE == 8 * SPMV_THREADS, "a lane streams two quads of the tile");
 
 struct SpmvPlan
 {
@@ -156,6 +163,11 @@ void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipSt
 void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s);
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s);
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
+// fused PCG vector updates: x += a p, r += na s, *d_out = <r, r> of the new r; p = beta p + s
+void launch_pcg_update(double a, double na, const double *p, const double *s, double *x, double *r, size_t n,
+                       double *d_out, hipStream_t stream);
+void launch_pcg_direction(double beta, const double *s, double *p, size_t n, hipStream_t stream);
+double global_sum(MPI_Comm comm, double v);     // scalar all-reduce over a communicator (identity on one rank)
 void launch_scale_copy(double b, const double *x, double *y, size_t n, hipStream_t s);   // y = b*x
 
 }  // namespace hamd

@@ -179,6 +179,53 @@ void dot_final_kernel(const double *__restrict__ partial, int m, double *__restr
    if (threadIdx.x == 0) { out[0] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]); }
 }
 
+// PCG, fused (krylov/pcg.c:716-760 does these as separate vector calls): x += a p, r += na s and the
+// per-workgroup partials of <r, r> of the updated r, accumulated exactly like dot_partial_kernel does
+// (same grid, same per-lane order), so the fused norm has the bits of a separate dot.
+__global__ __launch_bounds__(256)
+void pcg_update_kernel(double a, double na, const double *__restrict__ p, const double *__restrict__ s,
+                       double *__restrict__ x, double *__restrict__ r, size_t n, double *__restrict__ partial)
+{
+   __shared__ double wsum[4];
+   double acc = 0.0;
+   VEC_LOOP_BEGIN
+      const double2 pv = reinterpret_cast<const double2 *>(p)[i];
+      const double2 sv = reinterpret_cast<const double2 *>(s)[i];
+      double2 xv = reinterpret_cast<double2 *>(x)[i];
+      double2 rv = reinterpret_cast<double2 *>(r)[i];
+      xv.x += a * pv.x; xv.y += a * pv.y;
+      rv.x += na * sv.x; rv.y += na * sv.y;
+      reinterpret_cast<double2 *>(x)[i] = xv;
+      reinterpret_cast<double2 *>(r)[i] = rv;
+      acc += rv.x * rv.x + rv.y * rv.y;
+   VEC_LOOP_END
+   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+   {
+      x[n - 1] += a * p[n - 1];
+      const double rl = r[n - 1] + na * s[n - 1];
+      r[n - 1] = rl;
+      acc += rl * rl;
+   }
+   acc = wave_sum(acc);
+   if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = acc; }
+   __syncthreads();
+   if (threadIdx.x == 0) { partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]); }
+}
+
+// p = beta p + s, the product rounded before the sum as in Scale followed by Axpy(1, s, p)
+__global__ void pcg_direction_kernel(double beta, const double *__restrict__ s, double *__restrict__ p, size_t n)
+{
+#pragma clang fp contract(off)
+   VEC_LOOP_BEGIN
+      const double2 sv = reinterpret_cast<const double2 *>(s)[i];
+      double2 t = reinterpret_cast<double2 *>(p)[i];
+      t.x *= beta; t.y *= beta;
+      t.x += sv.x; t.y += sv.y;
+      reinterpret_cast<double2 *>(p)[i] = t;
+   VEC_LOOP_END
+   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double t = p[n - 1] * beta; p[n - 1] = t + s[n - 1]; }
+}
+
 __global__ void gather_kernel(const double *__restrict__ x, const int *__restrict__ idx,
                               double *__restrict__ out, size_t n)
 {
@@ -276,6 +323,17 @@ void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipSt
    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, s, x, y, n, partial);
    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, d_out);
 }
+void launch_pcg_update(double a, double na, const double *p, const double *sv, double *x, double *r, size_t n,
+                       double *d_out, hipStream_t s)
+{
+   int nb = vec_grid(n);
+   if (nb > DOT_BLOCKS) { nb = DOT_BLOCKS; }
+   double *partial = reduce_scratch(DOT_BLOCKS + 16) + 16;
+   hipLaunchKernelGGL(pcg_update_kernel, dim3(nb), dim3(256), 0, s, a, na, p, sv, x, r, n, partial);
+   hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, d_out);
+}
+void launch_pcg_direction(double beta, const double *sv, double *p, size_t n, hipStream_t s)
+{ if (n) hipLaunchKernelGGL(pcg_direction_kernel, dim3(vec_grid(n)), dim3(256), 0, s, beta, sv, p, n); }
 void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, out, n); }
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s)

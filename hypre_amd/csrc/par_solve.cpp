@@ -809,16 +809,27 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       alpha = gamma / sdotp;
       if (alpha <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero alpha value in PCG"); if (i == 1) { i_prod = i_prod_0; } break; }
       gamma_old = gamma;
-      hypre_ParVectorAxpy(alpha, p, x);
-      hypre_ParVectorAxpy(-alpha, s, r);
+      // x += alpha p ; r -= alpha s ; <r,r> of the new residual: one pass (pcg.c:716-760 makes
+      // three vector calls of it; element values and the norm's summation order are unchanged)
+      double *d_rr = reduce_scratch(2048) + 1;
+      launch_pcg_update(alpha, -alpha, p->local_vector->data, s->local_vector->data, x->local_vector->data,
+                        r->local_vector->data, (size_t) r->local_vector->size, d_rr, stream());
+      x->all_zeros = 0; r->all_zeros = 0;
       precond(r, s);
       gamma = hypre_ParVectorInnerProd(r, s);
-      i_prod = d->two_norm ? hypre_ParVectorInnerProd(r, r) : gamma;
+      if (d->two_norm)
+      {
+         double *h = handle().h_reduce;
+         HIP_CHECK(hipMemcpyAsync(h + 1, d_rr, sizeof(double), hipMemcpyDeviceToHost, stream()));
+         HIP_CHECK(hipStreamSynchronize(stream()));
+         i_prod = global_sum(r->comm, h[1]);
+      }
+      else { i_prod = gamma; }
       if (i_prod / bi_prod < eps) { d->converged = 1; break; }
       if (gamma <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero gamma value in PCG"); break; }
       beta = gamma / gamma_old;
-      hypre_ParVectorScale(beta, p);
-      hypre_ParVectorAxpy(1.0, s, p);
+      // p = beta p + s in one pass (Scale then Axpy in the reference)
+      launch_pcg_direction(beta, s->local_vector->data, p->local_vector->data, (size_t) p->local_vector->size, stream());
    }
    if (i >= d->max_iter && (i_prod / bi_prod) >= eps && eps > 0)
    {

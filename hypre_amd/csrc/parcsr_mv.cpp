@@ -20,6 +20,15 @@
 
 using namespace hamd;
 
+namespace hamd {
+double global_sum(MPI_Comm comm, double v)
+{
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   if (o && o->size > 1 && o->allreduce_sum) { o->allreduce_sum(o->ctx, &v, 1, 0, nullptr); }
+   return v;
+}
+}  // namespace hamd
+
 namespace {
 
 // events used to order the two streams; created once
@@ -151,12 +160,6 @@ hypre_ParCSRMatrix *hypre_ParCSRMatrixClone_v2(hypre_ParCSRMatrix *A, HYPRE_Int 
    return B;
 }
 
-static double global_sum(MPI_Comm comm, double v)
-{
-   const hypre_amd_CommOps *o = comm_ops(comm);
-   if (o && o->size > 1 && o->allreduce_sum) { o->allreduce_sum(o->ctx, &v, 1, 0, nullptr); }
-   return v;
-}
 
 HYPRE_Int hypre_ParCSRMatrixSetDNumNonzeros(hypre_ParCSRMatrix *m)
 {
