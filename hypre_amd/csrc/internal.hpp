@@ -103,10 +103,14 @@ struct SpmvPlan
    bool  tiled = false;              // false -> wave-per-row kernel (long rows)
    // cached explicit transpose (built on first MatvecT)
    hypre_CSRMatrix *AT = nullptr;
+   // cached strictly lower triangular part (built on the first two-stage Gauss-Seidel sweep: its inner
+   // steps stream half the entries instead of masking the upper half of the full matrix)
+   hypre_CSRMatrix *Lstrict = nullptr;
    // fp32 copy of the values for the mixed-precision path (lazily built)
    float *a32 = nullptr;
 };
 SpmvPlan *get_plan(hypre_CSRMatrix *A);
+hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A);   // device CSR of {a_ij : j < i}, cached in A's plan
 void      drop_plan(hypre_CSRMatrix *A);
 
 // epilogue selector of the tiled SpMV family
@@ -163,6 +167,9 @@ void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipSt
 void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s);
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s);
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
+void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s);
+void launch_fill_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, const double *Aa, const HYPRE_Int *Li, HYPRE_Int *Lj,
+                       double *La, int n, hipStream_t s);
 // fused PCG vector updates: x += a p, r += na s, *d_out = <r, r> of the new r; p = beta p + s
 void launch_pcg_update(double a, double na, const double *p, const double *s, double *x, double *r, size_t n,
                        double *d_out, hipStream_t stream);

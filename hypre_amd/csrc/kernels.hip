@@ -226,6 +226,24 @@ __global__ void pcg_direction_kernel(double beta, const double *__restrict__ s, 
    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { const double t = p[n - 1] * beta; p[n - 1] = t + s[n - 1]; }
 }
 
+// strictly lower triangular part of a CSR matrix, entries kept in their stored order
+__global__ void count_lower_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, int n, int *__restrict__ cnt)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) { return; }
+   int c = 0;
+   for (int k = Ai[i]; k < Ai[i + 1]; k++) { if (Aj[k] < i) { c++; } }
+   cnt[i] = c;
+}
+__global__ void fill_lower_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa,
+                                  const int *__restrict__ Li, int *__restrict__ Lj, double *__restrict__ La, int n)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) { return; }
+   int o = Li[i];
+   for (int k = Ai[i]; k < Ai[i + 1]; k++) { if (Aj[k] < i) { Lj[o] = Aj[k]; La[o] = Aa[k]; o++; } }
+}
+
 __global__ void gather_kernel(const double *__restrict__ x, const int *__restrict__ idx,
                               double *__restrict__ out, size_t n)
 {
@@ -334,6 +352,11 @@ void launch_pcg_update(double a, double na, const double *p, const double *sv, d
 }
 void launch_pcg_direction(double beta, const double *sv, double *p, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(pcg_direction_kernel, dim3(vec_grid(n)), dim3(256), 0, s, beta, sv, p, n); }
+void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s)
+{ if (n > 0) hipLaunchKernelGGL(count_lower_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aj, n, cnt); }
+void launch_fill_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, const double *Aa, const HYPRE_Int *Li, HYPRE_Int *Lj,
+                       double *La, int n, hipStream_t s)
+{ if (n > 0) hipLaunchKernelGGL(fill_lower_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aj, Aa, Li, Lj, La, n); }
 void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, out, n); }
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s)

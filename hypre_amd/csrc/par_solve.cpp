@@ -167,14 +167,17 @@ HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, h
    double *zin = zd, *zout = rd;
    if (n > 0 && diag->num_nonzeros > 0)
    {
-      SpmvPlan *plan = get_plan(diag);
-      for (int k = 0; k < num_inner_iters; k++)
+      // the inner steps run on a cached copy of the strictly lower triangle (half the bytes of
+      // masking the full matrix, which is what the reference's fill-mode SpMV does)
+      hypre_CSRMatrix *Lm = strict_lower_of(diag);
+      SpmvPlan *plan = get_plan(Lm);
+      for (int k = 0; k < num_inner_iters && Lm->num_nonzeros > 0; k++)
       {
          // 2+3) z_out = (L_strict z_in)./D ; u += mult * z_out   — one fused pass
          SpmvArgs a{};
-         a.Ai = diag->i; a.Aj = diag->j; a.Aa = diag->data; a.Aa32 = nullptr;
+         a.Ai = Lm->i; a.Aj = Lm->j; a.Aa = Lm->data; a.Aa32 = nullptr;
          a.x = zin; a.b = nullptr; a.y = zout; a.aux = ud; a.d = A_diag_diag; a.marker = nullptr;
-         a.alpha = mult; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_STRICT_LOWER;
+         a.alpha = mult; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_WHOLE;
          spmv_default_flags(a);
          launch_spmv(plan, a, OP_TSGS, s);
          std::swap(zin, zout);

@@ -48,6 +48,7 @@ static void free_plan(SpmvPlan *p)
    if (p->d_tile_k) { HIP_CHECK(hipFree(p->d_tile_k)); }
    if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
+   if (p->Lstrict) { hypre_CSRMatrixDestroy(p->Lstrict); }
    delete p;
 }
 
@@ -101,6 +102,29 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
    }
    t[A] = p;
    return p;
+}
+
+// Strictly lower triangular part of a device matrix as its own CSR matrix (entries in stored
+// order), cached in the plan: counted and filled by one lane per row, row offsets scanned on the host.
+hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A)
+{
+   SpmvPlan *plan = get_plan(A);
+   if (plan->Lstrict) { return plan->Lstrict; }
+   const int n = A->num_rows;
+   hipStream_t s = stream();
+   std::vector<int> cnt((size_t) std::max(n, 1)), off((size_t) n + 1, 0);
+   int *d_cnt = hypre_TAlloc(int, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+   launch_count_lower(A->i, A->j, n, d_cnt, s);
+   HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t) n, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   for (int i = 0; i < n; i++) { off[(size_t) i + 1] = off[(size_t) i] + cnt[(size_t) i]; }
+   hypre_Free(d_cnt, HYPRE_MEMORY_DEVICE);
+   hypre_CSRMatrix *L = hypre_CSRMatrixCreate(n, A->num_cols, off[(size_t) n]);
+   hypre_CSRMatrixInitialize_v2(L, 0, HYPRE_MEMORY_DEVICE);
+   hypre_TMemcpy(L->i, off.data(), HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   if (off[(size_t) n] > 0) { launch_fill_lower(A->i, A->j, A->data, L->i, L->j, L->data, n, s); }
+   plan->Lstrict = L;
+   return L;
 }
 
 }  // namespace hamd
