@@ -405,7 +405,9 @@ HYPRE_Int hypre_ParCSRRelax_Cheby_Solve(hypre_ParCSRMatrix *A, hypre_ParVector *
 
    // tmp (or r) = -A u ; then r = ds.*(f + tmp), orig = u, u = c_k r, tmp = ds.*u
    double *first = scale ? td : rd;
-   dev_par_matvec(-1.0, A, ud, 0.0, first, first);
+   // u known to be zero (all_zeros flag): -A u = 0 without touching the matrix, same bits as the product
+   if (u->all_zeros) { launch_set(first, 0.0, (size_t) n, s); }
+   else { dev_par_matvec(-1.0, A, ud, 0.0, first, first); }
    launch_cheby_start(fd, first, ds, coefs[cheby_order], cheby_order == 0, ud, od, rd, td, (size_t) n, s);
    for (int i = cheby_order - 1; i >= 0; i--)
    {

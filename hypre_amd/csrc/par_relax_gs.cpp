@@ -202,13 +202,15 @@ extern "C" HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMat
    hypre_MPI_Comm_size(A->comm, &nprocs);
 
    // ghost values of the incoming iterate (par_relax.c:735-754), overlapped with the schedule lookup
-   hypre_ParCSRCommHandle *ch = (nprocs > 1) ? dev_halo_begin(A, ud) : nullptr;
+   // an iterate known to be zero has zero ghosts: no exchange, no ghost terms (same bits: res - a*0 = res)
+   const bool zero_guess = u->all_zeros != 0;
+   hypre_ParCSRCommHandle *ch = (nprocs > 1 && !zero_guess) ? dev_halo_begin(A, ud) : nullptr;
    GsSchedule *g = get_schedule(diag, std::max(1, std::min(handle().gs_threads, n)));
    dev_halo_end(ch);
 
    GsArgs a{};
    a.Di = diag->i; a.Dj = diag->j; a.Da = diag->data;
-   const bool has_offd = nprocs > 1 && offd && offd->num_cols > 0 && offd->num_nonzeros > 0;
+   const bool has_offd = nprocs > 1 && !zero_guess && offd && offd->num_cols > 0 && offd->num_nonzeros > 0;
    a.Oi = has_offd ? offd->i : nullptr; a.Oj = has_offd ? offd->j : nullptr; a.Oa = has_offd ? offd->data : nullptr;
    a.vext = has_offd ? A->comm_pkg->tmp_data : nullptr;
    a.f = f->local_vector->data;
@@ -234,6 +236,7 @@ extern "C" HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMat
       a.dir = dirn;
       run_direction(g->dir[dirn > 0 ? 0 : 1], a, s);
    }
+   u->all_zeros = 0;               // the sweep has written u (relax 89 calls this twice: the second sweep must fetch ghosts)
    handle().sync_compute = saved;
    maybe_sync();
    return hypre_error_flag;

@@ -161,7 +161,11 @@ HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, h
    const int saved = handle().sync_compute;
    handle().sync_compute = 0;
    // 0) r = w (f - A u)     1) z = r./D ; u += z
-   dev_par_matvec(-relax_weight, A, ud, relax_weight, f->local_vector->data, rd);
+   // u known to be zero (par_vector.h all_zeros; set by SetZeros and by the cycle on the way down):
+   // A u = 0 exactly, so r = w f without touching the matrix.  The reference uses the flag this way
+   // only in its Jacobi sweep (par_relax.c:1221-1228); the result here is the same bits either way.
+   if (u->all_zeros) { launch_scale_copy(relax_weight, f->local_vector->data, rd, (size_t) n, s); }
+   else { dev_par_matvec(-relax_weight, A, ud, relax_weight, f->local_vector->data, rd); }
    launch_diagscale2(A_diag_diag, rd, 1.0, zd, ud, 1, (size_t) n, s);
    double mult = -1.0;
    double *zin = zd, *zout = rd;
@@ -184,6 +188,7 @@ HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, h
          mult *= -1.0;
       }
    }
+   u->all_zeros = 0;
    handle().sync_compute = saved;
    maybe_sync();
    return hypre_error_flag;
