@@ -102,6 +102,81 @@ inline void chunk(int n, int T, int t, int *b, int *e)
    *e = (int) (*b + per + (t < rest ? 1 : 0));
 }
 
+// Sparse accumulator index for one matrix row at a time: integer key -> 64-bit value, emptied
+// after every row by revisiting only the slots that were used.  It stands in for the reference's
+// per-thread marker arrays of full vector length (par_rap.c P_marker / A_marker, par_lr_interp.c
+// P_marker): those cost num_threads x n words to allocate and fill, which dominates the setup on a
+// many-core host; the insertion ORDER of a row's entries, which fixes the layout of RAP and P, is
+// unchanged.
+struct RowMap
+{
+   std::vector<HYPRE_Int> key;
+   std::vector<long long> val;
+   std::vector<HYPRE_Int> used;
+   HYPRE_Int              mask;
+   explicit RowMap(HYPRE_Int cap = 1024) : key((size_t) cap, -1), val((size_t) cap, 0), mask(cap - 1) { used.reserve((size_t) cap / 2); }
+   static inline HYPRE_Int hash(HYPRE_Int k) { return (HYPRE_Int) (((unsigned) k * 2654435761u) >> 7); }
+   // value stored for k, or `absent`
+   inline long long get(HYPRE_Int k, long long absent) const
+   {
+      HYPRE_Int h = hash(k) & mask;
+      while (key[(size_t) h] != -1)
+      {
+         if (key[(size_t) h] == k) { return val[(size_t) h]; }
+         h = (h + 1) & mask;
+      }
+      return absent;
+   }
+   // set (insert or overwrite)
+   inline void set(HYPRE_Int k, long long v)
+   {
+      HYPRE_Int h = hash(k) & mask;
+      while (key[(size_t) h] != -1)
+      {
+         if (key[(size_t) h] == k) { val[(size_t) h] = v; return; }
+         h = (h + 1) & mask;
+      }
+      key[(size_t) h] = k; val[(size_t) h] = v; used.push_back(h);
+      if (2 * used.size() > key.size()) { grow(); }
+   }
+   void grow()
+   {
+      std::vector<HYPRE_Int> ok; std::vector<long long> ov;
+      ok.reserve(used.size()); ov.reserve(used.size());
+      for (HYPRE_Int h : used) { ok.push_back(key[(size_t) h]); ov.push_back(val[(size_t) h]); }
+      const size_t cap = key.size() * 2;
+      key.assign(cap, -1); val.assign(cap, 0); mask = (HYPRE_Int) cap - 1; used.clear();
+      for (size_t q = 0; q < ok.size(); q++)
+      {
+         HYPRE_Int h = hash(ok[q]) & mask;
+         while (key[(size_t) h] != -1) { h = (h + 1) & mask; }
+         key[(size_t) h] = ok[q]; val[(size_t) h] = ov[q]; used.push_back(h);
+      }
+   }
+   inline void clear()
+   {
+      for (HYPRE_Int h : used) { key[(size_t) h] = -1; }
+      used.clear();
+   }
+};
+
+// Marker for the interpolation rows of one thread.  When everything a thread's rows can reach lies
+// in a narrow index window (banded orderings: grids), a plain array over that window is used and
+// keeps the reference's semantics of stale entries (older positions / tags never match); otherwise
+// the per-row hash map, emptied after every row (absent reads as -1, which never matches either).
+struct RowMarker
+{
+   bool                   windowed = false;
+   HYPRE_Int              lo = 0;
+   std::vector<long long> w;
+   RowMap                 h;
+   RowMarker() : h(1024) {}
+   void use_window(HYPRE_Int lo_, HYPRE_Int hi_) { windowed = true; lo = lo_; w.assign((size_t) (hi_ - lo_ + 1), -1); }
+   inline long long get(HYPRE_Int k) const { return windowed ? w[(size_t) (k - lo)] : h.get(k, -1); }
+   inline void set(HYPRE_Int k, long long v) { if (windowed) { w[(size_t) (k - lo)] = v; } else { h.set(k, v); } }
+   inline void end_row() { if (!windowed) { h.clear(); } }
+};
+
 }  // namespace
 
 extern "C" {
@@ -705,7 +780,16 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       std::vector<HYPRE_Real> &pa = ta[(size_t) t];
       // marker holds, per fine point, either the position of its column in
       // the current row (>= row begin), or the strong-F tag of the current row
-      std::vector<long long> marker((size_t) std::max(n, 1), -1);
+      RowMarker marker;
+      if (re > rb)
+      {
+         // index window of everything rows [rb, re) can touch: two hops through A's pattern
+         HYPRE_Int lo1 = rb, hi1 = re - 1;
+         for (HYPRE_Int k = Ai[rb]; k < Ai[re]; k++) { lo1 = std::min(lo1, Aj[k]); hi1 = std::max(hi1, Aj[k]); }
+         HYPRE_Int lo2 = lo1, hi2 = hi1;
+         for (HYPRE_Int k = Ai[lo1]; k < Ai[hi1 + 1]; k++) { lo2 = std::min(lo2, Aj[k]); hi2 = std::max(hi2, Aj[k]); }
+         if ((long long) hi2 - lo2 + 1 <= 16LL * (re - rb) + 65536) { marker.use_window(lo2, hi2); }
+      }
       long long strong_f = -2;
       for (HYPRE_Int i = rb; i < re; i++)
       {
@@ -722,17 +806,17 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
                const HYPRE_Int i1 = Sj[jj];
                if (CF_marker[i1] >= 0)
                {
-                  if (marker[(size_t) i1] < begin) { marker[(size_t) i1] = (long long) pj.size(); pj.push_back(f2c[(size_t) i1]); pa.push_back(0.0); }
+                  if (marker.get(i1) < begin) { marker.set(i1, (long long) pj.size()); pj.push_back(f2c[(size_t) i1]); pa.push_back(0.0); }
                }
                else if (CF_marker[i1] != -3)
                {
-                  marker[(size_t) i1] = strong_f;
+                  marker.set(i1, strong_f);
                   for (HYPRE_Int kk = Si[i1]; kk < Si[i1 + 1]; kk++)
                   {
                      const HYPRE_Int k1 = Sj[kk];
-                     if (CF_marker[k1] >= 0 && marker[(size_t) k1] < begin)
+                     if (CF_marker[k1] >= 0 && marker.get(k1) < begin)
                      {
-                        marker[(size_t) k1] = (long long) pj.size(); pj.push_back(f2c[(size_t) k1]); pa.push_back(0.0);
+                        marker.set(k1, (long long) pj.size()); pj.push_back(f2c[(size_t) k1]); pa.push_back(0.0);
                      }
                   }
                }
@@ -741,15 +825,15 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
             for (HYPRE_Int jj = Ai[i] + 1; jj < Ai[i + 1]; jj++)
             {
                const HYPRE_Int i1 = Aj[jj];
-               if (marker[(size_t) i1] >= begin) { pa[(size_t) marker[(size_t) i1]] += Aa[jj]; }
-               else if (marker[(size_t) i1] == strong_f)
+               if (marker.get(i1) >= begin) { pa[(size_t) marker.get(i1)] += Aa[jj]; }
+               else if (marker.get(i1) == strong_f)
                {
                   HYPRE_Real sum = 0.0;
                   const int sgn = Aa[Ai[i1]] < 0 ? -1 : 1;
                   for (HYPRE_Int j1 = Ai[i1] + 1; j1 < Ai[i1 + 1]; j1++)
                   {
                      const HYPRE_Int i2 = Aj[j1];
-                     if ((marker[(size_t) i2] >= begin || i2 == i) && (sgn * Aa[j1]) < 0) { sum += Aa[j1]; }
+                     if ((marker.get(i2) >= begin || i2 == i) && (sgn * Aa[j1]) < 0) { sum += Aa[j1]; }
                   }
                   if (sum != 0)
                   {
@@ -757,7 +841,7 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
                      for (HYPRE_Int j1 = Ai[i1] + 1; j1 < Ai[i1 + 1]; j1++)
                      {
                         const HYPRE_Int i2 = Aj[j1];
-                        if (marker[(size_t) i2] >= begin && (sgn * Aa[j1]) < 0) { pa[(size_t) marker[(size_t) i2]] += distribute * Aa[j1]; }
+                        if (marker.get(i2) >= begin && (sgn * Aa[j1]) < 0) { pa[(size_t) marker.get(i2)] += distribute * Aa[j1]; }
                         if (i2 == i && (sgn * Aa[j1]) < 0) { diagonal += distribute * Aa[j1]; }
                      }
                   }
@@ -769,6 +853,7 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
             strong_f--;
          }
          rowlen[(size_t) i] = (HYPRE_Int) ((long long) pj.size() - begin);
+         marker.end_row();
       }
    }
    // stitch
@@ -906,14 +991,14 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
       chunk(nc, T, t, &rb, &re);
       std::vector<HYPRE_Int> &oj = tj[(size_t) t];
       std::vector<HYPRE_Real> &oa = ta[(size_t) t];
-      std::vector<long long> Pmark((size_t) std::max(nc, 1), -1);
-      std::vector<HYPRE_Int> Amark((size_t) std::max(nf, 1), -1);
+      RowMap Pmark(1024), Amark(1024);         // column -> position in the row being formed
       std::vector<HYPRE_Int> raj;
       std::vector<HYPRE_Real> raa;
+      (void) nf;
       for (HYPRE_Int ic = rb; ic < re; ic++)
       {
          const long long begin = (long long) oj.size();
-         if (square) { Pmark[(size_t) ic] = begin; oj.push_back(ic); oa.push_back(0.0); }
+         if (square) { Pmark.set(ic, begin); oj.push_back(ic); oa.push_back(0.0); }
          raj.clear(); raa.clear();
          for (HYPRE_Int j1 = Ri[ic]; j1 < Ri[ic + 1]; j1++)
          {
@@ -922,10 +1007,10 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
             for (HYPRE_Int j2 = Ai[i1]; j2 < Ai[i1 + 1]; j2++)
             {
                const HYPRE_Int i2 = Aj[j2];
-               const HYPRE_Int m = Amark[(size_t) i2];
-               if (m < 0 || m >= (HYPRE_Int) raj.size() || raj[(size_t) m] != i2)
+               const long long m = Amark.get(i2, -1);
+               if (m < 0)
                {
-                  Amark[(size_t) i2] = (HYPRE_Int) raj.size();
+                  Amark.set(i2, (long long) raj.size());
                   raj.push_back(i2); raa.push_back(r * Aa[j2]);
                }
                else { raa[(size_t) m] += r * Aa[j2]; }
@@ -938,12 +1023,13 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
             for (HYPRE_Int j2 = Pi[i1]; j2 < Pi[i1 + 1]; j2++)
             {
                const HYPRE_Int i2 = Pj[j2];
-               const long long m = Pmark[(size_t) i2];
-               if (m < begin) { Pmark[(size_t) i2] = (long long) oj.size(); oj.push_back(i2); oa.push_back(rap * Pa[j2]); }
+               const long long m = Pmark.get(i2, -1);
+               if (m < begin) { Pmark.set(i2, (long long) oj.size()); oj.push_back(i2); oa.push_back(rap * Pa[j2]); }
                else { oa[(size_t) m] += rap * Pa[j2]; }
             }
          }
          rowlen[(size_t) ic] = (HYPRE_Int) ((long long) oj.size() - begin);
+         Amark.clear(); Pmark.clear();
       }
    }
    std::vector<HYPRE_Int> Ci((size_t) nc + 1, 0);
@@ -1259,7 +1345,9 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          d->U_array[level] = new_vec(comm, fine_size, Al->row_starts, HYPRE_MEMORY_HOST);
       }
       hypre_ParCSRMatrix *S = nullptr;
+      const double t_s0 = omp_get_wtime();
       hypre_BoomerAMGCreateS(Al, d->strong_threshold, d->max_row_sum, 1, nullptr, &S);
+      const double t_s1 = omp_get_wtime();
       const HYPRE_Int nloc = Al->diag->num_rows;
       d->CF_marker_array[level] = hypre_IntArrayCreate(nloc);
       hypre_IntArrayInitialize_v2(d->CF_marker_array[level], HYPRE_MEMORY_HOST);
@@ -1272,6 +1360,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          hypre_ParCSRMatrixDestroy(S);
          break;
       }
+      const double t_c1 = omp_get_wtime();
       HYPRE_Int *CF = d->CF_marker_array[level]->data;
       HYPRE_BigInt cpts[2];
       coarse_parms(comm, nloc, CF, cpts, &coarse_size);
@@ -1307,6 +1396,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          coarse_size = fine_size;
          break;
       }
+      const double t_i0 = omp_get_wtime();
       hypre_ParCSRMatrix *P = nullptr;
       if (d->interp_type == 6)
       {
@@ -1325,8 +1415,14 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       hypre_ParCSRMatrixSetNumNonzeros(P);
       hypre_ParCSRMatrixSetDNumNonzeros(P);
       d->P_array[level] = P;
+      const double t_r0 = omp_get_wtime();
       hypre_ParCSRMatrix *AH = nullptr;
       hypre_BoomerAMGBuildCoarseOperatorKT(P, Al, P, 1, &AH);
+      if (getenv("HYPRE_AMD_SETUP_TIMING") && comm_rank(comm) == 0)
+      {
+         fprintf(stderr, "setup level %d: rows %lld  strength %.2fs  coarsen %.2fs  interp %.2fs  RAP %.2fs  (threads %d)\n", level,
+                 (long long) fine_size, t_s1 - t_s0, t_c1 - t_s1, t_r0 - t_i0, omp_get_wtime() - t_r0, omp_get_max_threads());
+      }
       if (!AH || hypre_error_flag) { break; }
       ++level;
       hostA[(size_t) level] = AH;

@@ -10,6 +10,7 @@
 //   seq_mv/vector.c / vector_device.c             BLAS-1
 #include "internal.hpp"
 #include <unordered_map>
+#include <omp.h>
 #include <algorithm>
 
 using namespace hamd;
@@ -285,16 +286,78 @@ HYPRE_Int hypre_CSRMatrixTranspose(hypre_CSRMatrix *A, hypre_CSRMatrix **AT_ptr,
    const bool with_data = data && A->data;
    std::vector<HYPRE_Int> ti((size_t) nc + 1, 0), tj((size_t) nnz);
    std::vector<HYPRE_Complex> ta(with_data ? (size_t) nnz : 0);
-   for (HYPRE_Int k = 0; k < nnz; k++) { ti[(size_t) Aj[k] + 1]++; }
-   for (HYPRE_Int c = 0; c < nc; c++) { ti[(size_t) c + 1] += ti[(size_t) c]; }
-   std::vector<HYPRE_Int> pos(ti.begin(), ti.end() - 1);
-   for (HYPRE_Int r = 0; r < nr; r++)
+   // Stable counting sort by column (rows of A^T list their entries by ascending row of A).  Large
+   // matrices: T row blocks count their columns separately (seq_mv/csr_matop.c:1060-1230 does the
+   // same with one bucket array per OpenMP thread); block t's entries of a column go behind those of
+   // the blocks before it, so the result is the sequential one.
+   int T = 1;
+   if (nnz > (1 << 20))
    {
-      for (HYPRE_Int k = Ai[r]; k < Ai[r + 1]; k++)
+      T = std::min(omp_get_max_threads(), 16);
+      while (T > 1 && (size_t) T * (size_t) nc > (size_t) 1 << 30) { T /= 2; }
+   }
+   if (T <= 1)
+   {
+      for (HYPRE_Int k = 0; k < nnz; k++) { ti[(size_t) Aj[k] + 1]++; }
+      for (HYPRE_Int c = 0; c < nc; c++) { ti[(size_t) c + 1] += ti[(size_t) c]; }
+      std::vector<HYPRE_Int> pos(ti.begin(), ti.end() - 1);
+      for (HYPRE_Int r = 0; r < nr; r++)
       {
-         const HYPRE_Int q = pos[(size_t) Aj[k]]++;
-         tj[(size_t) q] = r;
-         if (with_data) { ta[(size_t) q] = Aa[k]; }
+         for (HYPRE_Int k = Ai[r]; k < Ai[r + 1]; k++)
+         {
+            const HYPRE_Int q = pos[(size_t) Aj[k]]++;
+            tj[(size_t) q] = r;
+            if (with_data) { ta[(size_t) q] = Aa[k]; }
+         }
+      }
+   }
+   else
+   {
+      std::vector<HYPRE_Int> cnt((size_t) T * (size_t) nc, 0);
+      std::vector<HYPRE_Int> rbeg((size_t) T + 1, 0);
+      for (int t = 0; t <= T; t++)
+      {
+         // row blocks balanced by entries
+         const long long target = (long long) nnz * t / T;
+         rbeg[(size_t) t] = (HYPRE_Int) (std::lower_bound(Ai, Ai + nr + 1, (HYPRE_Int) target) - Ai);
+      }
+      rbeg[0] = 0; rbeg[(size_t) T] = nr;
+#pragma omp parallel num_threads(T)
+      {
+         const int t = omp_get_thread_num();
+         HYPRE_Int *c = cnt.data() + (size_t) t * (size_t) nc;
+         for (HYPRE_Int k = Ai[rbeg[(size_t) t]]; k < Ai[rbeg[(size_t) t + 1]]; k++) { c[Aj[k]]++; }
+#pragma omp barrier
+         // column totals, then (after the scan) each block's first slot per column
+#pragma omp for schedule(static)
+         for (HYPRE_Int col = 0; col < nc; col++)
+         {
+            HYPRE_Int tot = 0;
+            for (int b = 0; b < T; b++) { tot += cnt[(size_t) b * (size_t) nc + (size_t) col]; }
+            ti[(size_t) col + 1] = tot;
+         }
+#pragma omp single
+         { for (HYPRE_Int col = 0; col < nc; col++) { ti[(size_t) col + 1] += ti[(size_t) col]; } }
+#pragma omp for schedule(static)
+         for (HYPRE_Int col = 0; col < nc; col++)
+         {
+            HYPRE_Int off = ti[(size_t) col];
+            for (int b = 0; b < T; b++)
+            {
+               const HYPRE_Int m = cnt[(size_t) b * (size_t) nc + (size_t) col];
+               cnt[(size_t) b * (size_t) nc + (size_t) col] = off;
+               off += m;
+            }
+         }
+         for (HYPRE_Int r = rbeg[(size_t) t]; r < rbeg[(size_t) t + 1]; r++)
+         {
+            for (HYPRE_Int k = Ai[r]; k < Ai[r + 1]; k++)
+            {
+               const HYPRE_Int q = c[Aj[k]]++;
+               tj[(size_t) q] = r;
+               if (with_data) { ta[(size_t) q] = Aa[k]; }
+            }
+         }
       }
    }
    hypre_CSRMatrix *AT = hypre_CSRMatrixCreate(nc, nr, nnz);

@@ -44,3 +44,31 @@ def test_gselim(oracle):
     L = oracle.load()
     assert L.oracle_gselim(Mc.ctypes.data_as(oracle.RealP), x.ctypes.data_as(oracle.RealP), 7) == 0
     assert np.allclose(x, np.linalg.solve(M, b), rtol=1e-12)
+
+
+def test_host_transpose_large_matrix_is_the_stable_counting_sort(lib):
+    """hypre_CSRMatrixTranspose on the host switches to row blocks counted in parallel above 2^20 entries; the
+    result must be the sequential stable sort (rows of A^T list their entries by ascending row of A)."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from hypre_amd import binding as B
+    rng = np.random.default_rng(11)
+    nr, nc, per = 150000, 90000, 9
+    cols = rng.integers(0, nc, size=(nr, per))
+    cols.sort(axis=1)
+    indptr = np.arange(0, nr * per + 1, per)
+    A = sp.csr_matrix((rng.uniform(-1, 1, nr * per), cols.ravel(), indptr), shape=(nr, nc))   # duplicates kept
+    A.has_canonical_format = False
+    hA = B.csr_from_arrays(nr, nc, indptr, cols.ravel(), A.data, location=B.HYPRE_MEMORY_HOST)
+    hT = C.POINTER(B.CSRMatrix)()
+    lib.hypre_CSRMatrixTranspose(hA, C.byref(hT), 1)
+    B.check()
+    ti, tj, ta = B.csr_to_arrays(hT)
+    # reference: stable argsort by column
+    order = np.argsort(cols.ravel(), kind="stable")
+    rows = np.repeat(np.arange(nr), per)
+    assert np.array_equal(tj, rows[order].astype(np.int32))
+    assert np.array_equal(ta, A.data[order])
+    assert np.array_equal(ti, np.concatenate([[0], np.cumsum(np.bincount(cols.ravel(), minlength=nc))]).astype(np.int32))
+    lib.hypre_CSRMatrixDestroy(hA)
+    lib.hypre_CSRMatrixDestroy(hT)
