@@ -717,14 +717,24 @@ HYPRE_Int hypre_BoomerAMGInterpTruncation(hypre_ParCSRMatrix *P, HYPRE_Real tol,
       }
    }
    for (HYPRE_Int i = 0; i < n; i++) { ndi[(size_t) i + 1] = ndi[(size_t) i] + cntd[(size_t) i]; noi[(size_t) i + 1] = noi[(size_t) i] + cnto[(size_t) i]; }
-   // compact front to back (new offsets never exceed old ones)
-   for (HYPRE_Int i = 0; i < n; i++)
+   // compact: rows move to their new offsets (out of place, rows in parallel)
+   auto compact = [&](hypre_CSRMatrix *M, const std::vector<HYPRE_Int> &ni, const std::vector<HYPRE_Int> &cnt)
    {
-      const HYPRE_Int s = Pd->i[i], t = ndi[(size_t) i];
-      if (s != t) { for (HYPRE_Int k = 0; k < cntd[(size_t) i]; k++) { Pd->j[t + k] = Pd->j[s + k]; Pd->data[t + k] = Pd->data[s + k]; } }
-      const HYPRE_Int so = Po->i[i], to = noi[(size_t) i];
-      if (so != to) { for (HYPRE_Int k = 0; k < cnto[(size_t) i]; k++) { Po->j[to + k] = Po->j[so + k]; Po->data[to + k] = Po->data[so + k]; } }
-   }
+      const HYPRE_Int nnz_new = ni[(size_t) n];
+      if (nnz_new == M->i[n]) { return; }
+      HYPRE_Int  *nj = hypre_TAlloc(HYPRE_Int, (size_t) std::max(nnz_new, 1), HYPRE_MEMORY_HOST);
+      HYPRE_Real *na = hypre_TAlloc(HYPRE_Real, (size_t) std::max(nnz_new, 1), HYPRE_MEMORY_HOST);
+#pragma omp parallel for schedule(static)
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         const HYPRE_Int s0 = M->i[i], t0 = ni[(size_t) i];
+         for (HYPRE_Int k = 0; k < cnt[(size_t) i]; k++) { nj[t0 + k] = M->j[s0 + k]; na[t0 + k] = M->data[s0 + k]; }
+      }
+      hypre_Free(M->j, HYPRE_MEMORY_HOST); hypre_Free(M->data, HYPRE_MEMORY_HOST);
+      M->j = nj; M->data = na;
+   };
+   compact(Pd, ndi, cntd);
+   compact(Po, noi, cnto);
    memcpy(Pd->i, ndi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
    memcpy(Po->i, noi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
    Pd->num_nonzeros = ndi[(size_t) n];
