@@ -23,7 +23,7 @@ namespace hamd {
 // Tuning knobs (A/B-testable without rebuilding): HYPRE_AMD_SPMV_GT, HYPRE_AMD_SPMV_XCD.
 void spmv_default_flags(SpmvArgs &a)
 {
-   static int gt = -1, xcd = 0;
+   static int gt = -1, xcd = 8;
    if (gt < 0)
    {
       const char *e = getenv("HYPRE_AMD_SPMV_GT");
@@ -31,7 +31,11 @@ void spmv_default_flags(SpmvArgs &a)
       // 3.76 -> 4.15 TB/s, level 2 (70/row) 3.17 -> 3.41 TB/s: fewer cache lines per gather instruction
       gt = e ? atoi(e) : 1;
       e = getenv("HYPRE_AMD_SPMV_XCD");
-      xcd = e ? atoi(e) : 0;   // measured: dispatch order 4.96 TB/s, chunks of 4..28 tiles per XCD the same, contiguous eighths 4.59 TB/s
+      // workgroup g runs on XCD g % 8 (own L2): handing every XCD runs of 8 consecutive tiles keeps rows that
+      // are neighbours in the matrix in one L2.  Measured on the 256^3 hierarchy: fine-level y = A x unchanged,
+      // restriction (P^T, scattered fine-vector gathers) 0.185 -> 0.167 ms, whole V-cycle 2.849 -> 2.821 ms;
+      // chunks of 4..16 the same, 128 hurts the small levels, one contiguous eighth per XCD is 8 % slower.
+      xcd = e ? atoi(e) : 8;
    }
    a.gather_t = gt; a.xcd_map = xcd;
 }
