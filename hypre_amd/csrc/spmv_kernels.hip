@@ -18,8 +18,8 @@
 //   phase 2  per-row reduction from LDS with 1, 8 or 32 lanes per row (chosen
 //            per tile from its mean row length), row sums of the multi-lane
 //            paths go through LDS so that the epilogue is one coalesced pass.
-// Tiles go to workgroups in dispatch order (XCD-aware placements were measured
-// and do not pay: see spmv_default_flags).
+// Tiles are dealt to the 8 XCDs (each with its own L2) in runs of 8 consecutive
+// tiles; the measured alternatives are listed at spmv_default_flags.
 //
 // Replaces (behaviourally) seq_mv/csr_spmv_device.c:35-260 of the reference,
 // which uses K lanes per row chosen from the matrix-wide average row length,
