@@ -280,6 +280,7 @@ def main():
                                    % (n1 * P, n1 * Q, n1 * R, stencil, world, P, Q, R, smoother,
                                       ", fp32 matrix values in the cycle" if args.mixed else ""),
                        "transport": transport if world > 1 else "none",
+                       "replicated_from_level": int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)),
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s},
             "roofline": {"bound": "hbm", "kernel": "spmv_tiled_kernel<AXPBY> (fine-level y = A x)",

@@ -32,6 +32,15 @@ struct AmgPrivate
    // algorithmic byte count of one cycle (filled by setup, SURVEY §8d formula)
    double cycle_bytes = 0.0;
 
+   // Replicated tail (multi-rank, device): the levels from tail_level down are small enough that
+   // their halo exchanges are pure latency.  Setup gathers these operators onto every rank as a
+   // single-rank hierarchy; the cycle then gathers the right-hand side of level tail_level with ONE
+   // all-reduce, runs the rest of the V-cycle redundantly and locally, and keeps its own slice.
+   int               replicate_rows = 8192;   // global row count at or below which a level is replicated (0: off)
+   hypre_ParAMGData *tail = nullptr;
+   int               tail_level = -1;
+   double           *d_tail_f = nullptr;      // global right-hand side of level tail_level (device)
+
    void release_device();
    ~AmgPrivate() { release_device(); }
 };
@@ -52,6 +61,10 @@ void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_mark
 
 hypre_ParCSRCommHandle *dev_halo_begin(hypre_ParCSRMatrix *A, const double *x_local);
 void dev_halo_end(hypre_ParCSRCommHandle *h);
+
+// replicated tail (par_amg_replicate.cpp)
+void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMatrix *> &hostA);
+void destroy_replicated_tail(hypre_ParAMGData *d);
 
 // distributed setup pieces (par_amg_setup_dist.cpp)
 HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,

@@ -64,6 +64,7 @@ HYPRE_Int HYPRE_BoomerAMGCreate(HYPRE_Solver *solver)
 void amg_free_hierarchy(hypre_ParAMGData *d)
 {
    AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   destroy_replicated_tail(d);
    if (pv) { pv->release_device(); }
    const int L = d->num_levels;
    if (d->A_array)
@@ -254,6 +255,13 @@ HYPRE_Real *hypre_amd_BoomerAMGGetChebyCoefs(HYPRE_Solver s, HYPRE_Int l)
 { hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && d->cheby_coefs && l >= 0 && l < d->num_levels) ? d->cheby_coefs[l] : nullptr; }
 hypre_Vector *hypre_amd_BoomerAMGGetChebyDS(HYPRE_Solver s, HYPRE_Int l)
 { hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && d->cheby_ds && l >= 0 && l < d->num_levels) ? d->cheby_ds[l] : nullptr; }
+
+// global row count at or below which the levels of a multi-rank device hierarchy are replicated on every
+// rank (0 disables; see par_amg_replicate.cpp)
+HYPRE_Int hypre_amd_BoomerAMGSetReplicateThreshold(HYPRE_Solver s, HYPRE_Int rows)
+{ AMG_DATA(s, d); ((AmgPrivate *) d->amd_private)->replicate_rows = rows < 0 ? 0 : rows; return hypre_error_flag; }
+HYPRE_Int hypre_amd_BoomerAMGGetReplicatedLevel(HYPRE_Solver s)
+{ hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && ((AmgPrivate *) d->amd_private)->tail) ? ((AmgPrivate *) d->amd_private)->tail_level : -1; }
 
 HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver s, HYPRE_MemoryLocation loc)
 { AMG_DATA(s, d); d->memory_location = loc; return hypre_error_flag; }

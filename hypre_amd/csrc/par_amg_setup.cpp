@@ -1574,6 +1574,9 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       pv->cycle_bytes = bytes;
    }
 
+   // multi-rank device runs: small levels are replicated on every rank (par_amg_replicate.cpp)
+   if (target == HYPRE_MEMORY_DEVICE) { build_replicated_tail(d, hostA); }
+
    // place the hierarchy where the solve phase will run
    if (target == HYPRE_MEMORY_DEVICE)
    {

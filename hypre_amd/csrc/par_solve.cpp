@@ -399,6 +399,40 @@ struct LevelVec
    void flip() { cur = other(); }
 };
 
+// Levels pv->tail_level and below on this rank's replica (par_amg_replicate.cpp): gather f, cycle, keep own slice.
+int run_replicated_tail(hypre_ParAMGData *d, AmgPrivate *pv, const double *f_local, double *u_local, double *op_count)
+{
+   hypre_ParAMGData *t = pv->tail;
+   hypre_ParCSRMatrix *Al = d->A_array[pv->tail_level];
+   const int nloc = Al->diag->num_rows;
+   const size_t first = (size_t) Al->row_starts[0];
+   const int ng = (int) t->A_array[0]->global_num_rows;
+   hipStream_t s = stream();
+   double *g = pv->d_tail_f;
+   const hypre_amd_CommOps *o = comm_ops(Al->comm);
+   HIP_CHECK(hipMemsetAsync(g, 0, sizeof(double) * (size_t) ng, s));
+   if (nloc) { HIP_CHECK(hipMemcpyAsync(g + first, f_local, sizeof(double) * (size_t) nloc, hipMemcpyDeviceToDevice, s)); }
+   if (o->device_buffers) { o->allreduce_sum(o->ctx, g, ng, 1, (void *) s); }
+   else
+   {
+      std::vector<double> h((size_t) ng);
+      hypre_TMemcpy(h.data(), g, double, (size_t) ng, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      o->allreduce_sum(o->ctx, h.data(), ng, 0, nullptr);
+      hypre_TMemcpy(g, h.data(), double, (size_t) ng, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   }
+   HIP_CHECK(hipMemcpyAsync(t->F_array[0]->local_vector->data, g, sizeof(double) * (size_t) ng, hipMemcpyDeviceToDevice, s));
+   hypre_ParVectorSetZeros(t->U_array[0]);
+   t->cycle_op_count = 0;
+   const int err = hypre_BoomerAMGCycle(t, t->F_array, t->U_array);
+   if (nloc)
+   {
+      HIP_CHECK(hipMemcpyAsync(u_local, t->U_array[0]->local_vector->data + first, sizeof(double) * (size_t) nloc,
+                               hipMemcpyDeviceToDevice, s));
+   }
+   if (op_count) { *op_count += t->cycle_op_count; }
+   return err;
+}
+
 bool is_jacobi_type(int t) { return t == 0 || t == 7 || t == 18; }
 bool is_ge_type(int t) { return t == 9 || t == 19 || t == 98 || t == 99 || t == 198 || t == 199; }
 
@@ -416,6 +450,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    hipStream_t s = stream();
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
+   const int saved_gs_threads = handle().gs_threads;
    handle().gs_threads = pv->emulated_threads;
    const bool saved_fp32 = handle().fp32_values;
    handle().fp32_values = pv->mixed_precision;
@@ -464,7 +499,17 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       LevelVec &u = lv[(size_t) level];
       const double w = d->relax_weight[level];
 
-      for (int j = 0; j < num_sweep; j++)
+      // replicated tail: from this level down the V-cycle runs on this rank's own copy of the operators
+      // (one all-reduce of the right-hand side instead of four halo exchanges per level)
+      const bool tail_here = pv->tail != nullptr && level == pv->tail_level;
+      if (tail_here)
+      {
+         err = run_replicated_tail(d, pv, fd, u.home, &cycle_op_count);
+         u.cur = u.home;
+         zeros[(size_t) level] = 0;
+         if (err) { break; }
+      }
+      for (int j = 0; j < (tail_here ? 0 : num_sweep); j++)
       {
          int relax_points = 0, relax_local = d->relax_order;
          if (L == 1 && d->max_levels > 1) { relax_points = 0; relax_local = 0; }
@@ -558,7 +603,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       if (err) { break; }
 
       --lev_counter[(size_t) level];
-      if (lev_counter[(size_t) level] >= 0 && level != L - 1)
+      if (lev_counter[(size_t) level] >= 0 && level != L - 1 && !tail_here)
       {
          // descend: u_c = 0 ; r = f - A u ; f_c = P^T r
          const int fine = level, coarse = level + 1;
@@ -621,6 +666,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    d->cycle_op_count = cycle_op_count;
    (void) ztemp;
    handle().fp32_values = saved_fp32;
+   handle().gs_threads = saved_gs_threads;
    handle().sync_compute = saved_sync;
    maybe_sync();
    return err;

@@ -222,6 +222,13 @@ HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_th
 HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on);
 /* grid / operator complexity of the last setup */
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
+/* Multi-rank device hierarchies: levels with at most `rows` global rows are gathered onto every rank at
+ * setup and the V-cycle below the first such level runs locally from one all-reduced right-hand side
+ * (latency of four halo exchanges per level removed).  Applies to V-cycles with Jacobi-type smoothers
+ * (relax 0/7/18, +CF); default 8192, 0 disables.  hypre's own relative is the seq_threshold /
+ * hypre_seqAMGSetup path (par_amg_setup.c), which re-coarsens the gathered operator instead. */
+HYPRE_Int hypre_amd_BoomerAMGSetReplicateThreshold(HYPRE_Solver solver, HYPRE_Int rows);
+HYPRE_Int hypre_amd_BoomerAMGGetReplicatedLevel(HYPRE_Solver solver);      /* -1: none */
 /* par_amg_solve.c:391-401: operation count of the last cycle (the reference's cycle complexity = this / nnz(A_0)) */
 HYPRE_Int hypre_amd_BoomerAMGGetCycleOpCount(HYPRE_Solver solver, HYPRE_Real *count);
 /* algorithmic HBM bytes of one cycle on the current hierarchy (SURVEY §8d formula) */

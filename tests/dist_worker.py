@@ -19,6 +19,9 @@ def main():
     import pyoracle as O
 
     case = json.loads(sys.argv[1])
+    # a rank that stops making progress dumps its Python stack and exits instead of hanging the suite
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("HYPRE_AMD_TEST_WATCHDOG", "300")), exit=True)
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     L = B.load_library()
@@ -29,6 +32,8 @@ def main():
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
     device = bool(case.get("device", 0))
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE if device else B.HYPRE_MEMORY_HOST)
+    if "replicate" in case:
+        L.hypre_amd_BoomerAMGSetReplicateThreshold(s, int(case["replicate"]))
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
     B.check()
     g, o = C.c_double(), C.c_double()
@@ -83,6 +88,7 @@ def main():
             L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
             L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
         B.check()
+        mine.update(replicated_level=int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)))
         mine.update(dev_its=its.value, dev_rel=rel.value, dev_x=B.parvec_to_numpy(dx), xt=xt,
                     dev_y=B.parvec_to_numpy(dy), dev_z=B.parvec_to_numpy(dz), dev_dot=dot)
     parts = [None] * world if rank == 0 else None
@@ -115,6 +121,7 @@ def main():
             yd = np.concatenate([p["dev_y"] for p in parts])
             zd = np.concatenate([p["dev_z"] for p in parts])
             xd = np.concatenate([p["dev_x"] for p in parts])
+            out.update(replicated_level=parts[0]["replicated_level"])
             out.update(dev_iterations=parts[0]["dev_its"], dev_rel_resid=parts[0]["dev_rel"],
                        matvec_err=float(np.max(np.abs(yd - yr)) / np.max(np.abs(yr))),
                        matvecT_err=float(np.max(np.abs(zd - zr)) / np.max(np.abs(zr))),

@@ -29,6 +29,21 @@ def test_two_or_three_ranks_on_device(name):
         assert abs(out["conv_factor"] - exp["conv_factor"]) < 5.1e-7
 
 
+def test_replicated_tail_is_used_and_optional():
+    """Jacobi-type V-cycles on several ranks run their small levels on a replicated copy (one all-reduce instead of
+    four halo exchanges per level); switched off, the same solve goes through the distributed levels.  Both
+    reproduce the reference's golden (smoother.out.9: relax 18 with CF ordering, 3 ranks)."""
+    case = dict(GOLD["smoother.out.9"])
+    on = run_ranks(3, {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1})
+    off = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1, "replicate": 0})
+    assert on["replicated_level"] >= 1 and off["replicated_level"] == -1
+    for out in (on, off):
+        assert out["dev_iterations"] == case["expect"]["iterations"]
+        assert abs(out["dev_rel_resid"] - case["expect"]["rel_resid"]) <= 5e-7 * case["expect"]["rel_resid"]
+    # same operators, same sweeps; only the association of the row sums differs (one piece vs diag + ghost block)
+    assert abs(on["dev_rel_resid"] - off["dev_rel_resid"]) <= 1e-6 * off["dev_rel_resid"]
+
+
 def test_pcg_three_ranks_on_device():
     case = dict(GOLD["solvers.out.19"])
     out = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1})
