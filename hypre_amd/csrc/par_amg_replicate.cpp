@@ -88,7 +88,8 @@ hypre_ParCSRMatrix *replicate_matrix(hypre_ParCSRMatrix *M)
    return R;
 }
 
-bool jacobi_like(int t) { return t == 0 || t == 7 || t == 18; }
+// smoothers whose result does not depend on how the rows are spread over ranks
+bool jacobi_like(int t) { return t == 0 || t == 7 || t == 18 || t == 16; }
 bool ge_like(int t) { return t == 9 || t == 19 || t == 98 || t == 99 || t == 198 || t == 199; }
 
 hypre_ParVector *self_vec(HYPRE_BigInt n, HYPRE_MemoryLocation loc)
@@ -174,6 +175,36 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
    t->A = t->A_array[0];
    t->Vtemp = self_vec(t->A_array[0]->global_num_rows, HYPRE_MEMORY_HOST);
    t->Ztemp = self_vec(t->A_array[0]->global_num_rows, HYPRE_MEMORY_HOST);
+   if (d->cheby_coefs)
+   {
+      // Chebyshev: coefficients are the same on every rank, the scaling vector is gathered
+      t->cheby_order = d->cheby_order; t->cheby_scale = d->cheby_scale; t->cheby_variant = d->cheby_variant;
+      t->cheby_eig_est = d->cheby_eig_est; t->cheby_fraction = d->cheby_fraction;
+      t->cheby_coefs = (HYPRE_Real **) calloc((size_t) TL, sizeof(void *));
+      t->cheby_ds = (hypre_Vector **) calloc((size_t) TL, sizeof(void *));
+      t->max_eig_est = (HYPRE_Real *) calloc((size_t) TL, sizeof(HYPRE_Real));
+      t->min_eig_est = (HYPRE_Real *) calloc((size_t) TL, sizeof(HYPRE_Real));
+      const int nco = std::min(std::max((int) d->cheby_order, 1), 4) + 1;
+      for (int l = 0; l < TL; l++)
+      {
+         const int g = Lr + l;
+         t->max_eig_est[l] = d->max_eig_est[g]; t->min_eig_est[l] = d->min_eig_est[g];
+         if (d->cheby_coefs[g])
+         {
+            t->cheby_coefs[l] = hypre_CTAlloc(HYPRE_Real, (size_t) nco, HYPRE_MEMORY_HOST);
+            memcpy(t->cheby_coefs[l], d->cheby_coefs[g], sizeof(HYPRE_Real) * (size_t) nco);
+         }
+         if (d->cheby_ds && d->cheby_ds[g])
+         {
+            std::vector<double> all = allgather_var<double>(o, d->cheby_ds[g]->data, d->cheby_ds[g]->size);
+            t->cheby_ds[l] = hypre_SeqVectorCreate((HYPRE_Int) all.size());
+            hypre_SeqVectorInitialize_v2(t->cheby_ds[l], HYPRE_MEMORY_HOST);
+            memcpy(t->cheby_ds[l]->data, all.data(), sizeof(double) * all.size());
+         }
+      }
+      t->Ptemp = self_vec(t->A_array[0]->global_num_rows, HYPRE_MEMORY_HOST);
+      t->Rtemp = self_vec(t->A_array[0]->global_num_rows, HYPRE_MEMORY_HOST);
+   }
    // the dense coarse operator was gathered by hypre_GaussElimSetup already: same matrix on every rank
    if (d->A_mat && d->gs_setup)
    {
@@ -209,6 +240,9 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
       }
       hypre_ParVectorMigrate(t->Vtemp, HYPRE_MEMORY_DEVICE);
       hypre_ParVectorMigrate(t->Ztemp, HYPRE_MEMORY_DEVICE);
+      if (t->Ptemp) { hypre_ParVectorMigrate(t->Ptemp, HYPRE_MEMORY_DEVICE); }
+      if (t->Rtemp) { hypre_ParVectorMigrate(t->Rtemp, HYPRE_MEMORY_DEVICE); }
+      if (t->cheby_ds) { for (int l = 0; l < TL; l++) { if (t->cheby_ds[l]) { hypre_SeqVectorMigrate(t->cheby_ds[l], HYPRE_MEMORY_DEVICE); } } }
       pv->d_tail_f = hypre_TAlloc(double, (size_t) std::max<HYPRE_BigInt>(t->A_array[0]->global_num_rows, 1), HYPRE_MEMORY_DEVICE);
    }
    else
