@@ -36,7 +36,7 @@ struct AmgPrivate
    // their halo exchanges are pure latency.  Setup gathers these operators onto every rank as a
    // single-rank hierarchy; the cycle then gathers the right-hand side of level tail_level with ONE
    // all-reduce, runs the rest of the V-cycle redundantly and locally, and keeps its own slice.
-   int               replicate_rows = 8192;   // global row count at or below which a level is replicated (0: off)
+   int               replicate_rows = 16384;   // global row count at or below which a level is replicated (0: off)
    hypre_ParAMGData *tail = nullptr;
    int               tail_level = -1;
    double           *d_tail_f = nullptr;      // global right-hand side of level tail_level (device)

@@ -225,7 +225,7 @@ HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *gr
 /* Multi-rank device hierarchies: levels with at most `rows` global rows are gathered onto every rank at
  * setup and the V-cycle below the first such level runs locally from one all-reduced right-hand side
  * (latency of four halo exchanges per level removed).  Applies to V-cycles with Jacobi-type smoothers
- * (relax 0/7/18, +CF); default 8192, 0 disables.  hypre's own relative is the seq_threshold /
+ * (relax 0/7/18, +CF); default 16384, 0 disables.  hypre's own relative is the seq_threshold /
  * hypre_seqAMGSetup path (par_amg_setup.c), which re-coarsens the gathered operator instead. */
 HYPRE_Int hypre_amd_BoomerAMGSetReplicateThreshold(HYPRE_Solver solver, HYPRE_Int rows);
 HYPRE_Int hypre_amd_BoomerAMGGetReplicatedLevel(HYPRE_Solver solver);      /* -1: none */
