@@ -77,10 +77,14 @@ def main():
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend="gloo")
         else:
-            torch.cuda.set_device(local_rank)
+            # HYPRE_AMD_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box): ranks share device 0; RCCL refuses that,
+            # which exercises the fallback below
+            share = os.environ.get("HYPRE_AMD_BENCH_SHARE_GPU") == "1"
+            torch.cuda.set_device(0 if share else local_rank)
             # nccl (= RCCL) for device tensors; gloo beside it only so that the ranks can agree on
             # the fallback below through host tensors should the RCCL communicator be unusable
-            dist.init_process_group(backend="cpu:gloo,cuda:nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl",
+                                    device_id=None if share else torch.device("cuda", local_rank))
 
     from hypre_amd import binding as B, ij
     L = B.load_library()          # raises when the HIP library is missing: no fallback exists

@@ -224,8 +224,9 @@ HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
 /* Multi-rank device hierarchies: levels with at most `rows` global rows are gathered onto every rank at
  * setup and the V-cycle below the first such level runs locally from one all-reduced right-hand side
- * (latency of four halo exchanges per level removed).  Applies to V-cycles with Jacobi-type smoothers
- * (relax 0/7/18, +CF); default 16384, 0 disables.  hypre's own relative is the seq_threshold /
+ * (latency of four halo exchanges per level removed).  Applies to V-cycles with smoothers whose result
+ * does not depend on the row distribution (relax 0/7/18 with or without CF ordering, Chebyshev 16); default 16384,
+ * 0 disables.  hypre's own relative is the seq_threshold /
  * hypre_seqAMGSetup path (par_amg_setup.c), which re-coarsens the gathered operator instead. */
 HYPRE_Int hypre_amd_BoomerAMGSetReplicateThreshold(HYPRE_Solver solver, HYPRE_Int rows);
 HYPRE_Int hypre_amd_BoomerAMGGetReplicatedLevel(HYPRE_Solver solver);      /* -1: none */
