@@ -34,6 +34,8 @@ def parse():
     # the default is BASELINE config C2/C3; the switches below select the other device configs
     ap.add_argument("--problem", choices=["laplacian", "27pt", "difconv"], default="laplacian")
     ap.add_argument("--relax", type=int, default=18, help="smoother (18 l1-Jacobi, 11/12 two-stage GS, 13 l1-GS ...)")
+    ap.add_argument("--relax-up", type=int, default=-1,
+                    help="smoother of the up leg (e.g. --relax 13 --relax-up 14, the symmetric pair PCG needs)")
     ap.add_argument("--mixed", action="store_true", help="fp32 matrix values inside the cycle (config C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cycles", type=int, default=2)
@@ -120,6 +122,8 @@ def main():
     n1 = args.n
     opt = ij.IJOptions(n=(n1 * P, n1 * Q, n1 * R), P=(P, Q, R), coarsen_type=8, interp_type=6, P_max_elmts=4,
                        relax_type=args.relax, num_sweeps=1, problem=args.problem)
+    if args.relax_up > -1:
+        opt.relax_down, opt.relax_up = args.relax, args.relax_up
     if args.problem == "difconv":
         opt.c, opt.a = (1.0, 1.0, 0.001), (0.0, 0.0, 0.0)       # anisotropic diffusion (config C5)
     t0 = time.time()
@@ -274,6 +278,8 @@ def main():
                    "difconv": "7-pt anisotropic diffusion (1, 1, 0.001)"}[args.problem]
         smoother = {18: "l1-Jacobi", 7: "Jacobi", 0: "weighted Jacobi", 11: "two-stage GS (1 inner)",
                     12: "two-stage GS (2 inner)"}.get(args.relax, "relax %d" % args.relax)
+        if args.relax_up > -1:
+            smoother += " down / relax %d up" % args.relax_up
         arith = "fp32 matrix values / fp64 vectors" if args.mixed else "fp64"
         out = {
             "metric": "BoomerAMG V-cycle DOF/s (%d^3 %s per GPU, %s V(1,1), %s)" % (n1, stencil, smoother, arith),

@@ -89,10 +89,10 @@ struct GsArgs
    int    skip_diag, non_scale;
    double w, omega;
    int    n, threads;
-   const int *rows;            // rows ordered by level
+   const int4 *sched;          // rows ordered by level: {row, first entry, end of row, -}
 };
-void launch_gs_level(const GsArgs &a, int start, int count, hipStream_t s);
-void launch_gs_multilevel(const GsArgs &a, const int *d_lev_start, int lev_begin, int lev_end, hipStream_t s);
+void launch_gs_level(const GsArgs &a, int lanes, int start, int count, hipStream_t s);
+void launch_gs_run(const GsArgs &a, int lanes, const int *d_lev_start, int lev_begin, int lev_end, hipStream_t s);
 void drop_gs_schedule(const hypre_CSRMatrix *A);
 
 // fused elementwise passes of the Chebyshev smoother (cheby_kernels.hip)

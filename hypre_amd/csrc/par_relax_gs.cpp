@@ -10,6 +10,7 @@
 // from its sparsity pattern and cached beside the SpMV plan.
 #include "amg_internal.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 
@@ -19,8 +20,8 @@ namespace {
 
 struct GsDirection
 {
-   std::vector<int> lev_start;      // [nlev + 1] offsets into rows
-   int             *d_rows = nullptr;
+   std::vector<int> lev_start;      // [nlev + 1] offsets into sched
+   int4            *d_sched = nullptr;   // rows in level order: {row, first entry, end of row, -}
    int             *d_lev_start = nullptr;
    int              nlev = 0;
 };
@@ -29,6 +30,7 @@ struct GsSchedule
 {
    const HYPRE_Int *key_i = nullptr, *key_j = nullptr;
    int              n = 0, nnz = 0, threads = 1;
+   int              lanes = 8;      // lanes that share a row (power of two covering the average row)
    GsDirection      dir[2];         // 0 forward, 1 backward
 };
 
@@ -43,7 +45,7 @@ void free_schedule(GsSchedule *g)
    if (!g) { return; }
    for (int d = 0; d < 2; d++)
    {
-      if (g->dir[d].d_rows) { (void) hipFree(g->dir[d].d_rows); }
+      if (g->dir[d].d_sched) { (void) hipFree(g->dir[d].d_sched); }
       if (g->dir[d].d_lev_start) { (void) hipFree(g->dir[d].d_lev_start); }
    }
    delete g;
@@ -101,11 +103,11 @@ void build_direction(GsDirection &D, int n, int threads, const int *Ai, const in
    for (int i = 0; i < n; i++) { D.lev_start[(size_t) level[(size_t) i] + 1]++; }
    for (int l = 0; l < nlev; l++) { D.lev_start[(size_t) l + 1] += D.lev_start[(size_t) l]; }
    std::vector<int> pos(D.lev_start.begin(), D.lev_start.end() - (nlev > 0 ? 1 : 0));
-   std::vector<int> rows((size_t) std::max(n, 1));
-   for (int i = 0; i < n; i++) { rows[(size_t) pos[(size_t) level[(size_t) i]]++] = i; }
-   HIP_CHECK(hipMalloc((void **) &D.d_rows, sizeof(int) * (size_t) std::max(n, 1)));
+   std::vector<int4> rows((size_t) std::max(n, 1));
+   for (int i = 0; i < n; i++) { rows[(size_t) pos[(size_t) level[(size_t) i]]++] = make_int4(i, Ai[i], Ai[i + 1], 0); }
+   HIP_CHECK(hipMalloc((void **) &D.d_sched, sizeof(int4) * (size_t) std::max(n, 1)));
    HIP_CHECK(hipMalloc((void **) &D.d_lev_start, sizeof(int) * ((size_t) nlev + 1)));
-   HIP_CHECK(hipMemcpy(D.d_rows, rows.data(), sizeof(int) * (size_t) n, hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(D.d_sched, rows.data(), sizeof(int4) * (size_t) n, hipMemcpyHostToDevice));
    HIP_CHECK(hipMemcpy(D.d_lev_start, D.lev_start.data(), sizeof(int) * ((size_t) nlev + 1), hipMemcpyHostToDevice));
 }
 
@@ -130,31 +132,37 @@ GsSchedule *get_schedule(hypre_CSRMatrix *A, int threads)
    HIP_CHECK(hipStreamSynchronize(stream()));
    hypre_TMemcpy(hi.data(), A->i, HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_HOST, A->memory_location);
    if (nnz > 0) { hypre_TMemcpy(hj.data(), A->j, HYPRE_Int, (size_t) nnz, HYPRE_MEMORY_HOST, A->memory_location); }
+   const double avg = n > 0 ? (double) nnz / n : 1.0;
+   g->lanes = avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : 32;
    build_direction(g->dir[0], n, threads, hi.data(), hj.data(), true);
    build_direction(g->dir[1], n, threads, hi.data(), hj.data(), false);
    t[A] = g;
    return g;
 }
 
-// small levels share one single-workgroup launch, large ones get their own grid
-void run_direction(const GsDirection &D, GsArgs a, hipStream_t s)
+// Levels that fit one pass of a workgroup (1024 / lanes rows) share one single-workgroup launch whose
+// steps are pipelined (gs_kernels.hip: ~2 us per level); a larger level gets a grid of its own (~5 us).
+// Measured on the 64^3 7-pt hierarchy: 1 pass 16.7 ms per V(1,1) cycle, 2: 17.0, 4: 18.8, 8: 36.5.
+void run_direction(const GsDirection &D, int lanes, GsArgs a, hipStream_t s)
 {
-   constexpr int SMALL = 1024;
-   a.rows = D.d_rows;
+   static const int passes = [] { const char *e = getenv("HYPRE_AMD_GS_RUN_PASSES"); return std::max(1, e ? atoi(e) : 1); }();
+   const int small = passes * (1024 / lanes);
+   constexpr int MAX_RUN = 12288;                // level offsets of a run sit in LDS
+   a.sched = D.d_sched;
    int lev = 0;
    while (lev < D.nlev)
    {
       const int cnt = D.lev_start[(size_t) lev + 1] - D.lev_start[(size_t) lev];
-      if (cnt <= SMALL)
+      if (cnt <= small)
       {
          int end = lev + 1;
-         while (end < D.nlev && D.lev_start[(size_t) end + 1] - D.lev_start[(size_t) end] <= SMALL) { end++; }
-         launch_gs_multilevel(a, D.d_lev_start, lev, end, s);
+         while (end < D.nlev && end - lev < MAX_RUN && D.lev_start[(size_t) end + 1] - D.lev_start[(size_t) end] <= small) { end++; }
+         launch_gs_run(a, lanes, D.d_lev_start, lev, end, s);
          lev = end;
       }
       else
       {
-         launch_gs_level(a, D.lev_start[(size_t) lev], cnt, s);
+         launch_gs_level(a, lanes, D.lev_start[(size_t) lev], cnt, s);
          lev++;
       }
    }
@@ -234,7 +242,7 @@ extern "C" HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMat
       if (sweep == 0) { a.uold = vt; }
       else { launch_copy(zt, ud, (size_t) n, s); a.uold = zt; }
       a.dir = dirn;
-      run_direction(g->dir[dirn > 0 ? 0 : 1], a, s);
+      run_direction(g->dir[dirn > 0 ? 0 : 1], g->lanes, a, s);
    }
    u->all_zeros = 0;               // the sweep has written u (relax 89 calls this twice: the second sweep must fetch ghosts)
    handle().sync_compute = saved;
