@@ -68,6 +68,23 @@ class ParVector(C.Structure):
                 ("owns_data", Int), ("all_zeros", Int), ("assumed_partition", C.c_void_p)]
 
 
+class IJMatrix(C.Structure):
+    _fields_ = [("comm", Int), ("row_partitioning", BigInt * 2), ("col_partitioning", BigInt * 2),
+                ("object_type", Int), ("object", C.c_void_p), ("translator", C.c_void_p),
+                ("assumed_part", C.c_void_p), ("assemble_flag", Int), ("global_first_row", BigInt),
+                ("global_first_col", BigInt), ("global_num_rows", BigInt), ("global_num_cols", BigInt),
+                ("omp_flag", Int), ("print_level", Int)]
+
+
+class IJVector(C.Structure):
+    _fields_ = [("comm", Int), ("partitioning", BigInt * 2), ("num_components", Int), ("object_type", Int),
+                ("object", C.c_void_p), ("translator", C.c_void_p), ("assumed_part", C.c_void_p),
+                ("global_first_row", BigInt), ("global_num_rows", BigInt), ("print_level", Int)]
+
+
+HYPRE_PARCSR = 5555
+
+
 class IntArray(C.Structure):
     _fields_ = [("data", IntP), ("size", Int), ("memory_location", Int)]
 
@@ -230,6 +247,18 @@ PROTOTYPES = {
                                                    RealP, IntP, IntP, RealP, Int]),
     "hypre_amd_ParVectorFromArray": (ParVecp, [Int, BigInt, BigIntP, RealP, Int]),
     "hypre_amd_ParVectorToArray": (Int, [ParVecp, RealP]),
+    # IJ text files
+    "HYPRE_IJMatrixRead": (Int, [C.c_char_p, Int, Int, C.POINTER(C.POINTER(IJMatrix))]),
+    "HYPRE_IJMatrixPrint": (Int, [C.POINTER(IJMatrix), C.c_char_p]),
+    "HYPRE_IJMatrixGetObject": (Int, [C.POINTER(IJMatrix), C.POINTER(C.c_void_p)]),
+    "HYPRE_IJMatrixDestroy": (Int, [C.POINTER(IJMatrix)]),
+    "hypre_ParCSRMatrixPrintIJ": (Int, [ParCSRp, Int, Int, C.c_char_p]),
+    "HYPRE_IJVectorRead": (Int, [C.c_char_p, Int, Int, C.POINTER(C.POINTER(IJVector))]),
+    "HYPRE_IJVectorPrint": (Int, [C.POINTER(IJVector), C.c_char_p]),
+    "HYPRE_IJVectorGetObject": (Int, [C.POINTER(IJVector), C.POINTER(C.c_void_p)]),
+    "HYPRE_IJVectorDestroy": (Int, [C.POINTER(IJVector)]),
+    "hypre_amd_IJMatrixWrap": (C.POINTER(IJMatrix), [ParCSRp]),
+    "hypre_amd_IJVectorWrap": (C.POINTER(IJVector), [ParVecp]),
 }
 
 _lib = None

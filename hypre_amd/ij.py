@@ -24,6 +24,8 @@ class IJOptions:
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
         self.solver = 0               # 0 AMG, 1 AMG-PCG
         self.rhs = "one"              # one (-rhsisone default) | rand (-rhsrand) | xisone
+        self.fromfile = None          # -fromfile <name>: matrix from IJ text files <name>.<rank %05d>
+        self.rhsfromfile = None       # -rhsfromfile <name>: right-hand side from IJ text files
         self.coarsen_type = 10
         self.interp_type = 6
         self.P_max_elmts = 4
@@ -110,6 +112,8 @@ def stencil_values(opt):
 
 def build_matrix(opt, comm=0, rank=0, nprocs=1):
     """Rank (p,q,r) = (id % P, (id / P) % Q, id / (P*Q))   (test/ij.c:9693-9695)."""
+    if opt.fromfile:
+        return read_matrix(opt.fromfile, comm=comm)
     P, Q, R = opt.P if opt.P else (1, nprocs, 1)     # test/ij.c BuildParLaplacian: P = 1, Q = num_procs, R = 1
     if P * Q * R != nprocs:
         raise ValueError("P*Q*R must equal the number of ranks")
@@ -117,6 +121,34 @@ def build_matrix(opt, comm=0, rank=0, nprocs=1):
     kind = {"laplacian": "7pt", "27pt": "27pt", "difconv": "difconv"}[opt.problem]
     nx, ny, nz = opt.n
     return B.laplacian(nx, ny, nz, P, Q, R, p, q, r, comm=comm, values=stencil_values(opt), kind=kind)
+
+
+def read_matrix(name, comm=0):
+    """test/ij.c:2824-2833 (build_matrix_type -1): HYPRE_IJMatrixRead + GetObject; the IJ shell is dropped and
+    the ParCSR matrix lives on (host memory)."""
+    L = B.load_library()
+    ij = C.POINTER(B.IJMatrix)()
+    L.HYPRE_IJMatrixRead(name.encode(), comm, B.HYPRE_PARCSR, C.byref(ij))
+    B.check()
+    obj = C.c_void_p()
+    L.HYPRE_IJMatrixGetObject(ij, C.byref(obj))
+    A = C.cast(obj, C.POINTER(B.ParCSRMatrix))
+    ij.contents.object = None          # keep the matrix, free the shell
+    L.HYPRE_IJMatrixDestroy(ij)
+    return A
+
+
+def read_vector(name, comm=0):
+    """test/ij.c:3406-3432 (build_rhs_type 0): the local slice as a numpy array."""
+    L = B.load_library()
+    ij = C.POINTER(B.IJVector)()
+    L.HYPRE_IJVectorRead(name.encode(), comm, B.HYPRE_PARCSR, C.byref(ij))
+    B.check()
+    obj = C.c_void_p()
+    L.HYPRE_IJVectorGetObject(ij, C.byref(obj))
+    vals = B.parvec_to_numpy(C.cast(obj, C.POINTER(B.ParVector)))
+    L.HYPRE_IJVectorDestroy(ij)
+    return vals
 
 
 class HypreRand:
@@ -137,6 +169,11 @@ class HypreRand:
 def build_rhs_host(opt, A, rank=0, allreduce=None):
     """(b, x0) as numpy arrays for this rank (test/ij.c:3465-3600)."""
     n = A.contents.diag.contents.num_rows
+    if opt.rhsfromfile:
+        b = read_vector(opt.rhsfromfile, comm=A.contents.comm)
+        if len(b) != n:
+            raise ValueError("right-hand side file holds %d entries for %d local rows" % (len(b), n))
+        return b, np.zeros(n)
     if opt.rhs == "one":
         return np.ones(n), np.zeros(n)
     if opt.rhs == "rand":
@@ -252,6 +289,11 @@ def parse_cli(argv):
                 raise SystemExit("ij: %s needs %d value(s)" % (flag, count))
             setattr(opt, attr, vals[0] if count == 1 else tuple(vals))
             i += 1 + count
+        elif flag in ("-fromfile", "-rhsfromfile"):
+            if i + 1 >= len(argv):
+                raise SystemExit("ij: %s needs a file name" % flag)
+            setattr(opt, flag[1:], argv[i + 1])
+            i += 2
         elif flag in ("-wl", "-owl"):
             val, lev = float(argv[i + 1]), int(argv[i + 2])
             if lev > -1:        # test/ij.c:4543-4550 applies the level weight only for level > -1

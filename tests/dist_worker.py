@@ -29,6 +29,9 @@ def main():
     if L.hypre_amd_CommSelfTest(comm, 4099) != 0:
         raise SystemExit("communicator self-test failed on rank %d" % rank)
     opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
+    for name in ("fromfile", "rhsfromfile"):          # the reference's input files live beside the goldens
+        if getattr(opt, name):
+            setattr(opt, name, os.path.join(ROOT, "tests", "golden", "ij_files", getattr(opt, name)))
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
     device = bool(case.get("device", 0))
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE if device else B.HYPRE_MEMORY_HOST)

@@ -45,7 +45,10 @@ def test_struct_sizes_match_headers(lib):
 #include <stdio.h>
 #include <stddef.h>
 #include "hypre_amd_parcsr_ls.h"
+#include "hypre_amd_IJ_mv.h"
 int main(void) {
+  printf("%zu %zu %zu %zu ", sizeof(hypre_IJMatrix), offsetof(hypre_IJMatrix, global_first_row),
+         sizeof(hypre_IJVector), offsetof(hypre_IJVector, global_first_row));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hypre_CSRMatrix), sizeof(hypre_Vector),
          sizeof(hypre_ParCSRMatrix), sizeof(hypre_ParVector), sizeof(hypre_ParCSRCommPkg),
          offsetof(hypre_ParCSRMatrix, comm_pkg), offsetof(hypre_ParVector, all_zeros),
@@ -57,6 +60,9 @@ int main(void) {
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                         os.path.join(td, "probe.c"), "-o", os.path.join(td, "probe")], check=True)
         out = subprocess.run([os.path.join(td, "probe")], capture_output=True, text=True, check=True).stdout.split()
+    ij, out = [int(v) for v in out[:4]], out[4:]
+    assert ij == [C.sizeof(B.IJMatrix), B.IJMatrix.global_first_row.offset,
+                  C.sizeof(B.IJVector), B.IJVector.global_first_row.offset]
     sizes = [int(v) for v in out]
     assert sizes[0] == C.sizeof(B.CSRMatrix)
     assert sizes[1] == C.sizeof(B.Vector)

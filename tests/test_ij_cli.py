@@ -44,7 +44,9 @@ def _replay(case, timeout=600):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(case["np"]),
                "--master-addr", "127.0.0.1", "--master-port", str(29600 + (abs(hash(case["cmd"])) % 300)),
                "-m", "hypre_amd.ij"] + args
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    # jobs that read matrix files run where the reference's input files were copied (test/TEST_ij layout)
+    cwd = os.path.join(HERE, "golden", "ij_files") if "-fromfile" in args else ROOT
+    p = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-2000:]
     return p.stdout
 
@@ -52,7 +54,7 @@ def _replay(case, timeout=600):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
                                   "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24",
-                                  "coarsening.out.4", "interp.out.0", "matrix.out.0"])
+                                  "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
