@@ -76,7 +76,8 @@ __global__ void scale_copy_kernel(double b, const double *__restrict__ x, double
    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { y[n - 1] = b * x[n - 1]; }
 }
 
-__global__ void axpy_kernel(double a, const double *__restrict__ x, double *__restrict__ y, size_t n)
+// x may alias y (GMRES forms its restart residual with Axpy(a, p, p), gmres.c:939-947): no restrict
+__global__ void axpy_kernel(double a, const double *x, double *y, size_t n)
 {
    VEC_LOOP_BEGIN
       const double2 xv = reinterpret_cast<const double2 *>(x)[i];

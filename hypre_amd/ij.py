@@ -22,7 +22,8 @@ class IJOptions:
         self.problem = "laplacian"    # laplacian | 27pt | difconv
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
-        self.solver = 0               # 0 AMG, 1 AMG-PCG
+        self.solver = 0               # 0 AMG, 1 AMG-PCG, 3 AMG-GMRES
+        self.k_dim = 5                # -k (GMRES restart length, test/ij.c:1731)
         self.rhs = "one"              # one (-rhsisone default) | rand (-rhsrand) | xisone
         self.fromfile = None          # -fromfile <name>: matrix from IJ text files <name>.<rank %05d>
         self.rhsfromfile = None       # -rhsfromfile <name>: right-hand side from IJ text files
@@ -255,7 +256,7 @@ _VALUE_FLAGS = {
     "-tr": ("trunc_factor", float, 1), "-Pmx": ("P_max_elmts", int, 1), "-interptype": ("interp_type", int, 1),
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
-    "-precon_cycles": ("precon_cycles", int, 1),
+    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
     "-cheby_fraction": ("cheby_fraction", float, 1),
@@ -301,8 +302,8 @@ def parse_cli(argv):
             i += 3
         else:
             raise SystemExit("ij: option %s is outside the scope of this driver" % flag)
-    if opt.solver not in (0, 1):
-        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG)" % opt.solver)
+    if opt.solver not in (0, 1, 3):
+        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 3 AMG-GMRES)" % opt.solver)
     if opt.interp_type not in (6, 3):
         raise SystemExit("ij: -interptype %d is outside the scope of this driver (6 ext+i, 3 direct)" % opt.interp_type)
     smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 16, 18, 88, 89)
@@ -361,6 +362,9 @@ def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
                   "                   cycle = %f" % (cyc.value / nnz0 if nnz0 else 0.0), "", "", "",
                   "BoomerAMG Iterations = %d" % its.value,
                   "Final Relative Residual Norm = %e" % rel.value, ""]
+    elif opt.solver == 3:
+        its.value, rel.value = solve_gmres(opt, s, A, db, dx, comm=comm)
+        lines += ["", "GMRES Iterations = %d" % its.value, "Final GMRES Relative Residual Norm = %e" % rel.value, ""]
     else:
         L.HYPRE_BoomerAMGSetTol(s, 0.0)
         L.HYPRE_BoomerAMGSetMaxIter(s, opt.precon_cycles)
@@ -382,6 +386,27 @@ def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
     if rank == 0:
         out.write("\n".join(lines) + "\n")
         out.flush()
+    return its.value, rel.value
+
+
+def solve_gmres(opt, amg, A, b, x, comm=0):
+    """test/ij.c:6715-6790, 6919-6925, 7190-7215: AMG-GMRES (solver 3)."""
+    L = B.load_library()
+    L.HYPRE_BoomerAMGSetTol(amg, 0.0)
+    L.HYPRE_BoomerAMGSetMaxIter(amg, opt.precon_cycles)
+    g = C.c_void_p()
+    L.HYPRE_ParCSRGMRESCreate(comm, C.byref(g))
+    L.HYPRE_GMRESSetKDim(g, opt.k_dim)
+    L.HYPRE_GMRESSetMaxIter(g, opt.max_iter)
+    L.HYPRE_GMRESSetTol(g, opt.tol)
+    L.HYPRE_GMRESSetAbsoluteTol(g, 0.0)
+    L.HYPRE_GMRESSetPrecond(g, C.cast(L.HYPRE_BoomerAMGSolve, C.c_void_p), None, amg)
+    L.HYPRE_ParCSRGMRESSetup(g, A, b, x)
+    L.HYPRE_ParCSRGMRESSolve(g, A, b, x)
+    its, rel = C.c_int(), C.c_double()
+    L.HYPRE_GMRESGetNumIterations(g, C.byref(its))
+    L.HYPRE_GMRESGetFinalRelativeResidualNorm(g, C.byref(rel))
+    L.HYPRE_ParCSRGMRESDestroy(g)
     return its.value, rel.value
 
 

@@ -332,6 +332,27 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
 HYPRE_Int HYPRE_PCGGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
 HYPRE_Int HYPRE_PCGGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
 
+/* ---- GMRES with BoomerAMG as right preconditioner (`ij -solver 3`) ----
+ * krylov/gmres.c:274-1000, krylov/HYPRE_gmres.c, parcsr_ls/HYPRE_parcsr_gmres.c; defaults of
+ * hypre_GMRESCreate (gmres.c:68-110): k_dim 5, tol 1e-6, max_iter 1000.  SetKDim must precede Setup
+ * (Setup allocates the k_dim + 1 basis vectors, gmres.c:204-215).  HYPRE_ERROR_CONV when max_iter is
+ * reached above the tolerance (gmres.c:982-985). */
+HYPRE_Int HYPRE_ParCSRGMRESCreate(MPI_Comm comm, HYPRE_Solver *solver);
+HYPRE_Int HYPRE_ParCSRGMRESDestroy(HYPRE_Solver solver);
+HYPRE_Int HYPRE_GMRESSetKDim(HYPRE_Solver solver, HYPRE_Int k_dim);
+HYPRE_Int HYPRE_GMRESSetTol(HYPRE_Solver solver, HYPRE_Real tol);
+HYPRE_Int HYPRE_GMRESSetAbsoluteTol(HYPRE_Solver solver, HYPRE_Real a_tol);
+HYPRE_Int HYPRE_GMRESSetMinIter(HYPRE_Solver solver, HYPRE_Int min_iter);
+HYPRE_Int HYPRE_GMRESSetMaxIter(HYPRE_Solver solver, HYPRE_Int max_iter);
+HYPRE_Int HYPRE_GMRESSetSkipRealResidualCheck(HYPRE_Solver solver, HYPRE_Int skip_real_r_check);
+HYPRE_Int HYPRE_GMRESSetPrecond(HYPRE_Solver solver, HYPRE_PtrToSolverFcn precond,
+                                HYPRE_PtrToSolverFcn precond_setup, HYPRE_Solver precond_solver);
+HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x);
+HYPRE_Int HYPRE_GMRESGetNumIterations(HYPRE_Solver solver, HYPRE_Int *num_iterations);
+HYPRE_Int HYPRE_GMRESGetFinalRelativeResidualNorm(HYPRE_Solver solver, HYPRE_Real *norm);
+HYPRE_Int HYPRE_GMRESGetConverged(HYPRE_Solver solver, HYPRE_Int *converged);
+
 #ifdef __cplusplus
 }
 #endif

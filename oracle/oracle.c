@@ -979,3 +979,141 @@ int oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, do
    free(p); free(s); free(r);
    return i;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Right-preconditioned restarted GMRES with the AMG cycle as preconditioner  */
+/* (krylov/gmres.c:274-1000 with the defaults rel_change = 0, cf_tol = 0,     */
+/* skip_real_r_check = 0, min_iter = 0, hybrid = 0; modified Gram-Schmidt,    */
+/* Givens rotations, true-residual check before accepting convergence).      */
+/* Returns the iteration count; *rel_resid_out = |r| / |b| as the driver      */
+/* prints it ("Final GMRES Relative Residual Norm").                          */
+/* ------------------------------------------------------------------------- */
+int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
+                     int k_dim, int precond_cycles, double *rel_resid_out, int *converged_out)
+{
+   const opar *A = &amg->A[0];
+   const long long n = A->row_starts[A->nranks];
+   const double epsmac = 1.e-16;
+   double **p = (double **) calloc((size_t) k_dim + 1, sizeof(double *));
+   double **hh = (double **) calloc((size_t) k_dim + 1, sizeof(double *));
+   double *rs = (double *) calloc((size_t) k_dim + 1, sizeof(double));
+   double *c = (double *) calloc((size_t) k_dim, sizeof(double));
+   double *sn = (double *) calloc((size_t) k_dim, sizeof(double));
+   double *r = (double *) calloc((size_t) n, sizeof(double));
+   double *w = (double *) calloc((size_t) n, sizeof(double));
+   double b_norm, r_norm, den_norm, epsilon, t, gamma, real_r_norm_old, real_r_norm_new;
+   int i = 0, j, k, iter = 0, converged = 0;
+   for (i = 0; i <= k_dim; i++)
+   {
+      p[i] = (double *) calloc((size_t) n, sizeof(double));
+      hh[i] = (double *) calloc((size_t) k_dim, sizeof(double));
+   }
+
+#define PRECOND(rhs, sol)                                                                  \
+   do {                                                                                    \
+      for (long long q_ = 0; q_ < n; q_++) { (sol)[q_] = 0.0; }                            \
+      oracle_amg_solve(amg, (rhs), (sol), 0.0, 0, precond_cycles, 0, 1, NULL, NULL, NULL); \
+   } while (0)
+
+   memcpy(p[0], b, sizeof(double) * (size_t) n);
+   oracle_par_matvec(-1.0, A, x, 1.0, p[0], p[0]);
+   b_norm = sqrt(oracle_inner_prod(b, b, n));
+   real_r_norm_old = b_norm;
+   r_norm = sqrt(oracle_inner_prod(p[0], p[0], n));
+   den_norm = (b_norm > 0.0) ? b_norm : r_norm;
+   epsilon = (a_tol > r_tol * den_norm) ? a_tol : r_tol * den_norm;
+
+   i = 0;
+   while (iter < max_iter)
+   {
+      rs[0] = r_norm;
+      if (r_norm == 0.0) { break; }
+      if (r_norm <= epsilon)
+      {
+         memcpy(r, b, sizeof(double) * (size_t) n);
+         oracle_par_matvec(-1.0, A, x, 1.0, r, r);
+         r_norm = sqrt(oracle_inner_prod(r, r, n));
+         if (r_norm <= epsilon) { break; }
+      }
+      t = 1.0 / r_norm;
+      oracle_scale(t, p[0], n);
+      i = 0;
+      while (i < k_dim && iter < max_iter)
+      {
+         i++;
+         iter++;
+         PRECOND(p[i - 1], r);
+         oracle_par_matvec(1.0, A, r, 0.0, p[i], p[i]);
+         for (j = 0; j < i; j++)
+         {
+            hh[j][i - 1] = oracle_inner_prod(p[j], p[i], n);
+            oracle_axpy(-hh[j][i - 1], p[j], p[i], n);
+         }
+         t = sqrt(oracle_inner_prod(p[i], p[i], n));
+         hh[i][i - 1] = t;
+         if (t != 0.0) { t = 1.0 / t; oracle_scale(t, p[i], n); }
+         for (j = 1; j < i; j++)
+         {
+            t = hh[j - 1][i - 1];
+            hh[j - 1][i - 1] = sn[j - 1] * hh[j][i - 1] + c[j - 1] * t;
+            hh[j][i - 1] = -sn[j - 1] * t + c[j - 1] * hh[j][i - 1];
+         }
+         t = hh[i][i - 1] * hh[i][i - 1];
+         t += hh[i - 1][i - 1] * hh[i - 1][i - 1];
+         gamma = sqrt(t);
+         if (gamma == 0.0) { gamma = epsmac; }
+         c[i - 1] = hh[i - 1][i - 1] / gamma;
+         sn[i - 1] = hh[i][i - 1] / gamma;
+         rs[i] = -hh[i][i - 1] * rs[i - 1];
+         rs[i] /= gamma;
+         rs[i - 1] = c[i - 1] * rs[i - 1];
+         hh[i - 1][i - 1] = sn[i - 1] * hh[i][i - 1] + c[i - 1] * hh[i - 1][i - 1];
+         r_norm = fabs(rs[i]);
+         if (r_norm <= epsilon) { break; }
+      }
+      /* solve the upper triangular system, form the update */
+      rs[i - 1] = rs[i - 1] / hh[i - 1][i - 1];
+      for (k = i - 2; k >= 0; k--)
+      {
+         t = 0.0;
+         for (j = k + 1; j < i; j++) { t -= hh[k][j] * rs[j]; }
+         t += rs[k];
+         rs[k] = t / hh[k][k];
+      }
+      memcpy(w, p[i - 1], sizeof(double) * (size_t) n);
+      oracle_scale(rs[i - 1], w, n);
+      for (j = i - 2; j >= 0; j--) { oracle_axpy(rs[j], p[j], w, n); }
+      PRECOND(w, r);
+      oracle_axpy(1.0, r, x, n);
+      if (r_norm <= epsilon)
+      {
+         memcpy(r, b, sizeof(double) * (size_t) n);
+         oracle_par_matvec(-1.0, A, x, 1.0, r, r);
+         real_r_norm_new = r_norm = sqrt(oracle_inner_prod(r, r, n));
+         if (r_norm <= epsilon) { converged = 1; break; }
+         if (real_r_norm_new >= real_r_norm_old) { converged = 1; break; }
+         memcpy(p[0], r, sizeof(double) * (size_t) n);
+         i = 0;
+         real_r_norm_old = real_r_norm_new;
+      }
+      /* residual vector of the restart */
+      for (j = i; j > 0; j--)
+      {
+         rs[j - 1] = -sn[j - 1] * rs[j];
+         rs[j] = c[j - 1] * rs[j];
+      }
+      if (i) { oracle_axpy(rs[i] - 1.0, p[i], p[i], n); }
+      for (j = i - 1; j > 0; j--) { oracle_axpy(rs[j], p[j], p[i], n); }
+      if (i)
+      {
+         oracle_axpy(rs[0] - 1.0, p[0], p[0], n);
+         oracle_axpy(1.0, p[i], p[0], n);
+      }
+   }
+#undef PRECOND
+   if (rel_resid_out) { *rel_resid_out = (b_norm > 0.0) ? r_norm / b_norm : r_norm; }
+   if (converged_out) { *converged_out = converged; }
+   for (i = 0; i <= k_dim; i++) { free(p[i]); free(hh[i]); }
+   free(p); free(hh); free(rs); free(c); free(sn); free(r); free(w);
+   return iter;
+}

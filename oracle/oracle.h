@@ -79,4 +79,7 @@ int    oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol,
                         double *resid_hist);
 int    oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
                       int two_norm, int precond_cycles, double *rel_resid_out, int *converged_out);
+/* krylov/gmres.c:274-1000: right-preconditioned GMRES(k_dim), defaults of hypre_GMRESCreate */
+int    oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
+                        int k_dim, int precond_cycles, double *rel_resid_out, int *converged_out);
 #endif

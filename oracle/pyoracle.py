@@ -89,6 +89,9 @@ def load():
     L.oracle_pcg_amg.restype = C.c_int
     L.oracle_pcg_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                  RealP, IntP]
+    L.oracle_gmres_amg.restype = C.c_int
+    L.oracle_gmres_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                   RealP, IntP]
     _lib = L
     return L
 
@@ -233,6 +236,15 @@ class Amg:
         conv = C.c_int(0)
         its = L.oracle_pcg_amg(C.byref(self.c), _rp(b), _rp(x), tol, atol, max_iter, two_norm, precond_cycles,
                                C.byref(rel), C.byref(conv))
+        return its, rel.value, conv.value
+
+    def gmres(self, b, x, tol=1e-8, atol=0.0, max_iter=1000, k_dim=5, precond_cycles=1):
+        L = load()
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        rel = C.c_double(0.0)
+        conv = C.c_int(0)
+        its = L.oracle_gmres_amg(C.byref(self.c), _rp(b), _rp(x), tol, atol, max_iter, k_dim, precond_cycles,
+                                 C.byref(rel), C.byref(conv))
         return its, rel.value, conv.value
 
 

@@ -76,6 +76,9 @@ def main():
             its, rel = C.c_int(), C.c_double()
             L.HYPRE_BoomerAMGGetNumIterations(s, C.byref(its))
             L.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+        elif opt.solver == 3:
+            its, rel = C.c_int(), C.c_double()
+            its.value, rel.value = ij.solve_gmres(opt, s, A, db, dx, comm=comm)
         else:
             L.HYPRE_BoomerAMGSetTol(s, 0.0)
             L.HYPRE_BoomerAMGSetMaxIter(s, opt.precon_cycles)
@@ -110,6 +113,10 @@ def main():
         if opt.solver == 0:
             its, rel, conv, hist = amg.solve(bg, xg, tol=opt.tol, max_iter=opt.mg_max_iter)
             out.update(iterations=its, rel_resid=rel, conv_factor=(hist[-1] / hist[0]) ** (1.0 / max(its, 1)))
+        elif opt.solver == 3:
+            its, rel, conv = amg.gmres(bg, xg, tol=opt.tol, max_iter=opt.max_iter, k_dim=opt.k_dim,
+                                       precond_cycles=opt.precon_cycles)
+            out.update(iterations=its, rel_resid=rel)
         else:
             its, rel, conv = amg.pcg(bg, xg, tol=opt.tol, max_iter=opt.max_iter, two_norm=opt.two_norm,
                                      precond_cycles=opt.precon_cycles)

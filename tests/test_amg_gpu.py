@@ -249,6 +249,45 @@ def _pcg_on_device(lib, mixed=False, **kw):
     return its.value, rel.value
 
 
+@pytest.mark.parametrize("kw", [dict(n=(12, 11, 10), relax_type=18, coarsen_type=8),
+                                dict(n=(12, 11, 10), relax_type=18, coarsen_type=8, k_dim=3, precon_cycles=2),
+                                dict(n=(10, 10, 10)),
+                                dict(n=(9, 9, 9), problem="difconv", a=(10.0, 10.0, 10.0), relax_type=7, tol=1e-10)])
+def test_gmres_on_device_matches_oracle(gpu_lib, oracle, kw):
+    """AMG-GMRES (krylov/gmres.c:274-1000) on the device against the oracle's restatement: same iteration
+    count (restarts included: k_dim 3 / 5), same final residual, same solution — also on a nonsymmetric
+    convection-diffusion operator, where PCG does not apply."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt, A, s = _setup(lib, solver=3, **kw)
+    amg = oracle.amg_from_solvers([s])
+    b, x0 = ij.build_rhs_host(opt, A)
+    dx, db = B.parvec_from_numpy(x0), B.parvec_from_numpy(b)
+    its, rel = ij.solve_gmres(opt, s, A, db, dx)
+    B.check()
+    xo = x0.copy()
+    oits, orel, _ = amg.gmres(b, xo, tol=opt.tol, max_iter=opt.max_iter, k_dim=opt.k_dim, precond_cycles=opt.precon_cycles)
+    assert its == oits and its > opt.k_dim - 2
+    assert abs(rel - orel) <= 1e-6 * orel + 5e-15        # relative residuals near 1e-10 carry the rounding of |b|-sized sums
+    xd = B.parvec_to_numpy(dx)
+    assert np.max(np.abs(xd - xo)) <= 1e-9 * np.max(np.abs(xo))
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+def test_gmres_reports_non_convergence(gpu_lib):
+    """gmres.c:982-985: HYPRE_ERROR_CONV when max_iter is hit above the tolerance."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt, A, s = _setup(lib, solver=3, n=(10, 10, 10), relax_type=18, coarsen_type=8, max_iter=2)
+    b, x0 = ij.build_rhs_host(opt, A)
+    dx, db = B.parvec_from_numpy(x0), B.parvec_from_numpy(b)
+    its, rel = ij.solve_gmres(opt, s, A, db, dx)
+    assert its == 2 and rel > opt.tol
+    assert lib.HYPRE_GetError() & 256
+    lib.HYPRE_ClearAllErrors()
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
 def test_golden_fsai103_pcg_relax7_on_device(gpu_lib):
     """TEST_ij/fsai.saved:89-91 — `ij -n 10 10 10 -solver 1 -rlx 7`: 22 iterations, 7.480945e-09."""
     its, rel = _pcg_on_device(gpu_lib, n=(10, 10, 10), relax_type=7)

@@ -54,15 +54,15 @@ def _replay(case, timeout=600):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
                                   "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24",
-                                  "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405"])
+                                  "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405", "solvers.out.24"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
     exp = case["expect"]
     if "iterations" in exp:
-        label = "Iterations" if " -solver 1" in " " + case["cmd"] else "BoomerAMG Iterations"
+        label = {1: "Iterations", 3: "GMRES Iterations"}.get(case["options"].get("solver", 0), "BoomerAMG Iterations")
         assert re.search(r"^%s = %d$" % (label, exp["iterations"]), out, re.M), out
-        m = re.search(r"^Final Relative Residual Norm = (\S+)$", out, re.M)
+        m = re.search(r"^Final %sRelative Residual Norm = (\S+)$" % ("GMRES " if label.startswith("GMRES") else ""), out, re.M)
         assert m and abs(float(m.group(1)) - exp["rel_resid"]) <= 1.5e-6 * exp["rel_resid"], out
     if "conv_factor" in exp:
         # the reference's own layout and precision (par_amg_solve.c:411-414)
