@@ -69,6 +69,7 @@ void destroy_replicated_tail(hypre_ParAMGData *d);
 // distributed setup pieces (par_amg_setup_dist.cpp)
 HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
                                   HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts,
+                                  const HYPRE_Int *dof_func,   // function of every local row, or nullptr (scalar problem)
                                   HYPRE_Real trunc_factor, HYPRE_Int max_elmts, hypre_ParCSRMatrix **P_ptr);
 HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
                                      HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr);

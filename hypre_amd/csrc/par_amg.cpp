@@ -154,6 +154,13 @@ HYPRE_Int HYPRE_BoomerAMGSetTruncFactor(HYPRE_Solver s, HYPRE_Real v)
 HYPRE_Int HYPRE_BoomerAMGSetPMaxElmts(HYPRE_Solver s, HYPRE_Int v)
 { AMG_DATA(s, d); if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; } d->P_max_elmts = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->keepTranspose = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetNumFunctions(HYPRE_Solver s, HYPRE_Int v)
+{
+   AMG_DATA(s, d);
+   if (v < 1) { hypre_error_in_arg(2); return hypre_error_flag; }      // par_amg.c hypre_BoomerAMGSetNumFunctions
+   d->num_functions = v;
+   return hypre_error_flag;
+}
 HYPRE_Int HYPRE_BoomerAMGSetTol(HYPRE_Solver s, HYPRE_Real v)
 { AMG_DATA(s, d); if (v < 0 || v > 1) { hypre_error_in_arg(2); return hypre_error_flag; } d->tol = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGSetMaxIter(HYPRE_Solver s, HYPRE_Int v)

@@ -182,7 +182,7 @@ struct RowMarker
 extern "C" {
 
 // ===========================================================================
-// strength of connection (par_strength.c:75-530, num_functions == 1)
+// strength of connection (par_strength.c:75-530)
 // S keeps, per row and in A's stored order, the off-diagonal columns j with
 //   a_ij < theta * min_k a_ik   (a_ii >= 0)   or   a_ij > theta * max_k a_ik   (a_ii < 0);
 // rows whose |row sum| exceeds max_row_sum*|a_ii| keep nothing.
@@ -190,10 +190,9 @@ extern "C" {
 HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_Real max_row_sum,
                                  HYPRE_Int num_functions, HYPRE_Int *dof_func, hypre_ParCSRMatrix **S_ptr)
 {
-   (void) dof_func;
-   if (num_functions > 1)
+   if (num_functions > 1 && !dof_func)
    {
-      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCreateS: systems (num_functions > 1) are out of scope");
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCreateS: num_functions > 1 needs the function of every row");
       return hypre_error_flag;
    }
    hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
@@ -205,6 +204,18 @@ HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_
    hypre_ParCSRMatrix *S = hypre_ParCSRMatrixCreate(A->comm, A->global_num_rows, A->global_num_rows,
                                                     A->row_starts, A->row_starts, nco, 0, 0);
    std::vector<HYPRE_Int> sdi((size_t) n + 1, 0), soi((size_t) n + 1, 0);
+   // systems, unknown approach (par_strength.c:177-222, 248-290, 343-403): couplings between different
+   // functions neither scale the threshold nor count as strong
+   const bool sys = num_functions > 1;
+   std::vector<HYPRE_Int> dof_offd;
+   if (sys && nco)
+   {
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      dof_offd.resize((size_t) nco);
+      halo_forward<HYPRE_Int>(A->comm_pkg, dof_func, dof_offd.data());
+   }
+   auto same_d = [&](HYPRE_Int i, HYPRE_Int k) { return !sys || dof_func[i] == dof_func[Adj[k]]; };
+   auto same_o = [&](HYPRE_Int i, HYPRE_Int k) { return !sys || dof_func[i] == dof_offd[(size_t) Aoj[k]]; };
    // pass 1: per-row counts, pass 2: fill (both row-parallel)
    std::vector<char> keep_d((size_t) Adi[n]), keep_o((size_t) Aoi[n]);
 #pragma omp parallel for schedule(static)
@@ -214,13 +225,13 @@ HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_
       HYPRE_Real row_scale = 0.0, row_sum = diag;
       if (diag < 0)
       {
-         for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { row_scale = std::max(row_scale, Ada[k]); row_sum += Ada[k]; }
-         for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { row_scale = std::max(row_scale, Aoa[k]); row_sum += Aoa[k]; }
+         for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { if (same_d(i, k)) { row_scale = std::max(row_scale, Ada[k]); row_sum += Ada[k]; } }
+         for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { if (same_o(i, k)) { row_scale = std::max(row_scale, Aoa[k]); row_sum += Aoa[k]; } }
       }
       else
       {
-         for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { row_scale = std::min(row_scale, Ada[k]); row_sum += Ada[k]; }
-         for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { row_scale = std::min(row_scale, Aoa[k]); row_sum += Aoa[k]; }
+         for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++) { if (same_d(i, k)) { row_scale = std::min(row_scale, Ada[k]); row_sum += Ada[k]; } }
+         for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++) { if (same_o(i, k)) { row_scale = std::min(row_scale, Aoa[k]); row_sum += Aoa[k]; } }
       }
       HYPRE_Int cd = 0, co = 0;
       if (Adi[i + 1] > Adi[i]) { keep_d[(size_t) Adi[i]] = 0; }
@@ -228,13 +239,13 @@ HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_
       for (HYPRE_Int k = Adi[i] + 1; k < Adi[i + 1]; k++)
       {
          bool strong = false;
-         if (!all_weak) { strong = diag < 0 ? !(Ada[k] <= theta * row_scale) : !(Ada[k] >= theta * row_scale); }
+         if (!all_weak) { strong = (diag < 0 ? !(Ada[k] <= theta * row_scale) : !(Ada[k] >= theta * row_scale)) && same_d(i, k); }
          keep_d[(size_t) k] = strong; cd += strong;
       }
       for (HYPRE_Int k = Aoi[i]; k < Aoi[i + 1]; k++)
       {
          bool strong = false;
-         if (!all_weak) { strong = diag < 0 ? !(Aoa[k] <= theta * row_scale) : !(Aoa[k] >= theta * row_scale); }
+         if (!all_weak) { strong = (diag < 0 ? !(Aoa[k] <= theta * row_scale) : !(Aoa[k] >= theta * row_scale)) && same_o(i, k); }
          keep_o[(size_t) k] = strong; co += strong;
       }
       sdi[(size_t) i + 1] = cd; soi[(size_t) i + 1] = co;
@@ -754,7 +765,13 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
                                           HYPRE_Int *dof_func, HYPRE_Int debug_flag, HYPRE_Real trunc_factor,
                                           HYPRE_Int max_elmts, hypre_ParCSRMatrix **P_ptr)
 {
-   (void) num_functions; (void) dof_func; (void) debug_flag;
+   (void) debug_flag;
+   if (num_functions > 1 && !dof_func)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildExtPIInterp: num_functions > 1 needs the function of every row");
+      return hypre_error_flag;
+   }
+   const bool sys = num_functions > 1;
    MPI_Comm comm = A->comm;
    if (comm_size(comm) > 1)
    {
@@ -762,7 +779,7 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       const hypre_amd_CommOps *o = comm_ops(comm);
       std::vector<HYPRE_BigInt> ends((size_t) o->size);
       o->allgather(o->ctx, &num_cpts_global[1], ends.data(), sizeof(HYPRE_BigInt));
-      return dist_build_extpi_interp(A, CF_marker, S, num_cpts_global, ends.back(), trunc_factor, max_elmts, P_ptr);
+      return dist_build_extpi_interp(A, CF_marker, S, num_cpts_global, ends.back(), sys ? dof_func : nullptr, trunc_factor, max_elmts, P_ptr);
    }
    hypre_CSRMatrix *Ad = A->diag;
    const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
@@ -857,7 +874,8 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
                   }
                   else { diagonal += Aa[jj]; }
                }
-               else if (CF_marker[i1] != -3) { diagonal += Aa[jj]; }
+               // weak neighbour: lumped into the diagonal, within the same function only (par_lr_interp.c:1706-1713)
+               else if (CF_marker[i1] != -3) { if (!sys || dof_func[i] == dof_func[i1]) { diagonal += Aa[jj]; } }
             }
             if (diagonal) { for (size_t k = (size_t) begin; k < pj.size(); k++) { pa[k] /= -diagonal; } }
             strong_f--;
@@ -903,7 +921,12 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
                                         HYPRE_Int *dof_func, HYPRE_Int debug_flag, HYPRE_Real trunc_factor,
                                         HYPRE_Int max_elmts, HYPRE_Int interp_type, hypre_ParCSRMatrix **P_ptr)
 {
-   (void) num_functions; (void) dof_func; (void) debug_flag; (void) interp_type;
+   (void) dof_func; (void) debug_flag; (void) interp_type;
+   if (num_functions > 1)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildDirInterp: systems (num_functions > 1) are supported with interp_type 6 only");
+      return hypre_error_flag;
+   }
    MPI_Comm comm = A->comm;
    if (comm_size(comm) > 1)
    {
@@ -1345,6 +1368,16 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       hypre_IntArrayInitialize_v2(d->CF_marker_array[0], HYPRE_MEMORY_HOST);
       for (HYPRE_Int i = 0; i < A->diag->num_rows; i++) { d->CF_marker_array[0]->data[i] = 1; }
    }
+   // systems, unknown approach: function of every row; (first row + i) mod num_functions unless the rows
+   // say otherwise (par_amg_setup.c:752-771), C-points carry theirs to the next level (par_coarse_parms.c)
+   std::vector<HYPRE_Int> dof_func;
+   if (d->num_functions > 1)
+   {
+      const HYPRE_Int n0 = A->diag->num_rows;
+      const HYPRE_Int offset = (HYPRE_Int) (A->first_row_index % (HYPRE_BigInt) d->num_functions);
+      dof_func.resize((size_t) n0);
+      for (HYPRE_Int i = 0; i < n0; i++) { dof_func[(size_t) i] = (i + offset) % d->num_functions; }
+   }
    while (not_finished)
    {
       hypre_ParCSRMatrix *Al = hostA[(size_t) level];
@@ -1356,7 +1389,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       }
       hypre_ParCSRMatrix *S = nullptr;
       const double t_s0 = omp_get_wtime();
-      hypre_BoomerAMGCreateS(Al, d->strong_threshold, d->max_row_sum, 1, nullptr, &S);
+      HYPRE_Int *dofs = d->num_functions > 1 ? dof_func.data() : nullptr;
+      hypre_BoomerAMGCreateS(Al, d->strong_threshold, d->max_row_sum, d->num_functions, dofs, &S);
       const double t_s1 = omp_get_wtime();
       const HYPRE_Int nloc = Al->diag->num_rows;
       d->CF_marker_array[level] = hypre_IntArrayCreate(nloc);
@@ -1374,6 +1408,11 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       HYPRE_Int *CF = d->CF_marker_array[level]->data;
       HYPRE_BigInt cpts[2];
       coarse_parms(comm, nloc, CF, cpts, &coarse_size);
+      std::vector<HYPRE_Int> coarse_dof_func;
+      if (d->num_functions > 1)
+      {
+         for (HYPRE_Int i = 0; i < nloc; i++) { if (CF[i] == 1) { coarse_dof_func.push_back(dof_func[(size_t) i]); } }
+      }
       if (coarse_size == 0 || coarse_size == fine_size)
       {
          // no coarse grid: one sweep of the default smoother on the last level (par_amg_setup.c:1655-1690)
@@ -1410,11 +1449,11 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       hypre_ParCSRMatrix *P = nullptr;
       if (d->interp_type == 6)
       {
-         hypre_BoomerAMGBuildExtPIInterp(Al, CF, S, cpts, 1, nullptr, 0, d->trunc_factor, d->P_max_elmts, &P);
+         hypre_BoomerAMGBuildExtPIInterp(Al, CF, S, cpts, d->num_functions, dofs, 0, d->trunc_factor, d->P_max_elmts, &P);
       }
       else if (d->interp_type == 3)
       {
-         hypre_BoomerAMGBuildDirInterp(Al, CF, S, cpts, 1, nullptr, 0, d->trunc_factor, d->P_max_elmts, 0, &P);
+         hypre_BoomerAMGBuildDirInterp(Al, CF, S, cpts, d->num_functions, dofs, 0, d->trunc_factor, d->P_max_elmts, 0, &P);
       }
       else
       {
@@ -1435,6 +1474,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       }
       if (!AH || hypre_error_flag) { break; }
       ++level;
+      dof_func.swap(coarse_dof_func);
       hostA[(size_t) level] = AH;
       d->A_array[level] = AH;
       // (par_amg_setup.c:3128-3136) switch to plain CLJP-free coarsening when the grid barely shrinks

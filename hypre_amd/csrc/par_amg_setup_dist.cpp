@@ -152,11 +152,19 @@ namespace hamd {
 // ===========================================================================
 HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
                                   HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts,
-                                  HYPRE_Real trunc_factor, HYPRE_Int max_elmts, hypre_ParCSRMatrix **P_ptr)
+                                  const HYPRE_Int *dof_func, HYPRE_Real trunc_factor, HYPRE_Int max_elmts,
+                                  hypre_ParCSRMatrix **P_ptr)
 {
    MPI_Comm comm = A->comm;
    if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
    hypre_ParCSRCommPkg *pkg = A->comm_pkg;
+   // systems: functions of the ghost columns of A (par_lr_interp.c:1706-1713, 1781-1787 need no more)
+   std::vector<HYPRE_Int> dof_offd;
+   if (dof_func && A->offd->num_cols)
+   {
+      dof_offd.resize((size_t) A->offd->num_cols);
+      halo_fwd<HYPRE_Int>(pkg, dof_func, dof_offd.data(), 11);
+   }
    hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
    const HYPRE_Int *Adi = Ad->i, *Adj = Ad->j, *Aoi = Ao->i, *Aoj = Ao->j;
    const HYPRE_Real *Ada = Ad->data, *Aoa = Ao->data;
@@ -342,7 +350,7 @@ HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, h
                }
                else { diagonal += Ada[jj]; }
             }
-            else if (CF_marker[i1] != -3) { diagonal += Ada[jj]; }
+            else if (CF_marker[i1] != -3) { if (!dof_func || dof_func[i] == dof_func[i1]) { diagonal += Ada[jj]; } }
          }
          for (HYPRE_Int jj = Aoi[i]; jj < Aoi[i + 1]; jj++)
          {
@@ -386,7 +394,7 @@ HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, h
                }
                else { diagonal += Aoa[jj]; }
             }
-            else if (CF_offd[(size_t) i1] != -3) { diagonal += Aoa[jj]; }
+            else if (CF_offd[(size_t) i1] != -3) { if (!dof_func || dof_func[i] == dof_offd[(size_t) i1]) { diagonal += Aoa[jj]; } }
          }
          if (diagonal)
          {

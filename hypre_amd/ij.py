@@ -52,6 +52,7 @@ class IJOptions:
         self.precon_cycles = 1
         self.keep_transpose = 1
         self.num_threads = 1
+        self.num_functions = 1        # -nf (systems of PDEs, unknown approach)
         self.ns_down = self.ns_up = self.ns_coarse = -1   # -ns_down / -ns_up / -ns_coarse
         self.level_w = None           # -wl  value level
         self.level_ow = None          # -owl value level
@@ -225,6 +226,7 @@ def create_amg(opt, memory_location=DEVICE):
     L.HYPRE_BoomerAMGSetMaxRowSum(s, opt.max_row_sum)
     L.HYPRE_BoomerAMGSetMaxIter(s, opt.mg_max_iter)
     L.HYPRE_BoomerAMGSetKeepTranspose(s, opt.keep_transpose)
+    L.HYPRE_BoomerAMGSetNumFunctions(s, opt.num_functions)
     for k, sweeps in ((1, opt.ns_down), (2, opt.ns_up), (3, opt.ns_coarse)):
         if sweeps > -1:
             L.HYPRE_BoomerAMGSetCycleNumSweeps(s, sweeps, k)
@@ -256,7 +258,7 @@ _VALUE_FLAGS = {
     "-tr": ("trunc_factor", float, 1), "-Pmx": ("P_max_elmts", int, 1), "-interptype": ("interp_type", int, 1),
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
-    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1),
+    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nf": ("num_functions", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
     "-cheby_fraction": ("cheby_fraction", float, 1),

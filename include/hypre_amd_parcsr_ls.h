@@ -184,6 +184,10 @@ HYPRE_Int HYPRE_BoomerAMGSetInterpType(HYPRE_Solver solver, HYPRE_Int interp_typ
 HYPRE_Int HYPRE_BoomerAMGSetTruncFactor(HYPRE_Solver solver, HYPRE_Real trunc_factor);
 HYPRE_Int HYPRE_BoomerAMGSetPMaxElmts(HYPRE_Solver solver, HYPRE_Int P_max_elmts);
 HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver solver, HYPRE_Int keepTranspose);
+/* systems of PDEs, "unknown" approach (HYPRE_parcsr_amg.c HYPRE_BoomerAMGSetNumFunctions; par_strength.c:248-403,
+ * par_lr_interp.c:1706-1713): row i belongs to function (global row) mod num_functions, couplings between
+ * different functions are neither strong nor lumped.  ext+i interpolation only. */
+HYPRE_Int HYPRE_BoomerAMGSetNumFunctions(HYPRE_Solver solver, HYPRE_Int num_functions);
 /* Chebyshev smoother parameters (HYPRE_parcsr_amg.c:1340-1400 -> par_amg.c:4583-4670) */
 HYPRE_Int HYPRE_BoomerAMGSetChebyOrder(HYPRE_Solver solver, HYPRE_Int order);
 HYPRE_Int HYPRE_BoomerAMGSetChebyFraction(HYPRE_Solver solver, HYPRE_Real ratio);
