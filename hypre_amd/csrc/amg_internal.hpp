@@ -12,6 +12,7 @@ struct AmgPrivate
 {
    int  emulated_threads = 1;      // thread count the thread-partitioned host loops emulate
    bool mixed_precision  = false;
+   bool filter_functions = false;  // systems: build the hierarchy from A without its inter-function couplings
    // per-level overrides of the smoother weights (HYPRE_BoomerAMGSetLevelRelaxWt / SetLevelOuterWt),
    // applied over the uniform values when setup fills relax_weight[] / omega[]
    std::vector<std::pair<int, double>> level_relax_wt, level_outer_wt;

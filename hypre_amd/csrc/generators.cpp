@@ -151,4 +151,54 @@ HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt 
    return assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value);
 }
 
+// Systems version of the 7-point operator: num_fun unknowns per grid point, A = L (x) mtrx with the unknowns
+// of a point numbered consecutively (par_laplace.c:380-848).  Every row keeps the scalar row's block order
+// [centre, -z, -y, -x, +x, +y, +z], num_fun entries per block (zeros of mtrx are stored); in the rows of
+// function j > 0 the first entry of the centre block and the diagonal entry trade places (:818-832).
+HYPRE_ParCSRMatrix GenerateSysLaplacian(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
+                                        HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
+                                        HYPRE_Int r, HYPRE_Int num_fun, HYPRE_Real *mtrx, HYPRE_Real *value)
+{
+   if (num_fun < 1 || !mtrx) { hypre_error_in_arg(11); return nullptr; }
+   hypre_ParCSRMatrix *L = GenerateLaplacian(comm, nx, ny, nz, P, Q, R, p, q, r, value);
+   if (!L) { return nullptr; }
+   const HYPRE_Int nf = num_fun, ng = L->diag->num_rows, nco = L->offd->num_cols;
+   const HYPRE_Int *Ldi = L->diag->i, *Ldj = L->diag->j, *Loi = L->offd->i, *Loj = L->offd->j;
+   const HYPRE_Real *Lda = L->diag->data, *Loa = L->offd->data;
+   std::vector<HYPRE_Int> di((size_t) ng * nf + 1, 0), oi((size_t) ng * nf + 1, 0);
+   std::vector<HYPRE_Int> dj((size_t) Ldi[ng] * nf * nf), oj((size_t) Loi[ng] * nf * nf);
+   std::vector<HYPRE_Real> da(dj.size()), oa(oj.size());
+   size_t dp = 0, op = 0;
+   for (HYPRE_Int g = 0; g < ng; g++)
+   {
+      for (HYPRE_Int i = 0; i < nf; i++)
+      {
+         const size_t row_begin = dp;
+         for (HYPRE_Int k = Ldi[g]; k < Ldi[g + 1]; k++)
+         {
+            for (HYPRE_Int j = 0; j < nf; j++) { dj[dp] = Ldj[k] * nf + j; da[dp++] = Lda[k] * mtrx[i * nf + j]; }
+         }
+         if (i > 0) { std::swap(dj[row_begin], dj[row_begin + (size_t) i]); std::swap(da[row_begin], da[row_begin + (size_t) i]); }
+         for (HYPRE_Int k = Loi[g]; k < Loi[g + 1]; k++)
+         {
+            for (HYPRE_Int j = 0; j < nf; j++) { oj[op] = Loj[k] * nf + j; oa[op++] = Loa[k] * mtrx[i * nf + j]; }
+         }
+         di[(size_t) g * nf + i + 1] = (HYPRE_Int) dp;
+         oi[(size_t) g * nf + i + 1] = (HYPRE_Int) op;
+      }
+   }
+   std::vector<HYPRE_BigInt> cmap((size_t) nco * nf);
+   for (HYPRE_Int c = 0; c < nco; c++)
+   {
+      for (HYPRE_Int j = 0; j < nf; j++) { cmap[(size_t) c * nf + j] = L->col_map_offd[c] * nf + j; }
+   }
+   HYPRE_BigInt part[2] = {L->row_starts[0] * nf, L->row_starts[1] * nf};
+   const HYPRE_BigInt gsize = L->global_num_rows * nf;
+   hypre_ParCSRMatrix *A = hypre_amd_ParCSRMatrixFromArrays(comm, gsize, gsize, part, part, (HYPRE_Int) cmap.size(), cmap.data(),
+                                                            di.data(), dj.data(), da.data(), oi.data(), oj.data(), oa.data(),
+                                                            HYPRE_MEMORY_HOST);
+   hypre_ParCSRMatrixDestroy(L);
+   return A;
+}
+
 }  // extern "C"

@@ -154,6 +154,13 @@ HYPRE_Int HYPRE_BoomerAMGSetTruncFactor(HYPRE_Solver s, HYPRE_Real v)
 HYPRE_Int HYPRE_BoomerAMGSetPMaxElmts(HYPRE_Solver s, HYPRE_Int v)
 { AMG_DATA(s, d); if (v < 0) { hypre_error_in_arg(2); return hypre_error_flag; } d->P_max_elmts = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->keepTranspose = v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetFilterFunctions(HYPRE_Solver s, HYPRE_Int v)
+{
+   AMG_DATA(s, d);
+   if (v < 0 || v > 1) { hypre_error_in_arg(2); return hypre_error_flag; }      // par_amg.c:3232-3250
+   ((AmgPrivate *) d->amd_private)->filter_functions = v != 0;
+   return hypre_error_flag;
+}
 HYPRE_Int HYPRE_BoomerAMGSetNumFunctions(HYPRE_Solver s, HYPRE_Int v)
 {
    AMG_DATA(s, d);

@@ -1312,6 +1312,48 @@ HYPRE_Int hypre_GaussElimSetup(hypre_ParAMGData *d, HYPRE_Int level, HYPRE_Int r
 // ===========================================================================
 // the level loop (par_amg_setup.c:28-3560 reduced to the in-scope options)
 // ===========================================================================
+// A without the couplings between different functions (parcsr_mv/par_csr_filter.c:21-186): entry (i, j) stays
+// when i and j are the same unknown of their grid points (equal index modulo block_size); ghost columns that lose
+// all their entries leave the column map.
+static hypre_ParCSRMatrix *blk_filter(hypre_ParCSRMatrix *A, HYPRE_Int block_size)
+{
+   if (A->global_num_rows % block_size || A->row_starts[0] % block_size || A->global_num_rows != A->global_num_cols)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "block size must divide the number of rows and the first row of every rank (square matrices only)");
+      return nullptr;
+   }
+   const hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
+   const HYPRE_Int n = Ad->num_rows, nco = Ao->num_cols;
+   std::vector<HYPRE_Int> di((size_t) n + 1, 0), oi((size_t) n + 1, 0), dj, oj;
+   std::vector<HYPRE_Real> da, oa;
+   std::vector<char> used((size_t) std::max(nco, 1), 0);
+   for (HYPRE_Int i = 0; i < n; i++)
+   {
+      const HYPRE_Int c = i % block_size;
+      for (HYPRE_Int k = Ad->i[i]; k < Ad->i[i + 1]; k++)
+      {
+         if (c == Ad->j[k] % block_size) { dj.push_back(Ad->j[k]); da.push_back(Ad->data[k]); }
+      }
+      for (HYPRE_Int k = Ao->i[i]; k < Ao->i[i + 1]; k++)
+      {
+         if (c == (HYPRE_Int) (A->col_map_offd[Ao->j[k]] % (HYPRE_BigInt) block_size))
+         {
+            oj.push_back(Ao->j[k]); oa.push_back(Ao->data[k]); used[(size_t) Ao->j[k]] = 1;
+         }
+      }
+      di[(size_t) i + 1] = (HYPRE_Int) dj.size();
+      oi[(size_t) i + 1] = (HYPRE_Int) oj.size();
+   }
+   std::vector<HYPRE_Int> renum((size_t) std::max(nco, 1), -1);
+   std::vector<HYPRE_BigInt> cmap;
+   for (HYPRE_Int c = 0; c < nco; c++) { if (used[(size_t) c]) { renum[(size_t) c] = (HYPRE_Int) cmap.size(); cmap.push_back(A->col_map_offd[c]); } }
+   for (HYPRE_Int &c : oj) { c = renum[(size_t) c]; }
+   hypre_ParCSRMatrix *Bm = hypre_amd_ParCSRMatrixFromArrays(A->comm, A->global_num_rows, A->global_num_cols, A->row_starts,
+                                                             A->col_starts, (HYPRE_Int) cmap.size(), cmap.data(), di.data(),
+                                                             dj.data(), da.data(), oi.data(), oj.data(), oa.data(), HYPRE_MEMORY_HOST);
+   return Bm;
+}
+
 static hypre_ParVector *new_vec(MPI_Comm comm, HYPRE_BigInt gsize, HYPRE_BigInt *part, HYPRE_MemoryLocation loc)
 {
    hypre_ParVector *v = hypre_ParVectorCreate(comm, gsize, part);
@@ -1355,6 +1397,17 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    std::vector<hypre_ParCSRMatrix *> hostA((size_t) max_levels, nullptr);
    const bool A_on_device = A->diag->memory_location == HYPRE_MEMORY_DEVICE;
    hostA[0] = A_on_device ? hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST) : A;
+   bool own_host_A0 = A_on_device;
+   if (d->num_functions > 1 && pv->filter_functions)
+   {
+      // par_amg_setup.c:774-780: the hierarchy (S, P, coarse operators, smoother diagonals) comes from the filtered
+      // matrix; the solve phase still smooths with the caller's A on level 0 (par_amg_solve.c:109)
+      hypre_ParCSRMatrix *At = blk_filter(hostA[0], d->num_functions);
+      if (!At) { if (own_host_A0) { hypre_ParCSRMatrixDestroy(hostA[0]); } return hypre_error_flag; }
+      if (own_host_A0) { hypre_ParCSRMatrixDestroy(hostA[0]); }
+      hostA[0] = At;
+      own_host_A0 = true;
+   }
    d->A_array[0] = A;
    if (hostA[0]->d_num_nonzeros < 0) { hypre_ParCSRMatrixSetDNumNonzeros(hostA[0]); A->d_num_nonzeros = hostA[0]->d_num_nonzeros; }
 
@@ -1648,12 +1701,12 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       hypre_ParVectorMigrate(d->Ztemp, HYPRE_MEMORY_DEVICE);
       if (d->Ptemp) { hypre_ParVectorMigrate(d->Ptemp, HYPRE_MEMORY_DEVICE); }
       if (d->Rtemp) { hypre_ParVectorMigrate(d->Rtemp, HYPRE_MEMORY_DEVICE); }
-      if (A_on_device) { hypre_ParCSRMatrixDestroy(hostA[0]); }
    }
    else
    {
       for (int l = 0; l < num_levels - 1; l++) { hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]); }
    }
+   if (own_host_A0) { hypre_ParCSRMatrixDestroy(hostA[0]); }
    return hypre_error_flag;
 }
 

@@ -20,6 +20,7 @@ class IJOptions:
         self.n = (10, 10, 10)
         self.P = None                 # (P, Q, R); default (1, nprocs, 1)
         self.problem = "laplacian"    # laplacian | 27pt | difconv
+        self.sys_num_fun = 1          # -sysL <num functions>: systems version of the 7-point operator
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
         self.solver = 0               # 0 AMG, 1 AMG-PCG, 3 AMG-GMRES
@@ -53,6 +54,7 @@ class IJOptions:
         self.keep_transpose = 1
         self.num_threads = 1
         self.num_functions = 1        # -nf (systems of PDEs, unknown approach)
+        self.filter_functions = 0     # -ff
         self.ns_down = self.ns_up = self.ns_coarse = -1   # -ns_down / -ns_up / -ns_coarse
         self.level_w = None           # -wl  value level
         self.level_ow = None          # -owl value level
@@ -122,6 +124,18 @@ def build_matrix(opt, comm=0, rank=0, nprocs=1):
     p, q, r = rank % P, (rank // P) % Q, rank // (P * Q)
     kind = {"laplacian": "7pt", "27pt": "27pt", "difconv": "difconv"}[opt.problem]
     nx, ny, nz = opt.n
+    if opt.sys_num_fun > 1:
+        # test/ij.c:9718-9870: coupling matrix of -sysL_opt 0
+        mtrx = {2: [2.0, 1.0, 1.0, 2.0], 3: [2.0, 1.0, 0.0, 1.0, 2.0, 1.0, 0.0, 1.0, 2.0]}.get(opt.sys_num_fun)
+        if mtrx is None or opt.problem != "laplacian":
+            raise ValueError("-sysL supports 2 or 3 functions of the 7-point operator")
+        L = B.load_library()
+        vals = np.ascontiguousarray(stencil_values(opt), dtype=np.float64)
+        m = np.ascontiguousarray(mtrx, dtype=np.float64)
+        A = L.GenerateSysLaplacian(comm, nx, ny, nz, P, Q, R, p, q, r, opt.sys_num_fun,
+                                   m.ctypes.data_as(C.POINTER(C.c_double)), vals.ctypes.data_as(C.POINTER(C.c_double)))
+        B.check()
+        return A
     return B.laplacian(nx, ny, nz, P, Q, R, p, q, r, comm=comm, values=stencil_values(opt), kind=kind)
 
 
@@ -227,6 +241,7 @@ def create_amg(opt, memory_location=DEVICE):
     L.HYPRE_BoomerAMGSetMaxIter(s, opt.mg_max_iter)
     L.HYPRE_BoomerAMGSetKeepTranspose(s, opt.keep_transpose)
     L.HYPRE_BoomerAMGSetNumFunctions(s, opt.num_functions)
+    L.HYPRE_BoomerAMGSetFilterFunctions(s, opt.filter_functions)
     for k, sweeps in ((1, opt.ns_down), (2, opt.ns_up), (3, opt.ns_coarse)):
         if sweeps > -1:
             L.HYPRE_BoomerAMGSetCycleNumSweeps(s, sweeps, k)
@@ -259,6 +274,7 @@ _VALUE_FLAGS = {
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
     "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nf": ("num_functions", int, 1),
+    "-sysL": ("sys_num_fun", int, 1), "-ff": ("filter_functions", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
     "-cheby_fraction": ("cheby_fraction", float, 1),

@@ -188,6 +188,9 @@ HYPRE_Int HYPRE_BoomerAMGSetKeepTranspose(HYPRE_Solver solver, HYPRE_Int keepTra
  * par_lr_interp.c:1706-1713): row i belongs to function (global row) mod num_functions, couplings between
  * different functions are neither strong nor lumped.  ext+i interpolation only. */
 HYPRE_Int HYPRE_BoomerAMGSetNumFunctions(HYPRE_Solver solver, HYPRE_Int num_functions);
+/* par_amg.c:3232-3250, par_amg_setup.c:774-780, parcsr_mv/par_csr_filter.c:21-186: with num_functions > 1, build
+ * the hierarchy from A without its inter-function couplings (`ij -ff 1`); level 0 is still smoothed with A */
+HYPRE_Int HYPRE_BoomerAMGSetFilterFunctions(HYPRE_Solver solver, HYPRE_Int filter_functions);
 /* Chebyshev smoother parameters (HYPRE_parcsr_amg.c:1340-1400 -> par_amg.c:4583-4670) */
 HYPRE_Int HYPRE_BoomerAMGSetChebyOrder(HYPRE_Solver solver, HYPRE_Int order);
 HYPRE_Int HYPRE_BoomerAMGSetChebyFraction(HYPRE_Solver solver, HYPRE_Real ratio);

@@ -251,6 +251,12 @@ HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt 
                                    HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
                                    HYPRE_Int r, HYPRE_Real *value);
 
+/* par_laplace.c:380-848: num_fun unknowns per grid point, A = (7-point operator) (x) mtrx[num_fun x num_fun]
+ * (`ij -sysL num_fun`; the driver's coupling matrices are in test/ij.c:9718-9870) */
+HYPRE_ParCSRMatrix GenerateSysLaplacian(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
+                                        HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
+                                        HYPRE_Int r, HYPRE_Int num_fun, HYPRE_Real *mtrx, HYPRE_Real *value);
+
 /* ---- binding conveniences (plain pointers in / out; used by the Python host
  * layer and the tests, the way an application would use the IJ interface) ---- */
 hypre_CSRMatrix *hypre_amd_CSRMatrixFromArrays(HYPRE_Int num_rows, HYPRE_Int num_cols, HYPRE_Int nnz,

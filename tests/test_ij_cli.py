@@ -54,7 +54,7 @@ def _replay(case, timeout=600):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
                                   "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24",
-                                  "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405", "solvers.out.24"])
+                                  "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405", "solvers.out.24", "solvers.out.28"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
