@@ -9,6 +9,7 @@
 // par_difconv.c; seq_mv/genpart.c:18-40 (partitioning).
 #include "internal.hpp"
 #include <algorithm>
+#include <cmath>
 
 namespace {
 
@@ -149,6 +150,19 @@ HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt 
    static const std::vector<StencilPt> st = {
       {0, 0, 0, 0}, {0, 0, -1, 3}, {0, -1, 0, 2}, {-1, 0, 0, 1}, {1, 0, 0, 4}, {0, 1, 0, 5}, {0, 0, 1, 6}};
    return assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value);
+}
+
+// Rotated anisotropic diffusion in 2-D, 7-point stencil [centre, SW, S, W, E, N, NE] (par_rotate_7pt.c:15-397):
+// -(c^2 + eps s^2) u_xx + 2 (1 - eps) s c u_xy - (s^2 + eps c^2) u_yy with s, c = sin, cos of alpha degrees.
+HYPRE_ParCSRMatrix GenerateRotate7pt(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_Int P, HYPRE_Int Q,
+                                     HYPRE_Int p, HYPRE_Int q, HYPRE_Real alpha, HYPRE_Real eps)
+{
+   const HYPRE_Real pi = 4.0 * std::atan(1.0), x = pi * alpha / 180.0, s = std::sin(x), c = std::cos(x);
+   const HYPRE_Real ac = -(c * c + eps * s * s), bc = 2.0 * (1.0 - eps) * s * c, cc = -(s * s + eps * c * c);
+   HYPRE_Real value[4] = {-2 * (2 * ac + bc + 2 * cc), 2 * ac + bc, bc + 2 * cc, -bc};
+   static const std::vector<StencilPt> st = {
+      {0, 0, 0, 0}, {-1, -1, 0, 3}, {0, -1, 0, 2}, {-1, 0, 0, 1}, {1, 0, 0, 1}, {0, 1, 0, 2}, {1, 1, 0, 3}};
+   return assemble(comm, nx, ny, 1, P, Q, 1, p, q, 0, st, value);
 }
 
 // Systems version of the 7-point operator: num_fun unknowns per grid point, A = L (x) mtrx with the unknowns

@@ -19,7 +19,9 @@ class IJOptions:
     def __init__(self, **kw):
         self.n = (10, 10, 10)
         self.P = None                 # (P, Q, R); default (1, nprocs, 1)
-        self.problem = "laplacian"    # laplacian | 27pt | difconv
+        self.problem = "laplacian"    # laplacian | 27pt | difconv | rotate
+        self.alpha = 1.0              # -alpha (rotate: angle in degrees; test/ij.c:11147)
+        self.eps = 0.0                # -eps   (rotate: anisotropy)
         self.sys_num_fun = 1          # -sysL <num functions>: systems version of the 7-point operator
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
@@ -122,6 +124,13 @@ def build_matrix(opt, comm=0, rank=0, nprocs=1):
     if P * Q * R != nprocs:
         raise ValueError("P*Q*R must equal the number of ranks")
     p, q, r = rank % P, (rank // P) % Q, rank // (P * Q)
+    if opt.problem == "rotate":
+        # test/ij.c:11130-11240 BuildParRotate7pt: a 2-D problem, -n and -P read two values each
+        if R != 1:
+            raise ValueError("-rotate is two-dimensional: R must be 1")
+        A = B.load_library().GenerateRotate7pt(comm, opt.n[0], opt.n[1], P, Q, p, q, opt.alpha, opt.eps)
+        B.check()
+        return A
     kind = {"laplacian": "7pt", "27pt": "27pt", "difconv": "difconv"}[opt.problem]
     nx, ny, nz = opt.n
     if opt.sys_num_fun > 1:
@@ -274,7 +283,7 @@ _VALUE_FLAGS = {
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
     "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nf": ("num_functions", int, 1),
-    "-sysL": ("sys_num_fun", int, 1), "-ff": ("filter_functions", int, 1),
+    "-alpha": ("alpha", float, 1), "-eps": ("eps", float, 1), "-sysL": ("sys_num_fun", int, 1), "-ff": ("filter_functions", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
     "-cheby_fraction": ("cheby_fraction", float, 1),
@@ -284,7 +293,7 @@ _VALUE_FLAGS = {
 }
 _SWITCH_FLAGS = {
     "-laplacian": ("problem", "laplacian"), "-27pt": ("problem", "27pt"), "-difconv": ("problem", "difconv"),
-    "-rhsrand": ("rhs", "rand"), "-rhsisone": ("rhs", "one"), "-xisone": ("rhs", "xisone"),
+    "-rotate": ("problem", "rotate"), "-rhsrand": ("rhs", "rand"), "-rhsisone": ("rhs", "one"), "-xisone": ("rhs", "xisone"),
     "-pmis": ("coarsen_type", 8), "-pmis1": ("coarsen_type", 9), "-hmis": ("coarsen_type", 10),
     "-fmg": ("fcycle", 1), "-amd_mixed": ("mixed", True),
 }

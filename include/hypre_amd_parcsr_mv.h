@@ -251,6 +251,9 @@ HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt 
                                    HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
                                    HYPRE_Int r, HYPRE_Real *value);
 
+/* par_rotate_7pt.c:15-397 (`ij -rotate -alpha a -eps e -n nx ny 1 -P P Q 1`) */
+HYPRE_ParCSRMatrix GenerateRotate7pt(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_Int P, HYPRE_Int Q,
+                                     HYPRE_Int p, HYPRE_Int q, HYPRE_Real alpha, HYPRE_Real eps);
 /* par_laplace.c:380-848: num_fun unknowns per grid point, A = (7-point operator) (x) mtrx[num_fun x num_fun]
  * (`ij -sysL num_fun`; the driver's coupling matrices are in test/ij.c:9718-9870) */
 HYPRE_ParCSRMatrix GenerateSysLaplacian(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
