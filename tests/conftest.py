@@ -31,3 +31,12 @@ def oracle():
     import pyoracle
     pyoracle.load()
     return pyoracle
+
+
+def free_port():
+    """A TCP port nobody is listening on right now (the kernel picks it), for a torch.distributed rendezvous on
+    127.0.0.1: fixed or hashed port numbers can collide between tests and leave a rank waiting for a store."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]

@@ -11,13 +11,12 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "ij_saved.json")))
-_port = [29700]
 
 
 def run_ranks(nranks, case, timeout=240, extra=None):
-    _port[0] += 1
+    from conftest import free_port
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(_port[0]), os.path.join(HERE, "dist_worker.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
            json.dumps(dict({"options": case["options"]}, **(extra or {})))]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)

@@ -37,12 +37,13 @@ def test_out_of_scope_flags_are_refused():
 
 def _replay(case, timeout=600):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    from conftest import free_port
     args = case["cmd"].split()
     if case["np"] == 1:
         cmd = [sys.executable, "-m", "hypre_amd.ij"] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(case["np"]),
-               "--master-addr", "127.0.0.1", "--master-port", str(29600 + (abs(hash(case["cmd"])) % 300)),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
                "-m", "hypre_amd.ij"] + args
     # jobs that read matrix files run where the reference's input files were copied (test/TEST_ij layout)
     cwd = os.path.join(HERE, "golden", "ij_files") if "-fromfile" in args else ROOT
