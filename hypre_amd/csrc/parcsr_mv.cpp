@@ -576,9 +576,30 @@ HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlaceDevice(HYPRE_Complex alpha, hypre_Pa
    HYPRE_AMD_REQUIRE_DEVICE(xl->memory_location, "hypre_ParCSRMatrixMatvec(x)");
    HYPRE_AMD_REQUIRE_DEVICE(yl->memory_location, "hypre_ParCSRMatrixMatvec(y)");
    HYPRE_AMD_REQUIRE_DEVICE(bl->memory_location, "hypre_ParCSRMatrixMatvec(b)");
-   if (xl->num_vectors != 1 || yl->num_vectors != 1)
+   if (xl->num_vectors != 1 || yl->num_vectors != 1 || bl->num_vectors != 1)
    {
-      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRMatrixMatvec: multivectors are not supported by the distributed product");
+      // column-major multivectors (par_csr_matvec.c:146-165 asserts idxstride == 1 as well): one product per column,
+      // each with its own halo exchange
+      const HYPRE_Int nv = xl->num_vectors;
+      if (yl->num_vectors != nv || bl->num_vectors != nv || xl->idxstride != 1 || yl->idxstride != 1 || bl->idxstride != 1)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRMatrixMatvec: multivectors must agree in num_vectors and be stored column by column");
+         return hypre_error_flag;
+      }
+      const int saved = handle().sync_compute;
+      handle().sync_compute = 0;
+      for (HYPRE_Int v = 0; v < nv; v++)
+      {
+         hypre_Vector xv = *xl, bv = *bl, yv = *yl;
+         xv.data += (size_t) v * xl->vecstride; xv.num_vectors = 1;
+         bv.data += (size_t) v * bl->vecstride; bv.num_vectors = 1;
+         yv.data += (size_t) v * yl->vecstride; yv.num_vectors = 1;
+         hypre_ParVector xp = *x, bp = *b, yp = *y;
+         xp.local_vector = &xv; bp.local_vector = &bv; yp.local_vector = &yv;
+         hypre_ParCSRMatrixMatvecOutOfPlaceDevice(alpha, A, &xp, beta, b == y ? &yp : &bp, &yp);
+      }
+      handle().sync_compute = saved;
+      maybe_sync();
       return hypre_error_flag;
    }
    const HYPRE_Int num_cols_offd = offd->num_cols;
@@ -654,6 +675,29 @@ HYPRE_Int hypre_ParCSRMatrixMatvecTDevice(HYPRE_Complex alpha, hypre_ParCSRMatri
    HYPRE_AMD_REQUIRE_DEVICE(diag->memory_location, "hypre_ParCSRMatrixMatvecT(A)");
    HYPRE_AMD_REQUIRE_DEVICE(xl->memory_location, "hypre_ParCSRMatrixMatvecT(x)");
    HYPRE_AMD_REQUIRE_DEVICE(yl->memory_location, "hypre_ParCSRMatrixMatvecT(y)");
+   if (xl->num_vectors != 1 || yl->num_vectors != 1)
+   {
+      const HYPRE_Int nv = xl->num_vectors;
+      if (yl->num_vectors != nv || xl->idxstride != 1 || yl->idxstride != 1)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRMatrixMatvecT: multivectors must agree in num_vectors and be stored column by column");
+         return hypre_error_flag;
+      }
+      const int saved = handle().sync_compute;
+      handle().sync_compute = 0;
+      for (HYPRE_Int v = 0; v < nv; v++)
+      {
+         hypre_Vector xv = *xl, yv = *yl;
+         xv.data += (size_t) v * xl->vecstride; xv.num_vectors = 1;
+         yv.data += (size_t) v * yl->vecstride; yv.num_vectors = 1;
+         hypre_ParVector xp = *x, yp = *y;
+         xp.local_vector = &xv; yp.local_vector = &yv;
+         hypre_ParCSRMatrixMatvecTDevice(alpha, A, &xp, beta, &yp);
+      }
+      handle().sync_compute = saved;
+      maybe_sync();
+      return hypre_error_flag;
+   }
    const HYPRE_Int num_cols_offd = offd->num_cols;
    HYPRE_Int nprocs;
    hypre_MPI_Comm_size(A->comm, &nprocs);

@@ -150,3 +150,67 @@ def test_blas1(gpu_lib, oracle):
     gpu_lib.hypre_SeqVectorElmdivpy(dx, dd, dy)
     assert np.allclose(B.vec_to_numpy(dy), ybefore + x / d, rtol=0, atol=1e-14)
     B.check()
+
+
+def _multivector(B, X, par=False):
+    """Column-major device multivector (seq_mv/vector.h:22-40: vecstride = size, idxstride = 1) holding the columns
+    of X; built as one long vector whose header is then re-shaped."""
+    n, nv = X.shape
+    flat = np.ascontiguousarray(X.T).ravel()
+    if par:
+        pv = B.parvec_from_numpy(flat, global_size=n)
+        pv.contents.partitioning[1] = n
+        pv.contents.last_index = n - 1
+        pv.contents.actual_local_size = n
+        v = pv.contents.local_vector
+    else:
+        pv = v = B.vec_from_numpy(flat)
+    v.contents.size, v.contents.num_vectors, v.contents.vecstride, v.contents.idxstride = n, nv, n, 1
+    return pv, v
+
+
+def _columns(B, v):
+    s = v.contents
+    flat = B.fetch(s.data, s.size * s.num_vectors, np.float64, s.memory_location)
+    return flat.reshape(s.num_vectors, s.size).T
+
+
+@pytest.mark.parametrize("par", [False, True])
+def test_multivectors_column_by_column(gpu_lib, oracle, par):
+    """csr_matvec.c:117-380 / par_csr_matvec.c:146-165: NV = 3 right-hand sides in one call, y = alpha A X + beta B and
+    Y = alpha A^T X + beta Y, each column equal to the single-vector product."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = laplace_3d(7, 6, 5)
+    n, nv = A.shape[0], 3
+    X = np.stack([rand_vector(n, 10 + k) for k in range(nv)], axis=1)
+    Bm = np.stack([rand_vector(n, 20 + k) for k in range(nv)], axis=1)
+    px, vx = _multivector(B, X, par)
+    pb, vb = _multivector(B, Bm, par)
+    py, vy = _multivector(B, np.zeros((n, nv)), par)
+    if par:
+        ii, jj, aa = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+        lapl = B.laplacian(7, 6, 5)
+        lib.hypre_ParCSRMatrixMigrate(lapl, B.HYPRE_MEMORY_DEVICE)
+        lib.hypre_ParCSRMatrixMatvecOutOfPlace(0.7, lapl, px, -1.3, pb, py)
+    else:
+        dA = B.csr_from_scipy(A)
+        lib.hypre_CSRMatrixMatvecOutOfPlace(0.7, dA, vx, -1.3, vb, vy, 0)
+    B.check()
+    Y = _columns(B, vy)
+    oA = oracle.Csr.from_scipy(A)
+    for k in range(nv):
+        yr = np.zeros(n)
+        oracle.csr_matvec(0.7, oA, X[:, k].copy(), -1.3, Bm[:, k].copy(), yr)
+        assert np.all(np.abs(Y[:, k] - yr) <= _bound(A, X[:, k], 0.7, -1.3, Bm[:, k]))
+    # transpose product, in place
+    if par:
+        lib.hypre_ParCSRMatrixMatvecT(-0.4, lapl, px, 0.5, pb)
+    else:
+        lib.hypre_CSRMatrixMatvecT(-0.4, dA, vx, 0.5, vb)
+    B.check()
+    Z = _columns(B, vb)
+    for k in range(nv):
+        zr = Bm[:, k].copy()
+        oracle.csr_matvecT(-0.4, oA, X[:, k].copy(), 0.5, zr)
+        assert np.all(np.abs(Z[:, k] - zr) <= _bound(A.T.tocsr(), X[:, k], -0.4, 0.5, Bm[:, k]))
