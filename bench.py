@@ -88,12 +88,12 @@ def main():
             dist.init_process_group(backend="cpu:gloo,cuda:nccl",
                                     device_id=None if share else torch.device("cuda", local_rank))
 
-    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1" and "HYPRE_AMD_BENCH_KEEP_OMP" not in os.environ:
-        # torch.distributed.run pins every rank to one OpenMP thread; the host-side AMG setup of this rank may use its
-        # share of the cores instead (the library's OpenMP runtime reads the variable when it is loaded, below)
-        os.environ["OMP_NUM_THREADS"] = str(max(1, len(os.sched_getaffinity(0)) // world))
     from hypre_amd import binding as B, ij
     L = B.load_library()          # raises when the HIP library is missing: no fallback exists
+    if world > 1 and "HYPRE_AMD_BENCH_KEEP_OMP" not in os.environ:
+        # torch.distributed.run pins every rank to one OpenMP thread; the host-side AMG setup of this rank may use its
+        # share of the node's cores instead
+        L.hypre_amd_SetHostThreads(max(1, L.hypre_amd_HostCpuShare() // world))
     if not L.hypre_amd_DeviceAvailable():
         raise SystemExit("bench.py needs a HIP device")
 

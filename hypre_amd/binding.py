@@ -125,6 +125,8 @@ PROTOTYPES = {
     "HYPRE_GetErrorArg": (Int, []),
     "hypre_amd_LastErrorMessage": (C.c_char_p, []),
     "HYPRE_Initialize": (Int, []),
+    "hypre_amd_HostCpuShare": (Int, []),
+    "hypre_amd_SetHostThreads": (Int, [Int]),
     "HYPRE_Finalize": (Int, []),
     "HYPRE_SetMemoryLocation": (Int, [Int]),
     "HYPRE_GetMemoryLocation": (Int, [IntP]),

@@ -68,6 +68,7 @@ struct Handle
 Handle &handle();
 const hypre_amd_CommOps *comm_ops(MPI_Comm comm);   // nullptr for an invalid handle
 bool    ensure_device();                 // lazily creates streams; false if no GPU
+int     host_cpu_share();                // cores this process may use: affinity mask cut by a cgroup CPU quota
 hipStream_t stream();                    // compute stream
 void    maybe_sync();                    // honours hypre_SetSyncCudaCompute
 double *reduce_scratch(size_t n);        // >= n doubles of device scratch

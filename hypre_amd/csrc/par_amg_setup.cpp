@@ -94,6 +94,7 @@ struct HypreRand
 
 inline int num_threads_avail() { return omp_get_max_threads(); }
 
+
 // contiguous row chunk of thread t out of T
 inline void chunk(int n, int T, int t, int *b, int *e)
 {
@@ -1431,9 +1432,14 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       dof_func.resize((size_t) n0);
       for (HYPRE_Int i = 0; i < n0; i++) { dof_func[(size_t) i] = (i + offset) % d->num_functions; }
    }
+   // host threads: no more than the cores this process owns, and no more than a level's rows can keep busy
+   const int saved_omp_threads = omp_get_max_threads();
+   const int thread_cap = std::max(1, std::min(saved_omp_threads, host_cpu_share()));
+   omp_set_num_threads(thread_cap);
    while (not_finished)
    {
       hypre_ParCSRMatrix *Al = hostA[(size_t) level];
+      omp_set_num_threads(std::max(1, std::min(thread_cap, Al->diag->num_rows / 4096)));
       fine_size = Al->global_num_rows;
       if (level > 0)
       {
@@ -1539,6 +1545,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          not_finished = false;
       }
    }
+   omp_set_num_threads(thread_cap);
    const int num_levels = level + 1;
    d->num_levels = num_levels;
    if (num_levels > 1 && !d->F_array[num_levels - 1])
@@ -1707,6 +1714,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       for (int l = 0; l < num_levels - 1; l++) { hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]); }
    }
    if (own_host_A0) { hypre_ParCSRMatrixDestroy(hostA[0]); }
+   omp_set_num_threads(saved_omp_threads);
    return hypre_error_flag;
 }
 

@@ -3,6 +3,13 @@
 // utilities/memory.c (hypre_MAlloc/hypre_Free/hypre_Memcpy), utilities/general.c
 // (HYPRE_Initialize, HYPRE_SetMemoryLocation, hypre_SetSyncCudaCompute).
 #include "internal.hpp"
+#include <omp.h>
+#include <sched.h>
+#include <unistd.h>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
 #include <string>
 
 extern "C" {
@@ -43,6 +50,39 @@ Handle &handle()
 {
    static Handle h;
    return h;
+}
+
+// Cores this process may really use: the affinity mask, cut by a cgroup CPU quota when one is set (a container on
+// a 256-thread host is often limited to a handful of cores while OpenMP still sees all of them; 256 threads on 16
+// cores made the setup of a 37-row level cost 0.9 s).  HYPRE_AMD_SETUP_THREADS overrides.
+int host_cpu_share()
+{
+   static int cached = 0;
+   if (cached > 0) { return cached; }
+   int n = (int) sysconf(_SC_NPROCESSORS_ONLN);
+   cpu_set_t set;
+   if (sched_getaffinity(0, sizeof set, &set) == 0) { n = std::min(n, CPU_COUNT(&set)); }
+   long long quota = -1, period = 0;
+   if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r"))                      // cgroup v2: "max 100000" or "<quota> <period>"
+   {
+      char q[64] = {0};
+      if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) { quota = atoll(q); }
+      fclose(f);
+   }
+   else
+   {
+      if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) { quota = -1; } fclose(g); }
+      if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) { period = 0; } fclose(g); }
+   }
+   if (quota > 0 && period > 0) { n = (int) std::min<long long>(n, std::max<long long>(1, (quota + period - 1) / period)); }
+   if (const char *e = getenv("HYPRE_AMD_SETUP_THREADS")) { if (atoi(e) > 0) { n = atoi(e); } }
+   cached = std::max(1, n);
+   return cached;
+}
+
+namespace {
+// host loops (setup, cached transposes, comm packages) never use more OpenMP threads than the process owns cores
+struct OmpCap { OmpCap() { if (omp_get_max_threads() > host_cpu_share()) { omp_set_num_threads(host_cpu_share()); } } } omp_cap_at_load;
 }
 
 bool ensure_device()
@@ -118,6 +158,15 @@ HYPRE_Int HYPRE_GetMemoryLocation(HYPRE_MemoryLocation *loc) { *loc = handle().m
 HYPRE_Int HYPRE_SetExecutionPolicy(HYPRE_ExecutionPolicy p) { handle().exec_policy = p; return hypre_error_flag; }
 HYPRE_Int HYPRE_GetExecutionPolicy(HYPRE_ExecutionPolicy *p) { *p = handle().exec_policy; return hypre_error_flag; }
 
+// host threads of the library's OpenMP loops (AMG setup, cached transposes): the share of cores this process
+// owns, and a setter for launchers that split a node between several ranks
+HYPRE_Int hypre_amd_HostCpuShare(void) { return hamd::host_cpu_share(); }
+HYPRE_Int hypre_amd_SetHostThreads(HYPRE_Int n)
+{
+   if (n < 1) { hypre_error_in_arg(1); return hypre_error_flag; }
+   omp_set_num_threads(n);
+   return hypre_error_flag;
+}
 HYPRE_Int hypre_SetSyncCudaCompute(HYPRE_Int action) { handle().sync_compute = action; return hypre_error_flag; }
 HYPRE_Int hypre_GetSyncCudaCompute(HYPRE_Int *p) { *p = handle().sync_compute; return hypre_error_flag; }
 HYPRE_Int hypre_SyncComputeStream(void)

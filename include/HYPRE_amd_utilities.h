@@ -101,6 +101,12 @@ HYPRE_Int HYPRE_GetExecutionPolicy(HYPRE_ExecutionPolicy *exec_policy);
 HYPRE_Int hypre_amd_DeviceAvailable(void);
 /* whether public device ops end with a stream synchronise (default 1);
  * utilities/general.c hypre_SetSyncCudaCompute */
+/* Host threads of the library's OpenMP loops (AMG setup, cached transposes).  At load the library limits itself to
+ * the cores the process owns (affinity mask cut by a cgroup CPU quota); a launcher that runs several ranks per node
+ * gives each its part with hypre_amd_SetHostThreads(hypre_amd_HostCpuShare() / ranks_per_node).  No reference
+ * counterpart (hypre takes OMP_NUM_THREADS as it finds it). */
+HYPRE_Int hypre_amd_HostCpuShare(void);
+HYPRE_Int hypre_amd_SetHostThreads(HYPRE_Int num_threads);
 HYPRE_Int hypre_SetSyncCudaCompute(HYPRE_Int action);
 HYPRE_Int hypre_GetSyncCudaCompute(HYPRE_Int *cuda_compute_stream_sync_ptr);
 HYPRE_Int hypre_SyncComputeStream(void);
