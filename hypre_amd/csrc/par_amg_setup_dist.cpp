@@ -11,6 +11,7 @@
 //   parcsr_ls/aux_interp.c:777-900         column map of P's off-rank block
 //   parcsr_ls/par_rap.c:30-2000            RAP with P_ext and RAP_ext
 #include "amg_internal.hpp"
+#include <omp.h>
 #include <algorithm>
 #include <cmath>
 
@@ -254,12 +255,21 @@ HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, h
    halo_fwd<HYPRE_BigInt>(pkg, f2c_big.data(), f2c_offd.data(), 21);
    halo_fwd<HYPRE_BigInt>(&ext_pkg, f2c_big.data(), f2c_offd.data() + nco, 21);
 
-   // ---- rows of P (sequential over rows; markers as in the reference) -------------------
-   std::vector<HYPRE_Int> Pdi((size_t) n + 1, 0), Poi((size_t) n + 1, 0), pdj, poj;
-   std::vector<HYPRE_Real> pda, poa;
+   // ---- rows of P: contiguous row blocks, one per thread, each with its own markers and output (a row only
+   // reads A, S, the ghost rows and the CF / coarse-index arrays) ------------------------------------------------
+   std::vector<HYPRE_Int> Pdi((size_t) n + 1, 0), Poi((size_t) n + 1, 0);
+   const int T = std::max(1, std::min(omp_get_max_threads(), n / 2048 + 1));
+   std::vector<std::vector<HYPRE_Int>> t_pdj((size_t) T), t_poj((size_t) T);
+   std::vector<std::vector<HYPRE_Real>> t_pda((size_t) T), t_poa((size_t) T);
+#pragma omp parallel num_threads(T)
+   {
+   const int tid = omp_get_thread_num();
+   const HYPRE_Int row_b = (HYPRE_Int) ((long long) n * tid / T), row_e = (HYPRE_Int) ((long long) n * (tid + 1) / T);
+   std::vector<HYPRE_Int> &pdj = t_pdj[(size_t) tid], &poj = t_poj[(size_t) tid];
+   std::vector<HYPRE_Real> &pda = t_pda[(size_t) tid], &poa = t_poa[(size_t) tid];
    std::vector<long long> mk((size_t) std::max(n, 1), -1), mko((size_t) std::max(full_off, 1), -1);
    long long strong_f = -2;
-   for (HYPRE_Int i = 0; i < n; i++)
+   for (HYPRE_Int i = row_b; i < row_e; i++)
    {
       const long long bd = (long long) pdj.size(), bo = (long long) poj.size();
       if (CF_marker[i] >= 0) { pdj.push_back(f2c[(size_t) i]); pda.push_back(1.0); }
@@ -403,19 +413,35 @@ HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, h
          }
          strong_f--;
       }
-      Pdi[(size_t) i + 1] = (HYPRE_Int) pdj.size();
-      Poi[(size_t) i + 1] = (HYPRE_Int) poj.size();
+      Pdi[(size_t) i + 1] = (HYPRE_Int) ((long long) pdj.size() - bd);      // row lengths; offsets after the region
+      Poi[(size_t) i + 1] = (HYPRE_Int) ((long long) poj.size() - bo);
    }
+   }  // parallel region
+   for (HYPRE_Int i = 0; i < n; i++) { Pdi[(size_t) i + 1] += Pdi[(size_t) i]; Poi[(size_t) i + 1] += Poi[(size_t) i]; }
 
    HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
    hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_global_cpts, A->col_starts, cs,
-                                                    full_off, (HYPRE_Int) pdj.size(), (HYPRE_Int) poj.size());
+                                                    full_off, Pdi[(size_t) n], Poi[(size_t) n]);
    hypre_CSRMatrixInitialize_v2(P->diag, 0, HYPRE_MEMORY_HOST);
    hypre_CSRMatrixInitialize_v2(P->offd, 0, HYPRE_MEMORY_HOST);
    memcpy(P->diag->i, Pdi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
    memcpy(P->offd->i, Poi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
-   if (!pdj.empty()) { memcpy(P->diag->j, pdj.data(), sizeof(HYPRE_Int) * pdj.size()); memcpy(P->diag->data, pda.data(), sizeof(HYPRE_Real) * pda.size()); }
-   if (!poj.empty()) { memcpy(P->offd->j, poj.data(), sizeof(HYPRE_Int) * poj.size()); memcpy(P->offd->data, poa.data(), sizeof(HYPRE_Real) * poa.size()); }
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+   for (int t = 0; t < T; t++)
+   {
+      const HYPRE_Int row_b = (HYPRE_Int) ((long long) n * t / T);
+      const size_t od = (size_t) Pdi[(size_t) row_b], oo = (size_t) Poi[(size_t) row_b];
+      if (!t_pdj[(size_t) t].empty())
+      {
+         memcpy(P->diag->j + od, t_pdj[(size_t) t].data(), sizeof(HYPRE_Int) * t_pdj[(size_t) t].size());
+         memcpy(P->diag->data + od, t_pda[(size_t) t].data(), sizeof(HYPRE_Real) * t_pda[(size_t) t].size());
+      }
+      if (!t_poj[(size_t) t].empty())
+      {
+         memcpy(P->offd->j + oo, t_poj[(size_t) t].data(), sizeof(HYPRE_Int) * t_poj[(size_t) t].size());
+         memcpy(P->offd->data + oo, t_poa[(size_t) t].data(), sizeof(HYPRE_Real) * t_poa[(size_t) t].size());
+      }
+   }
    if (trunc_factor != 0.0 || max_elmts > 0) { hypre_BoomerAMGInterpTruncation(P, trunc_factor, max_elmts); }
 
    // ---- column map of the off-rank block (aux_interp.c:777-900): used ghosts, ascending coarse id
@@ -571,9 +597,16 @@ HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix 
    for (HYPRE_Int s = 0; s < nsendRT; s++) { feeds[(size_t) pkgRT->send_map_elmts[s]].push_back(s); }
 
    // ---- local rows: diagonal slot, received contributions, RA_offd*P_ext, RA_diag*P
-   std::vector<HYPRE_Int> Cdi((size_t) ncRT + 1, 0), Coi((size_t) ncRT + 1, 0), cdj, coj;
-   std::vector<HYPRE_Real> cda, coa;
+   std::vector<HYPRE_Int> Cdi((size_t) ncRT + 1, 0), Coi((size_t) ncRT + 1, 0);
+   const int T = std::max(1, std::min(omp_get_max_threads(), ncRT / 2048 + 1));
+   std::vector<std::vector<HYPRE_Int>> t_cdj((size_t) T), t_coj((size_t) T);
+   std::vector<std::vector<HYPRE_Real>> t_cda((size_t) T), t_coa((size_t) T);
+#pragma omp parallel num_threads(T)
    {
+      const int tid = omp_get_thread_num();
+      const HYPRE_Int ic_b = (HYPRE_Int) ((long long) ncRT * tid / T), ic_e = (HYPRE_Int) ((long long) ncRT * (tid + 1) / T);
+      std::vector<HYPRE_Int> &cdj = t_cdj[(size_t) tid], &coj = t_coj[(size_t) tid];
+      std::vector<HYPRE_Real> &cda = t_cda[(size_t) tid], &coa = t_coa[(size_t) tid];
       std::vector<long long> Pm((size_t) std::max(ncP + ncoRAP, 1), -1);
       std::vector<HYPRE_Int> Am((size_t) std::max(ncoA + Ad->num_cols, 1), -1);
       std::vector<HYPRE_Int> radj, raoj;
@@ -589,7 +622,7 @@ HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix 
          if (Pm[(size_t) slot] < begin) { Pm[(size_t) slot] = (long long) coj.size(); coj.push_back(col_in_rap); coa.push_back(v); }
          else { coa[(size_t) Pm[(size_t) slot]] += v; }
       };
-      for (HYPRE_Int ic = 0; ic < ncRT; ic++)
+      for (HYPRE_Int ic = ic_b; ic < ic_e; ic++)
       {
          const long long bd = (long long) cdj.size(), bo = (long long) coj.size();
          if (square) { Pm[(size_t) ic] = bd; cdj.push_back(ic); cda.push_back(0.0); }
@@ -635,18 +668,33 @@ HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix 
             for (HYPRE_Int j2 = Pd->i[i1]; j2 < Pd->i[i1 + 1]; j2++) { add_d(Pd->j[j2], rap * Pd->data[j2], bd); }
             for (HYPRE_Int j2 = Po->i[i1]; j2 < Po->i[i1 + 1]; j2++) { add_o(mapP2RAP[(size_t) Po->j[j2]], rap * Po->data[j2], bo); }
          }
-         Cdi[(size_t) ic + 1] = (HYPRE_Int) cdj.size();
-         Coi[(size_t) ic + 1] = (HYPRE_Int) coj.size();
+         Cdi[(size_t) ic + 1] = (HYPRE_Int) ((long long) cdj.size() - bd);      // row lengths; offsets below
+         Coi[(size_t) ic + 1] = (HYPRE_Int) ((long long) coj.size() - bo);
       }
    }
+   for (HYPRE_Int ic = 0; ic < ncRT; ic++) { Cdi[(size_t) ic + 1] += Cdi[(size_t) ic]; Coi[(size_t) ic + 1] += Coi[(size_t) ic]; }
    hypre_ParCSRMatrix *C = hypre_ParCSRMatrixCreate(comm, RT->global_num_cols, P->global_num_cols, RT->col_starts,
-                                                    P->col_starts, ncoRAP, (HYPRE_Int) cdj.size(), (HYPRE_Int) coj.size());
+                                                    P->col_starts, ncoRAP, Cdi[(size_t) ncRT], Coi[(size_t) ncRT]);
    hypre_CSRMatrixInitialize_v2(C->diag, 0, HYPRE_MEMORY_HOST);
    hypre_CSRMatrixInitialize_v2(C->offd, 0, HYPRE_MEMORY_HOST);
    memcpy(C->diag->i, Cdi.data(), sizeof(HYPRE_Int) * ((size_t) ncRT + 1));
    memcpy(C->offd->i, Coi.data(), sizeof(HYPRE_Int) * ((size_t) ncRT + 1));
-   if (!cdj.empty()) { memcpy(C->diag->j, cdj.data(), sizeof(HYPRE_Int) * cdj.size()); memcpy(C->diag->data, cda.data(), sizeof(HYPRE_Real) * cda.size()); }
-   if (!coj.empty()) { memcpy(C->offd->j, coj.data(), sizeof(HYPRE_Int) * coj.size()); memcpy(C->offd->data, coa.data(), sizeof(HYPRE_Real) * coa.size()); }
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+   for (int t = 0; t < T; t++)
+   {
+      const HYPRE_Int ic_b = (HYPRE_Int) ((long long) ncRT * t / T);
+      const size_t od = (size_t) Cdi[(size_t) ic_b], oo = (size_t) Coi[(size_t) ic_b];
+      if (!t_cdj[(size_t) t].empty())
+      {
+         memcpy(C->diag->j + od, t_cdj[(size_t) t].data(), sizeof(HYPRE_Int) * t_cdj[(size_t) t].size());
+         memcpy(C->diag->data + od, t_cda[(size_t) t].data(), sizeof(HYPRE_Real) * t_cda[(size_t) t].size());
+      }
+      if (!t_coj[(size_t) t].empty())
+      {
+         memcpy(C->offd->j + oo, t_coj[(size_t) t].data(), sizeof(HYPRE_Int) * t_coj[(size_t) t].size());
+         memcpy(C->offd->data + oo, t_coa[(size_t) t].data(), sizeof(HYPRE_Real) * t_coa[(size_t) t].size());
+      }
+   }
    if (ncoRAP)
    {
       C->col_map_offd = hypre_TAlloc(HYPRE_BigInt, ncoRAP, HYPRE_MEMORY_HOST);

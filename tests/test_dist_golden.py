@@ -13,12 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "ij_saved.json")))
 
 
-def run_ranks(nranks, case, timeout=240, extra=None):
+def run_ranks(nranks, case, timeout=240, extra=None, omp=None):
     from conftest import free_port
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
            json.dumps(dict({"options": case["options"]}, **(extra or {})))]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    # one OpenMP thread per rank by default (8 cores here); HYPRE_AMD_TEST_OMP=<n> exercises the threaded setup loops
+    env = dict(os.environ, OMP_NUM_THREADS=str(omp) if omp else os.environ.get("HYPRE_AMD_TEST_OMP", "1"))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
@@ -37,3 +38,12 @@ def test_multi_rank_goldens(name):
     for key in ("conv_factor", "grid", "operator"):
         if key in exp:
             assert abs(out[key] - exp[key]) < 5.1e-7, (key, out[key], exp[key])
+
+
+def test_threaded_distributed_setup_reproduces_the_golden():
+    """The distributed interpolation and Galerkin product split their rows over OpenMP threads (one marker set and one
+    output block per thread); three threads per rank give the hierarchy of the sequential loops: solvers.out.19."""
+    case = GOLD["solvers.out.19"]
+    out = run_ranks(case["ranks"], case, omp=3)
+    assert out["iterations"] == case["expect"]["iterations"]
+    assert abs(out["rel_resid"] - case["expect"]["rel_resid"]) <= 5e-7 * case["expect"]["rel_resid"]
