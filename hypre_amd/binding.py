@@ -241,6 +241,7 @@ PROTOTYPES = {
     "GenerateLaplacian": (ParCSRp, [Int, BigInt, BigInt, BigInt, Int, Int, Int, Int, Int, Int, RealP]),
     "GenerateLaplacian27pt": (ParCSRp, [Int, BigInt, BigInt, BigInt, Int, Int, Int, Int, Int, Int, RealP]),
     "GenerateDifConv": (ParCSRp, [Int, BigInt, BigInt, BigInt, Int, Int, Int, Int, Int, Int, RealP]),
+    "GenerateVarDifConv": (ParCSRp, [Int, BigInt, BigInt, BigInt, Int, Int, Int, Int, Int, Int, Real, C.POINTER(ParVecp)]),
     "GenerateRotate7pt": (ParCSRp, [Int, BigInt, BigInt, Int, Int, Int, Int, Real, Real]),
     "GenerateSysLaplacian": (ParCSRp, [Int, BigInt, BigInt, BigInt, Int, Int, Int, Int, Int, Int, Int, RealP, RealP]),
     "hypre_amd_CSRMatrixFromArrays": (CSRp, [Int, Int, Int, IntP, IntP, RealP, Int]),

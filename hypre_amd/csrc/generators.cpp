@@ -42,9 +42,12 @@ struct Box
 // order entries are stored in each row; entry 0 must be the centre.
 struct StencilPt { int dx, dy, dz, vi; };
 
+// `point_values`, when given, fills value[] for the grid point whose row is being assembled (variable coefficients)
 HYPRE_ParCSRMatrix assemble(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz,
                             HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int ip, HYPRE_Int iq, HYPRE_Int ir,
-                            const std::vector<StencilPt> &stencil, const HYPRE_Real *value)
+                            const std::vector<StencilPt> &stencil, HYPRE_Real *value,
+                            void (*point_values)(void *, HYPRE_BigInt, HYPRE_BigInt, HYPRE_BigInt, HYPRE_Real *) = nullptr,
+                            void *point_ctx = nullptr)
 {
    Box bx;
    bx.nx = nx; bx.ny = ny; bx.nz = nz;
@@ -70,6 +73,7 @@ HYPRE_ParCSRMatrix assemble(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYP
       for (HYPRE_BigInt iy = y0; iy < y1; iy++)
          for (HYPRE_BigInt ix = x0; ix < x1; ix++)
          {
+            if (point_values) { point_values(point_ctx, ix, iy, iz, value); }
             for (const StencilPt &s : stencil)
             {
                const HYPRE_BigInt jx = ix + s.dx, jy = iy + s.dy, jz = iz + s.dz;
@@ -150,6 +154,54 @@ HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt 
    static const std::vector<StencilPt> st = {
       {0, 0, 0, 0}, {0, 0, -1, 3}, {0, -1, 0, 2}, {-1, 0, 0, 1}, {1, 0, 0, 4}, {0, 1, 0, 5}, {0, 0, 1, 6}};
    return assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value);
+}
+
+// Variable-coefficient diffusion -eps div(k grad u) on the unit cube, 7-point flux form with h = 1/(n+1)
+// (par_vardifconv.c:15-565): k = 0.01 in the eight 0.1-corners, 1000 in the inner [0.1, 0.9]^3 box, 1 elsewhere; the
+// reference's convection and reaction coefficients d, e, f, g are zero, its right-hand side function is 1 and its
+// boundary function 0, so the right-hand side it returns is the vector of ones (the driver builds that itself).
+namespace {
+struct VarDifCtx { HYPRE_Real eps, hx, hy, hz; };
+HYPRE_Real vardif_k(HYPRE_Real xx, HYPRE_Real yy, HYPRE_Real zz)
+{
+   const bool lx = xx < 0.1, hx = xx > 0.9, ly = yy < 0.1, hy = yy > 0.9, lz = zz < 0.1, hz = zz > 0.9;
+   if ((lx || hx) && (ly || hy) && (lz || hz)) { return 0.01; }
+   if (xx >= 0.1 && xx <= 0.9 && yy >= 0.1 && yy <= 0.9 && zz >= 0.1 && zz <= 0.9) { return 1000.0; }
+   return 1.0;
+}
+void vardif_values(void *vctx, HYPRE_BigInt ix, HYPRE_BigInt iy, HYPRE_BigInt iz, HYPRE_Real *v)
+{
+   const VarDifCtx *c = (const VarDifCtx *) vctx;
+   const HYPRE_Real xx = (HYPRE_Real) (ix + 1) * c->hx, yy = (HYPRE_Real) (iy + 1) * c->hy, zz = (HYPRE_Real) (iz + 1) * c->hz;
+   const HYPRE_Real afp = c->eps * vardif_k(xx + 0.5 * c->hx, yy, zz) / c->hx / c->hx;
+   const HYPRE_Real afm = c->eps * vardif_k(xx - 0.5 * c->hx, yy, zz) / c->hx / c->hx;
+   const HYPRE_Real bfp = c->eps * vardif_k(xx, yy + 0.5 * c->hy, zz) / c->hy / c->hy;
+   const HYPRE_Real bfm = c->eps * vardif_k(xx, yy - 0.5 * c->hy, zz) / c->hy / c->hy;
+   const HYPRE_Real cfp = c->eps * vardif_k(xx, yy, zz + 0.5 * c->hz) / c->hz / c->hz;
+   const HYPRE_Real cfm = c->eps * vardif_k(xx, yy, zz - 0.5 * c->hz) / c->hz / c->hz;
+   const HYPRE_Real df = 0.0 / c->hx, ef = 0.0 / c->hy, ff = 0.0 / c->hz, gf = 0.0;     // dfun = efun = ffun = gfun = 0
+   v[0] = afp + afm + bfp + bfm + cfp + cfm + gf - df - ef - ff;
+   v[1] = -cfm; v[2] = -bfm; v[3] = -afm; v[4] = -afp + df; v[5] = -bfp + ef; v[6] = -cfp + ff;
+}
+}  // namespace
+
+HYPRE_ParCSRMatrix GenerateVarDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz, HYPRE_Int P,
+                                      HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q, HYPRE_Int r, HYPRE_Real eps,
+                                      HYPRE_ParVector *rhs_ptr)
+{
+   VarDifCtx ctx{eps, 1.0 / (HYPRE_Real) (nx + 1), 1.0 / (HYPRE_Real) (ny + 1), 1.0 / (HYPRE_Real) (nz + 1)};
+   HYPRE_Real value[7];
+   static const std::vector<StencilPt> st = {
+      {0, 0, 0, 0}, {0, 0, -1, 1}, {0, -1, 0, 2}, {-1, 0, 0, 3}, {1, 0, 0, 4}, {0, 1, 0, 5}, {0, 0, 1, 6}};
+   hypre_ParCSRMatrix *A = assemble(comm, nx, ny, nz, P, Q, R, p, q, r, st, value, vardif_values, &ctx);
+   if (A && rhs_ptr)
+   {
+      hypre_ParVector *b = hypre_ParVectorCreate(comm, A->global_num_rows, A->row_starts);
+      hypre_ParVectorInitialize_v2(b, HYPRE_MEMORY_HOST);
+      for (HYPRE_Int i = 0; i < b->local_vector->size; i++) { b->local_vector->data[i] = 1.0; }      // rfun = 1, bndfun = 0
+      *rhs_ptr = b;
+   }
+   return A;
 }
 
 // Rotated anisotropic diffusion in 2-D, 7-point stencil [centre, SW, S, W, E, N, NE] (par_rotate_7pt.c:15-397):

@@ -21,7 +21,7 @@ class IJOptions:
         self.P = None                 # (P, Q, R); default (1, nprocs, 1)
         self.problem = "laplacian"    # laplacian | 27pt | difconv | rotate
         self.alpha = 1.0              # -alpha (rotate: angle in degrees; test/ij.c:11147)
-        self.eps = 0.0                # -eps   (rotate: anisotropy)
+        self.eps = None               # -eps   (rotate: anisotropy, default 0; vardifconv: diffusion scale, default 1)
         self.sys_num_fun = 1          # -sysL <num functions>: systems version of the 7-point operator
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
@@ -128,7 +128,14 @@ def build_matrix(opt, comm=0, rank=0, nprocs=1):
         # test/ij.c:11130-11240 BuildParRotate7pt: a 2-D problem, -n and -P read two values each
         if R != 1:
             raise ValueError("-rotate is two-dimensional: R must be 1")
-        A = B.load_library().GenerateRotate7pt(comm, opt.n[0], opt.n[1], P, Q, p, q, opt.alpha, opt.eps)
+        A = B.load_library().GenerateRotate7pt(comm, opt.n[0], opt.n[1], P, Q, p, q, opt.alpha,
+                                               0.0 if opt.eps is None else opt.eps)
+        B.check()
+        return A
+    if opt.problem == "vardifconv":
+        # test/ij.c:11260-11370 BuildParVarDifConv; the right-hand side it returns is all ones (build_rhs_host)
+        nx, ny, nz = opt.n
+        A = B.load_library().GenerateVarDifConv(comm, nx, ny, nz, P, Q, R, p, q, r, 1.0 if opt.eps is None else opt.eps, None)
         B.check()
         return A
     kind = {"laplacian": "7pt", "27pt": "27pt", "difconv": "difconv"}[opt.problem]
@@ -199,6 +206,10 @@ def build_rhs_host(opt, A, rank=0, allreduce=None):
         if len(b) != n:
             raise ValueError("right-hand side file holds %d entries for %d local rows" % (len(b), n))
         return b, np.zeros(n)
+    if opt.problem == "vardifconv":
+        # test/ij.c:2877-2879, 3856-3887: b from the generator (ones), random initial guess seeded with the rank
+        rng = HypreRand(rank)
+        return np.ones(n), np.array([rng.next() for _ in range(n)])
     if opt.rhs == "one":
         return np.ones(n), np.zeros(n)
     if opt.rhs == "rand":
@@ -293,7 +304,7 @@ _VALUE_FLAGS = {
 }
 _SWITCH_FLAGS = {
     "-laplacian": ("problem", "laplacian"), "-27pt": ("problem", "27pt"), "-difconv": ("problem", "difconv"),
-    "-rotate": ("problem", "rotate"), "-rhsrand": ("rhs", "rand"), "-rhsisone": ("rhs", "one"), "-xisone": ("rhs", "xisone"),
+    "-rotate": ("problem", "rotate"), "-vardifconv": ("problem", "vardifconv"), "-rhsrand": ("rhs", "rand"), "-rhsisone": ("rhs", "one"), "-xisone": ("rhs", "xisone"),
     "-pmis": ("coarsen_type", 8), "-pmis1": ("coarsen_type", 9), "-hmis": ("coarsen_type", 10),
     "-fmg": ("fcycle", 1), "-amd_mixed": ("mixed", True),
 }

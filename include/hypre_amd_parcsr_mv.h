@@ -251,6 +251,11 @@ HYPRE_ParCSRMatrix GenerateDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt 
                                    HYPRE_Int P, HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q,
                                    HYPRE_Int r, HYPRE_Real *value);
 
+/* par_vardifconv.c:15-565 (`ij -vardifconv -eps e`): variable-coefficient diffusion; *rhs_ptr (optional) receives the
+ * right-hand side the reference generator returns with its coefficient functions (all ones) */
+HYPRE_ParCSRMatrix GenerateVarDifConv(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_BigInt nz, HYPRE_Int P,
+                                      HYPRE_Int Q, HYPRE_Int R, HYPRE_Int p, HYPRE_Int q, HYPRE_Int r, HYPRE_Real eps,
+                                      HYPRE_ParVector *rhs_ptr);
 /* par_rotate_7pt.c:15-397 (`ij -rotate -alpha a -eps e -n nx ny 1 -P P Q 1`) */
 HYPRE_ParCSRMatrix GenerateRotate7pt(MPI_Comm comm, HYPRE_BigInt nx, HYPRE_BigInt ny, HYPRE_Int P, HYPRE_Int Q,
                                      HYPRE_Int p, HYPRE_Int q, HYPRE_Real alpha, HYPRE_Real eps);
