@@ -333,6 +333,11 @@ def parse_cli(argv):
                 raise SystemExit("ij: %s needs a file name" % flag)
             setattr(opt, flag[1:], argv[i + 1])
             i += 2
+        elif flag == "-rap":
+            # test/ij.c:2157-2161 rap2: 0 = the Galerkin triple product this library builds (the default)
+            if i + 1 >= len(argv) or int(argv[i + 1]) != 0:
+                raise SystemExit("ij: -rap 1 (two-product coarse operator) is outside the scope of this driver")
+            i += 2
         elif flag in ("-wl", "-owl"):
             val, lev = float(argv[i + 1]), int(argv[i + 2])
             if lev > -1:        # test/ij.c:4543-4550 applies the level weight only for level > -1
