@@ -929,25 +929,48 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
       return hypre_error_flag;
    }
    MPI_Comm comm = A->comm;
-   if (comm_size(comm) > 1)
-   {
-      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGBuildDirInterp: distributed setup is not available yet");
-      return hypre_error_flag;
-   }
-   hypre_CSRMatrix *Ad = A->diag;
-   const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
-   const HYPRE_Real *Aa = Ad->data;
-   const HYPRE_Int *Si = S->diag->i, *Sj = S->diag->j;
-   const HYPRE_Int n = Ad->num_rows;
+   const bool dist = comm_size(comm) > 1;
+   hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
+   const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j, *Aoi = Ao->i, *Aoj = Ao->j;
+   const HYPRE_Real *Aa = Ad->data, *Aoa = Ao->data;
+   const HYPRE_Int *Si = S->diag->i, *Sj = S->diag->j, *Soi = S->offd->i, *Soj = S->offd->j;
+   const HYPRE_Int n = Ad->num_rows, nco = dist ? Ao->num_cols : 0;
    std::vector<HYPRE_Int> f2c((size_t) std::max(n, 1), -1);
    HYPRE_Int c = 0;
    for (HYPRE_Int i = 0; i < n; i++) { if (CF_marker[i] >= 0) { f2c[(size_t) i] = c++; } }
-   std::vector<HYPRE_Int> Pi((size_t) n + 1, 0), pj;
-   std::vector<HYPRE_Real> pa;
-   std::vector<HYPRE_Int> marker((size_t) std::max(n, 1), -1);
+   // ghost columns: C/F marker and global coarse index (par_interp.c:1990-2060)
+   HYPRE_BigInt total_cpts = num_cpts_global[1];
+   std::vector<HYPRE_Int> CF_offd((size_t) std::max(nco, 1), -1);
+   std::vector<HYPRE_BigInt> f2c_offd((size_t) std::max(nco, 1), -1);
+   if (dist)
+   {
+      const hypre_amd_CommOps *o = comm_ops(comm);
+      std::vector<HYPRE_BigInt> ends((size_t) o->size);
+      o->allgather(o->ctx, &num_cpts_global[1], ends.data(), sizeof(HYPRE_BigInt));
+      total_cpts = ends.back();
+      if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      if (nco)
+      {
+         std::vector<HYPRE_BigInt> f2c_big((size_t) std::max(n, 1));
+         for (HYPRE_Int i = 0; i < n; i++) { f2c_big[(size_t) i] = (HYPRE_BigInt) f2c[(size_t) i] + num_cpts_global[0]; }
+         halo_forward<HYPRE_Int>(A->comm_pkg, CF_marker, CF_offd.data());
+         halo_forward<HYPRE_BigInt>(A->comm_pkg, f2c_big.data(), f2c_offd.data());
+      }
+      else
+      {
+         // collective all the same: ranks without ghosts still take part in the neighbours' exchanges
+         halo_forward<HYPRE_Int>(A->comm_pkg, CF_marker, CF_offd.data());
+         std::vector<HYPRE_BigInt> f2c_big((size_t) std::max(n, 1));
+         for (HYPRE_Int i = 0; i < n; i++) { f2c_big[(size_t) i] = (HYPRE_BigInt) f2c[(size_t) i] + num_cpts_global[0]; }
+         halo_forward<HYPRE_BigInt>(A->comm_pkg, f2c_big.data(), f2c_offd.data());
+      }
+   }
+   std::vector<HYPRE_Int> Pi((size_t) n + 1, 0), Poi((size_t) n + 1, 0), pj, poj;
+   std::vector<HYPRE_Real> pa, poa;
+   std::vector<HYPRE_Int> marker((size_t) std::max(n, 1), -1), marker_o((size_t) std::max(nco, 1), -1);
    for (HYPRE_Int i = 0; i < n; i++)
    {
-      const HYPRE_Int begin = (HYPRE_Int) pj.size();
+      const HYPRE_Int begin = (HYPRE_Int) pj.size(), begin_o = (HYPRE_Int) poj.size();
       if (CF_marker[i] >= 0) { pj.push_back(f2c[(size_t) i]); pa.push_back(1.0); }
       else
       {
@@ -957,6 +980,15 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
             if (CF_marker[i1] >= 0) { marker[(size_t) i1] = (HYPRE_Int) pj.size(); pj.push_back(f2c[(size_t) i1]); pa.push_back(0.0); }
          }
          const HYPRE_Int end = (HYPRE_Int) pj.size();
+         if (dist)
+         {
+            for (HYPRE_Int jj = Soi[i]; jj < Soi[i + 1]; jj++)
+            {
+               const HYPRE_Int i1 = Soj[jj];
+               if (CF_offd[(size_t) i1] >= 0) { marker_o[(size_t) i1] = (HYPRE_Int) poj.size(); poj.push_back(i1); poa.push_back(0.0); }
+            }
+         }
+         const HYPRE_Int end_o = (HYPRE_Int) poj.size();
          const HYPRE_Real diagonal = Aa[Ai[i]];
          HYPRE_Real sum_N_pos = 0, sum_N_neg = 0, sum_P_pos = 0, sum_P_neg = 0;
          for (HYPRE_Int jj = Ai[i] + 1; jj < Ai[i + 1]; jj++)
@@ -969,6 +1001,19 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
                if (Aa[jj] > 0) { sum_P_pos += Aa[jj]; } else { sum_P_neg += Aa[jj]; }
             }
          }
+         if (dist)
+         {
+            for (HYPRE_Int jj = Aoi[i]; jj < Aoi[i + 1]; jj++)
+            {
+               const HYPRE_Int i1 = Aoj[jj];
+               if (Aoa[jj] > 0) { sum_N_pos += Aoa[jj]; } else { sum_N_neg += Aoa[jj]; }
+               if (marker_o[(size_t) i1] >= begin_o)
+               {
+                  poa[(size_t) marker_o[(size_t) i1]] += Aoa[jj];
+                  if (Aoa[jj] > 0) { sum_P_pos += Aoa[jj]; } else { sum_P_neg += Aoa[jj]; }
+               }
+            }
+         }
          HYPRE_Real alfa = 1.0, beta = 1.0, diag = diagonal;
          if (sum_P_neg) { alfa = sum_N_neg / sum_P_neg / diag; }
          if (sum_P_pos) { beta = sum_N_pos / sum_P_pos / diag; }
@@ -976,20 +1021,52 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
          {
             if (pa[(size_t) k] > 0) { pa[(size_t) k] *= -beta; } else { pa[(size_t) k] *= -alfa; }
          }
+         for (HYPRE_Int k = begin_o; k < end_o; k++)
+         {
+            if (poa[(size_t) k] > 0) { poa[(size_t) k] *= -beta; } else { poa[(size_t) k] *= -alfa; }
+         }
       }
       Pi[(size_t) i + 1] = (HYPRE_Int) pj.size();
+      Poi[(size_t) i + 1] = (HYPRE_Int) poj.size();
    }
    HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
-   hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, num_cpts_global[1], A->col_starts, cs, 0,
-                                                    Pi[(size_t) n], 0);
+   hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_cpts, A->col_starts, cs, nco,
+                                                    Pi[(size_t) n], Poi[(size_t) n]);
    hypre_ParCSRMatrixInitialize_v2(P, HYPRE_MEMORY_HOST);
    memcpy(P->diag->i, Pi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
+   memcpy(P->offd->i, Poi.data(), sizeof(HYPRE_Int) * ((size_t) n + 1));
    if (!pj.empty())
    {
       memcpy(P->diag->j, pj.data(), sizeof(HYPRE_Int) * pj.size());
       memcpy(P->diag->data, pa.data(), sizeof(HYPRE_Real) * pa.size());
    }
+   if (!poj.empty())
+   {
+      memcpy(P->offd->j, poj.data(), sizeof(HYPRE_Int) * poj.size());
+      memcpy(P->offd->data, poa.data(), sizeof(HYPRE_Real) * poa.size());
+   }
    if (trunc_factor != 0.0 || max_elmts > 0) { hypre_BoomerAMGInterpTruncation(P, trunc_factor, max_elmts); }
+   if (dist)
+   {
+      // ghost C-points that survived: P's own column map, ascending (par_interp.c:2370-2440)
+      const HYPRE_Int nnz_o = P->offd->i[n];
+      std::vector<HYPRE_Int> renum((size_t) std::max(nco, 1), -1);
+      for (HYPRE_Int k = 0; k < nnz_o; k++) { renum[(size_t) P->offd->j[k]] = 0; }
+      std::vector<HYPRE_BigInt> cmap;
+      for (HYPRE_Int g = 0; g < nco; g++) { if (renum[(size_t) g] == 0) { renum[(size_t) g] = (HYPRE_Int) cmap.size(); cmap.push_back(f2c_offd[(size_t) g]); } }
+      for (HYPRE_Int k = 0; k < nnz_o; k++) { P->offd->j[k] = renum[(size_t) P->offd->j[k]]; }
+      P->offd->num_cols = (HYPRE_Int) cmap.size();
+      if (P->col_map_offd) { hypre_Free(P->col_map_offd, HYPRE_MEMORY_HOST); P->col_map_offd = nullptr; }
+      if (!cmap.empty())
+      {
+         P->col_map_offd = hypre_TAlloc(HYPRE_BigInt, cmap.size(), HYPRE_MEMORY_HOST);
+         memcpy(P->col_map_offd, cmap.data(), sizeof(HYPRE_BigInt) * cmap.size());
+      }
+      hypre_CSRMatrixSetRownnz(P->offd);
+      hypre_MatvecCommPkgCreate(P);
+      *P_ptr = P;
+      return hypre_error_flag;
+   }
    hypre_CSRMatrixSetRownnz(P->offd);
    *P_ptr = P;
    return hypre_error_flag;

@@ -47,3 +47,21 @@ def test_threaded_distributed_setup_reproduces_the_golden():
     out = run_ranks(case["ranks"], case, omp=3)
     assert out["iterations"] == case["expect"]["iterations"]
     assert abs(out["rel_resid"] - case["expect"]["rel_resid"]) <= 5e-7 * case["expect"]["rel_resid"]
+
+
+def test_distributed_direct_interpolation_is_rank_invariant():
+    """interp_type 3 (par_interp.c:1873-2450) has no job in the reference's regression set; with the rank-independent
+    PMIS variant (-pmis1, as default.jobs uses to check rank invariance) the 4-rank hierarchy must be the 1-rank one:
+    same complexities, same iteration count, same residual."""
+    # three levels: further down, Galerkin sums formed in a different association (diag block + ghost block) move
+    # couplings across the strength threshold and the C/F splittings drift apart by a point or two
+    # (no truncation: which of several equal weights survives -Pmx depends on the diag / ghost split of a row)
+    opts = {"n": [14, 13, 12], "coarsen_type": 9, "interp_type": 3, "relax_type": 18, "max_levels": 3, "P_max_elmts": 0}
+    one = run_ranks(1, {"options": dict(opts, rhs="one")})
+    # slabs in z keep the global row numbering of the single-rank problem (x fastest, z slowest), so the matrix, the
+    # sequential random numbers of -pmis1 and hence the C/F splitting are the same
+    four = run_ranks(4, {"options": dict(opts, rhs="one", P=[1, 1, 4])})
+    assert one["levels"] == four["levels"] and one["sizes"] == four["sizes"]
+    assert abs(one["grid"] - four["grid"]) < 1e-12 and abs(one["operator"] - four["operator"]) < 1e-12
+    assert one["iterations"] == four["iterations"]
+    assert abs(one["rel_resid"] - four["rel_resid"]) <= 1e-6 * one["rel_resid"]
