@@ -558,6 +558,21 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
                zeros[(size_t) level] = 0;
             }
          }
+         else if (relax_type == 17)
+         {
+            // FCF-Jacobi (par_cycle.c:539-556, par_relax_interface.c:83-117): weighted Jacobi on the F, the C and again
+            // the F points; one plain Jacobi sweep on the coarsest level, which has no C/F splitting
+            static const int fcf[3] = {-1, 1, -1};
+            const int npass = (level == L - 1) ? 1 : 3;
+            double *dd = diag_scratch((size_t) std::max(n, 1));
+            launch_diag_first(A[level]->diag->i, A[level]->diag->data, dd, n, s);
+            for (int pss = 0; pss < npass; pss++)
+            {
+               dev_jacobi_sweep(A[level], fd, cf, npass == 1 ? 0 : fcf[pss], w, dd, u.cur, u.other());
+               u.flip();
+            }
+            zeros[(size_t) level] = 0;
+         }
          else if (relax_type == 16)
          {
             // Chebyshev polynomial smoothing (par_cycle.c:529-537), in place on the current buffer

@@ -349,7 +349,7 @@ def parse_cli(argv):
         raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 3 AMG-GMRES)" % opt.solver)
     if opt.interp_type not in (6, 3):
         raise SystemExit("ij: -interptype %d is outside the scope of this driver (6 ext+i, 3 direct)" % opt.interp_type)
-    smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 16, 18, 88, 89)
+    smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 88, 89)
     for name in ("relax_type", "relax_down", "relax_up"):
         if getattr(opt, name) not in smoothers:
             raise SystemExit("ij: smoother %d is outside the scope of this driver" % getattr(opt, name))

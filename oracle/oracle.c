@@ -800,6 +800,25 @@ int oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros)
                all_zeros[level] = 0;
             }
          }
+         else if (relax_type == 17)
+         {
+            /* par_cycle.c:539-556 + par_relax_interface.c:83-117: F, C, F passes of weighted Jacobi; one plain
+               Jacobi sweep on the coarsest level, which has no C/F splitting */
+            if (level == L - 1)
+            {
+               err = oracle_relax(A, F[level], cf, 0, 0, amg->relax_weight[level], 0.0, NULL, U[level], vtemp,
+                                  amg->num_threads, &all_zeros[level]);
+            }
+            else
+            {
+               static const int fcf[3] = {-1, 1, -1};
+               for (int q = 0; q < 3 && !err; q++)
+               {
+                  err = oracle_relax(A, F[level], cf, 0, fcf[q], amg->relax_weight[level], 0.0, NULL, U[level], vtemp,
+                                     amg->num_threads, &all_zeros[level]);
+               }
+            }
+         }
          else if (relax_type == 18)
          {
             err = oracle_relax_if(A, F[level], cf, relax_type, amg->relax_order, cycle_param,
