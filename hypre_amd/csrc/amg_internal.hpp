@@ -23,6 +23,9 @@ struct AmgPrivate
    std::vector<double *> u_alt;     // [num_levels], device
    std::vector<int>      u_alt_len;
 
+   // relax 15: one unpreconditioned-CG solver per level, created at the first cycle that needs it
+   std::vector<HYPRE_Solver> cg_smoothers;
+
    // coarsest level: factors of the reference's pivot-free elimination
    // (utilities/gselim.h), computed once on the host, applied on the device
    double *d_coarse_lu = nullptr;   // n*n row-major: U on/above the diagonal, multipliers below

@@ -65,7 +65,12 @@ void amg_free_hierarchy(hypre_ParAMGData *d)
 {
    AmgPrivate *pv = (AmgPrivate *) d->amd_private;
    destroy_replicated_tail(d);
-   if (pv) { pv->release_device(); }
+   if (pv)
+   {
+      pv->release_device();
+      for (HYPRE_Solver cg : pv->cg_smoothers) { if (cg) { HYPRE_ParCSRPCGDestroy(cg); } }
+      pv->cg_smoothers.clear();
+   }
    const int L = d->num_levels;
    if (d->A_array)
    {

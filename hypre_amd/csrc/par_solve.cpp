@@ -558,6 +558,30 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
                zeros[(size_t) level] = 0;
             }
          }
+         else if (relax_type == 15)
+         {
+            // CG smoother (par_cycle.c:517-528, par_relax_more.c:464-493, setup par_amg_setup.c:3551-3567): num_sweep
+            // iterations of unpreconditioned CG from the current iterate, once per relaxation call
+            if (j == 0)
+            {
+               if (pv->cg_smoothers.size() < (size_t) L) { pv->cg_smoothers.resize((size_t) L, nullptr); }
+               hypre_Vector uv; hypre_ParVector up;
+               wrap(&uv, u.cur, n);
+               wrap_par(&up, &uv, A[level]->comm, A[level]->global_num_rows);
+               up.all_zeros = zeros[(size_t) level];
+               HYPRE_Solver &cg = pv->cg_smoothers[(size_t) level];
+               if (!cg)
+               {
+                  HYPRE_ParCSRPCGCreate(A[level]->comm, &cg);
+                  HYPRE_PCGSetTwoNorm(cg, 1);
+                  HYPRE_ParCSRPCGSetup(cg, A[level], F_array[level], &up);
+               }
+               HYPRE_PCGSetMaxIter(cg, num_sweep);
+               HYPRE_PCGSetTol(cg, 0.0);
+               HYPRE_ParCSRPCGSolve(cg, A[level], F_array[level], &up);
+               zeros[(size_t) level] = 0;
+            }
+         }
          else if (relax_type == 17)
          {
             // FCF-Jacobi (par_cycle.c:539-556, par_relax_interface.c:83-117): weighted Jacobi on the F, the C and again
@@ -783,10 +807,10 @@ struct hypre_amd_PCGData
    hypre_Solver base;
    MPI_Comm comm;
    HYPRE_Real tol = 1e-6, a_tol = 0.0;
-   HYPRE_Int max_iter = 1000, two_norm = 0;
+   HYPRE_Int max_iter = 1000, two_norm = 0, flex = 0;
    HYPRE_PtrToSolverFcn precond = nullptr, precond_setup = nullptr;
    HYPRE_Solver precond_data = nullptr;
-   hypre_ParVector *p = nullptr, *s = nullptr, *r = nullptr;
+   hypre_ParVector *p = nullptr, *s = nullptr, *r = nullptr, *r_old = nullptr;
    HYPRE_Int num_iterations = 0, converged = 0;
    HYPRE_Real rel_residual_norm = 0.0;
 };
@@ -803,7 +827,7 @@ HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver solver)
 {
    hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
    if (!d) { return hypre_error_flag; }
-   hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r);
+   hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r); hypre_ParVectorDestroy(d->r_old);
    delete d;
    return hypre_error_flag;
 }
@@ -811,6 +835,8 @@ HYPRE_Int HYPRE_PCGSetTol(HYPRE_Solver s, HYPRE_Real v) { ((hypre_amd_PCGData *)
 HYPRE_Int HYPRE_PCGSetAbsoluteTol(HYPRE_Solver s, HYPRE_Real v) { ((hypre_amd_PCGData *) s)->a_tol = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_PCGSetMaxIter(HYPRE_Solver s, HYPRE_Int v) { ((hypre_amd_PCGData *) s)->max_iter = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_PCGSetTwoNorm(HYPRE_Solver s, HYPRE_Int v) { ((hypre_amd_PCGData *) s)->two_norm = v; return hypre_error_flag; }
+// pcg.c:339-345: Polak-Ribiere beta instead of Fletcher-Reeves, for preconditioners that change between iterations
+HYPRE_Int HYPRE_PCGSetFlex(HYPRE_Solver s, HYPRE_Int v) { ((hypre_amd_PCGData *) s)->flex = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_PCGSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn precond, HYPRE_PtrToSolverFcn precond_setup,
                               HYPRE_Solver precond_solver)
 {
@@ -824,10 +850,11 @@ HYPRE_Int HYPRE_PCGGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v) {
 HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector b, HYPRE_ParVector x)
 {
    hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
-   hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r);
+   hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r); hypre_ParVectorDestroy(d->r_old);
    const HYPRE_MemoryLocation loc = x->local_vector->memory_location;
    auto mk = [&]() { hypre_ParVector *v = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts); hypre_ParVectorInitialize_v2(v, loc); return v; };
    d->p = mk(); d->s = mk(); d->r = mk();
+   d->r_old = d->flex ? mk() : nullptr;
    if (d->precond_setup) { d->precond_setup(d->precond_data, A, b, x); }
    return hypre_error_flag;
 }
@@ -837,9 +864,14 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
    hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
    hypre_ParVector *p = d->p, *s = d->s, *r = d->r;
    const HYPRE_Real r_tol = d->tol, a_tol = d->a_tol;
-   HYPRE_Real alpha, beta, gamma, gamma_old, bi_prod, eps, sdotp, i_prod = 0.0, i_prod_0 = 0.0;
+   HYPRE_Real alpha, beta, gamma, gamma_old, bi_prod, eps, sdotp, i_prod = 0.0, i_prod_0 = 0.0, delta = 0.0;
    HYPRE_Int i = 0;
    d->converged = 0;
+   if (d->flex && !d->r_old)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "HYPRE_ParCSRPCGSolve: call HYPRE_ParCSRPCGSetup after HYPRE_PCGSetFlex");
+      return hypre_error_flag;
+   }
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
    auto precond = [&](hypre_ParVector *rhs, hypre_ParVector *sol)
@@ -880,12 +912,14 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       gamma_old = gamma;
       // x += alpha p ; r -= alpha s ; <r,r> of the new residual: one pass (pcg.c:716-760 makes
       // three vector calls of it; element values and the norm's summation order are unchanged)
+      if (d->flex) { hypre_ParVectorCopy(r, d->r_old); }          // pcg.c:636-639
       double *d_rr = reduce_scratch(2048) + 1;
       launch_pcg_update(alpha, -alpha, p->local_vector->data, s->local_vector->data, x->local_vector->data,
                         r->local_vector->data, (size_t) r->local_vector->size, d_rr, stream());
       x->all_zeros = 0; r->all_zeros = 0;
       precond(r, s);
       gamma = hypre_ParVectorInnerProd(r, s);
+      if (d->flex) { delta = gamma - hypre_ParVectorInnerProd(d->r_old, s); }      // pcg.c:720-723
       if (d->two_norm)
       {
          double *h = handle().h_reduce;
@@ -896,7 +930,7 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       else { i_prod = gamma; }
       if (i_prod / bi_prod < eps) { d->converged = 1; break; }
       if (gamma <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero gamma value in PCG"); break; }
-      beta = gamma / gamma_old;
+      beta = (d->flex ? delta : gamma) / gamma_old;                 // pcg.c:957-965
       // p = beta p + s in one pass (Scale then Axpy in the reference)
       launch_pcg_direction(beta, s->local_vector->data, p->local_vector->data, (size_t) p->local_vector->size, stream());
    }

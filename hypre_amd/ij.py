@@ -27,6 +27,7 @@ class IJOptions:
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
         self.solver = 0               # 0 AMG, 1 AMG-PCG, 3 AMG-GMRES
         self.k_dim = 5                # -k (GMRES restart length, test/ij.c:1731)
+        self.flex = 0                 # -flex (flexible PCG: Polak-Ribiere beta)
         self.rhs = "one"              # one (-rhsisone default) | rand (-rhsrand) | xisone
         self.fromfile = None          # -fromfile <name>: matrix from IJ text files <name>.<rank %05d>
         self.rhsfromfile = None       # -rhsfromfile <name>: right-hand side from IJ text files
@@ -293,7 +294,7 @@ _VALUE_FLAGS = {
     "-tr": ("trunc_factor", float, 1), "-Pmx": ("P_max_elmts", int, 1), "-interptype": ("interp_type", int, 1),
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
-    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nf": ("num_functions", int, 1),
+    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nf": ("num_functions", int, 1), "-flex": ("flex", int, 1),
     "-alpha": ("alpha", float, 1), "-eps": ("eps", float, 1), "-sysL": ("sys_num_fun", int, 1), "-ff": ("filter_functions", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
@@ -349,7 +350,7 @@ def parse_cli(argv):
         raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 3 AMG-GMRES)" % opt.solver)
     if opt.interp_type not in (6, 3):
         raise SystemExit("ij: -interptype %d is outside the scope of this driver (6 ext+i, 3 direct)" % opt.interp_type)
-    smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 16, 17, 18, 88, 89)
+    smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 88, 89)
     for name in ("relax_type", "relax_down", "relax_up"):
         if getattr(opt, name) not in smoothers:
             raise SystemExit("ij: smoother %d is outside the scope of this driver" % getattr(opt, name))
@@ -416,6 +417,7 @@ def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
         L.HYPRE_PCGSetTol(pcg, opt.tol)
         L.HYPRE_PCGSetMaxIter(pcg, opt.max_iter)
         L.HYPRE_PCGSetTwoNorm(pcg, opt.two_norm)
+        L.HYPRE_PCGSetFlex(pcg, opt.flex)
         L.HYPRE_PCGSetPrecond(pcg, C.cast(L.HYPRE_BoomerAMGSolve, C.c_void_p), None, s)
         L.HYPRE_ParCSRPCGSetup(pcg, A, db, dx)
         L.HYPRE_ParCSRPCGSolve(pcg, A, db, dx)

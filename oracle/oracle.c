@@ -749,6 +749,53 @@ static void coarse_solve(const opar *A, const double *f, double *u)
 /* ------------------------------------------------------------------------- */
 /* V / W / F cycle (par_cycle.c:23-803)                                       */
 /* ------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------- */
+/* CG smoother (relax 15): hypre_ParCSRRelax_CG (par_relax_more.c:464-493) =   */
+/* hypre_PCGSolve (krylov/pcg.c:318-1000) with the identity as preconditioner  */
+/* (par_krylov_func.c:316-326), two_norm = 1, tol = 0, max_iter = num_its,     */
+/* started from the current iterate.                                           */
+/* ------------------------------------------------------------------------- */
+void oracle_cg_relax(const opar *A, const double *b, double *x, int num_its)
+{
+   const long long n = A->row_starts[A->nranks];
+   double *p = (double *) calloc((size_t) (n > 0 ? n : 1), sizeof(double));
+   double *s = (double *) calloc((size_t) (n > 0 ? n : 1), sizeof(double));
+   double *r = (double *) calloc((size_t) (n > 0 ? n : 1), sizeof(double));
+   double gamma, gamma_old, alpha, beta, sdotp;
+   const double bi_prod = oracle_inner_prod(b, b, n);
+   int i = 0;
+   if (!(bi_prod > 0.0))
+   {
+      memcpy(x, b, sizeof(double) * (size_t) n);          /* pcg.c:452-468: zero right-hand side */
+      free(p); free(s); free(r);
+      return;
+   }
+   memcpy(r, b, sizeof(double) * (size_t) n);
+   oracle_par_matvec(-1.0, A, x, 1.0, r, r);
+   memcpy(p, r, sizeof(double) * (size_t) n);
+   gamma = oracle_inner_prod(r, p, n);
+   while ((i + 1) <= num_its)
+   {
+      i++;
+      oracle_par_matvec(1.0, A, p, 0.0, s, s);
+      sdotp = oracle_inner_prod(s, p, n);
+      if (sdotp == 0.0) { break; }
+      alpha = gamma / sdotp;
+      if (alpha <= 0.0) { break; }
+      gamma_old = gamma;
+      oracle_axpy(alpha, p, x, n);
+      oracle_axpy(-alpha, s, r, n);
+      memcpy(s, r, sizeof(double) * (size_t) n);
+      gamma = oracle_inner_prod(r, s, n);
+      /* eps = 0: i_prod / bi_prod < eps never holds */
+      if (gamma <= 0.0) { break; }
+      beta = gamma / gamma_old;
+      oracle_scale(beta, p, n);
+      oracle_axpy(1.0, s, p, n);
+   }
+   free(p); free(s); free(r);
+}
+
 int oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros)
 {
    const int L = amg->num_levels;
@@ -799,6 +846,11 @@ int oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros)
                                         amg->cheby_coefs[level], amg->cheby_order, amg->cheby_scale, U[level]);
                all_zeros[level] = 0;
             }
+         }
+         else if (relax_type == 15)
+         {
+            /* par_cycle.c:517-528: num_sweep iterations of unpreconditioned CG, once per relaxation call */
+            if (j == 0) { oracle_cg_relax(A, F[level], U[level], num_sweep); all_zeros[level] = 0; }
          }
          else if (relax_type == 17)
          {
@@ -936,12 +988,20 @@ int oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol, in
 int oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
                    int two_norm, int precond_cycles, double *rel_resid_out, int *converged_out)
 {
+   return oracle_pcg_amg_flex(amg, b, x, r_tol, a_tol, max_iter, two_norm, precond_cycles, 0, rel_resid_out, converged_out);
+}
+
+/* flex != 0: Polak-Ribiere beta (pcg.c:339-345, 636-639, 720-723, 957-965) */
+int oracle_pcg_amg_flex(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
+                        int two_norm, int precond_cycles, int flex, double *rel_resid_out, int *converged_out)
+{
    const opar *A = &amg->A[0];
    const long long n = A->row_starts[A->nranks];
    double *p = (double *) calloc((size_t) n, sizeof(double));
    double *s = (double *) calloc((size_t) n, sizeof(double));
    double *r = (double *) calloc((size_t) n, sizeof(double));
-   double bi_prod, eps, gamma, gamma_old, alpha, beta, sdotp, i_prod = 0.0, i_prod_0 = 0.0;
+   double *r_old = (double *) calloc((size_t) n, sizeof(double));
+   double bi_prod, eps, gamma, gamma_old, alpha, beta, sdotp, i_prod = 0.0, i_prod_0 = 0.0, delta = 0.0;
    int i = 0, converged = 0;
 
 #define PRECOND(rhs, sol)                                                                  \
@@ -963,7 +1023,7 @@ int oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, do
       memcpy(x, b, sizeof(double) * (size_t) n);
       if (rel_resid_out) { *rel_resid_out = 0.0; }
       if (converged_out) { *converged_out = 0; }
-      free(p); free(s); free(r);
+      free(p); free(s); free(r); free(r_old);
       return 0;
    }
    memcpy(r, b, sizeof(double) * (size_t) n);
@@ -982,20 +1042,22 @@ int oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, do
       if (alpha <= 0.0) { if (i == 1) { i_prod = i_prod_0; } break; }
       gamma_old = gamma;
       oracle_axpy(alpha, p, x, n);
+      if (flex) { memcpy(r_old, r, sizeof(double) * (size_t) n); }
       oracle_axpy(-alpha, s, r, n);
       PRECOND(r, s);
       gamma = oracle_inner_prod(r, s, n);
+      if (flex) { delta = gamma - oracle_inner_prod(r_old, s, n); }
       i_prod = two_norm ? oracle_inner_prod(r, r, n) : gamma;
       if (i_prod / bi_prod < eps) { converged = 1; break; }
       if (gamma <= 0.0) { break; }
-      beta = gamma / gamma_old;
+      beta = (flex ? delta : gamma) / gamma_old;
       oracle_scale(beta, p, n);
       oracle_axpy(1.0, s, p, n);
    }
 #undef PRECOND
    if (rel_resid_out) { *rel_resid_out = sqrt(i_prod / bi_prod); }
    if (converged_out) { *converged_out = converged; }
-   free(p); free(s); free(r);
+   free(p); free(s); free(r); free(r_old);
    return i;
 }
 

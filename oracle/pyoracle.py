@@ -89,6 +89,9 @@ def load():
     L.oracle_pcg_amg.restype = C.c_int
     L.oracle_pcg_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                  RealP, IntP]
+    L.oracle_pcg_amg_flex.restype = C.c_int
+    L.oracle_pcg_amg_flex.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      RealP, IntP]
     L.oracle_gmres_amg.restype = C.c_int
     L.oracle_gmres_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                    RealP, IntP]
@@ -229,13 +232,13 @@ class Amg:
                                  1 if u_all_zeros else 0, C.byref(rel), C.byref(conv), _rp(hist))
         return its, rel.value, conv.value, hist[:its + 1]
 
-    def pcg(self, b, x, tol=1e-8, atol=0.0, max_iter=1000, two_norm=1, precond_cycles=1):
+    def pcg(self, b, x, tol=1e-8, atol=0.0, max_iter=1000, two_norm=1, precond_cycles=1, flex=0):
         L = load()
         b = np.ascontiguousarray(b, dtype=np.float64)
         rel = C.c_double(0.0)
         conv = C.c_int(0)
-        its = L.oracle_pcg_amg(C.byref(self.c), _rp(b), _rp(x), tol, atol, max_iter, two_norm, precond_cycles,
-                               C.byref(rel), C.byref(conv))
+        its = L.oracle_pcg_amg_flex(C.byref(self.c), _rp(b), _rp(x), tol, atol, max_iter, two_norm, precond_cycles,
+                                    int(flex), C.byref(rel), C.byref(conv))
         return its, rel.value, conv.value
 
     def gmres(self, b, x, tol=1e-8, atol=0.0, max_iter=1000, k_dim=5, precond_cycles=1):

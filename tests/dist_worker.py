@@ -87,6 +87,7 @@ def main():
             L.HYPRE_PCGSetTol(pcg, opt.tol)
             L.HYPRE_PCGSetMaxIter(pcg, opt.max_iter)
             L.HYPRE_PCGSetTwoNorm(pcg, opt.two_norm)
+            L.HYPRE_PCGSetFlex(pcg, opt.flex)
             L.HYPRE_PCGSetPrecond(pcg, C.cast(L.HYPRE_BoomerAMGSolve, C.c_void_p), None, s)
             L.HYPRE_ParCSRPCGSetup(pcg, A, db, dx)
             L.HYPRE_ParCSRPCGSolve(pcg, A, db, dx)
@@ -119,7 +120,7 @@ def main():
             out.update(iterations=its, rel_resid=rel)
         else:
             its, rel, conv = amg.pcg(bg, xg, tol=opt.tol, max_iter=opt.max_iter, two_norm=opt.two_norm,
-                                     precond_cycles=opt.precon_cycles)
+                                     precond_cycles=opt.precon_cycles, flex=opt.flex)
             out.update(iterations=its, rel_resid=rel)
         if device:
             A0 = amg.A_levels[0]

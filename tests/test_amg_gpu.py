@@ -110,6 +110,7 @@ def test_hybrid_gauss_seidel_sweep_is_the_sequential_sweep(gpu_lib, oracle, rela
     dict(relax_type=18, coarsen_type=8, problem="27pt"),
     dict(relax_type=6, coarsen_type=8),
     dict(relax_type=17, coarsen_type=10, relax_wt=0.9),
+    dict(relax_type=15, coarsen_type=8, num_sweeps=2),
     dict(relax_type=17, coarsen_type=8, relax_coarse=17),
     dict(relax_type=3, coarsen_type=10, relax_order=1),
     dict(relax_type=8, coarsen_type=8),

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
                                   "smoother.out.12", "smoother.out.16", "smoother.out.17", "smoother.out.23",
                                   "matrix.out.11", "solvers.out.404", "solvers.out.405",
                                   "solvers.out.2", "solvers.out.20", "solvers.out.22", "elast.out.7",
-                                  "solvers.out.sysu", "solvers.out.29", "solvers.out.30", "smoother.out.18", "smoother.out.19", "smoother.out.20", "smoother.out.14"])
+                                  "solvers.out.sysu", "solvers.out.29", "solvers.out.30", "smoother.out.18", "smoother.out.19", "smoother.out.20", "smoother.out.14", "smoother.out.15", "solvers.out.25"])
 def test_two_or_three_ranks_on_device(name):
     case = dict(GOLD[name])
     out = run_ranks(case["ranks"], {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1})
