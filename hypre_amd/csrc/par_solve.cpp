@@ -811,6 +811,8 @@ struct hypre_amd_PCGData
    HYPRE_PtrToSolverFcn precond = nullptr, precond_setup = nullptr;
    HYPRE_Solver precond_data = nullptr;
    hypre_ParVector *p = nullptr, *s = nullptr, *r = nullptr, *r_old = nullptr;
+   double *d_rr = nullptr;       // device scalar of this solver: <r,r> of the fused update survives the preconditioner call
+                                 // (which may itself run a PCG: the CG smoother)
    HYPRE_Int num_iterations = 0, converged = 0;
    HYPRE_Real rel_residual_norm = 0.0;
 };
@@ -828,6 +830,7 @@ HYPRE_Int HYPRE_ParCSRPCGDestroy(HYPRE_Solver solver)
    hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
    if (!d) { return hypre_error_flag; }
    hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r); hypre_ParVectorDestroy(d->r_old);
+   if (d->d_rr) { hypre_Free(d->d_rr, HYPRE_MEMORY_DEVICE); }
    delete d;
    return hypre_error_flag;
 }
@@ -855,6 +858,7 @@ HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
    auto mk = [&]() { hypre_ParVector *v = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts); hypre_ParVectorInitialize_v2(v, loc); return v; };
    d->p = mk(); d->s = mk(); d->r = mk();
    d->r_old = d->flex ? mk() : nullptr;
+   if (!d->d_rr && loc == HYPRE_MEMORY_DEVICE) { d->d_rr = hypre_TAlloc(double, 2, HYPRE_MEMORY_DEVICE); }
    if (d->precond_setup) { d->precond_setup(d->precond_data, A, b, x); }
    return hypre_error_flag;
 }
@@ -913,7 +917,7 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       // x += alpha p ; r -= alpha s ; <r,r> of the new residual: one pass (pcg.c:716-760 makes
       // three vector calls of it; element values and the norm's summation order are unchanged)
       if (d->flex) { hypre_ParVectorCopy(r, d->r_old); }          // pcg.c:636-639
-      double *d_rr = reduce_scratch(2048) + 1;
+      double *d_rr = d->d_rr;
       launch_pcg_update(alpha, -alpha, p->local_vector->data, s->local_vector->data, x->local_vector->data,
                         r->local_vector->data, (size_t) r->local_vector->size, d_rr, stream());
       x->all_zeros = 0; r->all_zeros = 0;
