@@ -29,7 +29,7 @@ def test_reference_job_line_parses_to_the_golden_options(name):
 
 def test_out_of_scope_flags_are_refused():
     from hypre_amd import ij
-    for bad in (["-agg_nl", "1"], ["-solver", "4"], ["-cljp"], ["-smtype", "6"], ["-interptype", "7"], ["-rlx", "15"],
+    for bad in (["-agg_nl", "1"], ["-solver", "4"], ["-cljp"], ["-smtype", "6"], ["-interptype", "7"], ["-rlx", "5"], ["-rap", "1"],
                 ["-w", "-10"], ["-owl", "-10", "0"], ["-rlx_coarse", "29"]):
         with pytest.raises(SystemExit):
             ij.parse_cli(bad)
