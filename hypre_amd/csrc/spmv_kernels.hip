@@ -204,6 +204,10 @@ struct TileStream
    v4i cA, cB;
    v2d vA01, vA23, vB01, vB23;     // fp64 values
    v4f fA, fB;                     // fp32 values (mixed precision)
+   // the spill of the tile's last row past the streamed window, one entry per lane (entry ka + TILE + tid), requested
+   // as soon as the tile's bounds are known so that it travels with the stream instead of after it
+   int    cC;
+   double vC;
 };
 
 template <typename T>
@@ -236,6 +240,16 @@ __device__ __forceinline__ void stream_issue(const SpmvArgs &p, int ka, int k1, 
    }
 }
 
+// the spill entries: lanes without one all re-read the first spill entry (one cache line)
+template <bool F32>
+__device__ __forceinline__ void stream_issue_spill(const SpmvArgs &p, int ka, int k1, TileStream &s)
+{
+   const int kC = ka + 8 * SPMV_THREADS + (int) threadIdx.x;
+   const int qC = min(kC < k1 ? kC : ka + 8 * SPMV_THREADS, p.last_quad);
+   s.cC = p.Aj[qC];
+   s.vC = F32 ? (double) p.Aa32[qC] : p.Aa[qC];
+}
+
 // gather x for the entries held in s, park the products in LDS (prod[k - ka])
 template <bool F32>
 __device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1, int ka, const TileStream &s,
@@ -243,6 +257,8 @@ __device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1
 {
    const int kA = ka + 4 * (int) threadIdx.x;
    const int kB = kA + 4 * SPMV_THREADS;
+   const int kC = ka + 8 * SPMV_THREADS + (int) threadIdx.x;
+   const double xC = (kC < k1) ? p.x[s.cC] : 0.0;
    double vA0, vA1, vA2, vA3, vB0, vB1, vB2, vB3;
    if (F32)
    {
@@ -288,8 +304,9 @@ __device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1
          if (kB + 3 < k1) { dst[3] = vB3 * p.x[s.cB.w]; }
       }
    }
-   // tail of a tile whose last row runs past 2 quads per lane
-   for (int k = kB + 4 * SPMV_THREADS; k < k1; k += 4 * SPMV_THREADS)
+   if (kC < k1) { prod[kC - ka] = s.vC * xC; }
+   // tail of a tile whose last row runs past the spill entries as well
+   for (int k = ka + 9 * SPMV_THREADS + 4 * (int) threadIdx.x; k < k1; k += 4 * SPMV_THREADS)
    {
       const v4i c = stream_load<v4i>(p.Aj + k);
       double v0, v1, v2, v3;
@@ -321,6 +338,8 @@ __device__ __forceinline__ void stream_consume_gt(const SpmvArgs &p, int k0, int
                                                   double *prod)
 {
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int kC = ka + 8 * SPMV_THREADS + (int) threadIdx.x;
+   const double xC = (kC < k1) ? p.x[s.cC] : 0.0;
 #pragma unroll
    for (int half = 0; half < 2; half++)
    {
@@ -355,8 +374,9 @@ __device__ __forceinline__ void stream_consume_gt(const SpmvArgs &p, int k0, int
       *reinterpret_cast<v2d *>(chunk + 4 * lane)     = lo;
       *reinterpret_cast<v2d *>(chunk + 4 * lane + 2) = hi;
    }
-   // tail of a tile whose last row runs past 2 quads per lane
-   for (int k = ka + 8 * SPMV_THREADS + 4 * (int) threadIdx.x; k < k1; k += 4 * SPMV_THREADS)
+   if (kC < k1) { prod[kC - ka] = s.vC * xC; }
+   // tail of a tile whose last row runs past the spill entries as well
+   for (int k = ka + 9 * SPMV_THREADS + 4 * (int) threadIdx.x; k < k1; k += 4 * SPMV_THREADS)
    {
       const v4i c = stream_load<v4i>(p.Aj + k);
       double v0, v1, v2, v3;
@@ -425,6 +445,7 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    const int k1 = tile_k[tile + 1];
    const int tid = threadIdx.x;
    const int nrows = r1 - r0;
+   stream_issue_spill<F32>(p, ka, k1, S);
    // fixed trip count (rp_cap <= RP_CAP): an open-ended loop here is unrolled into a register-hungry
    // load pipeline that costs the kernel its eighth wave per SIMD
 #pragma unroll
