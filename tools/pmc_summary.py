@@ -16,7 +16,7 @@ import sys
 tag, prefix = sys.argv[1], sys.argv[2]
 out = {}
 kernel = None
-for d in sorted(glob.glob(prefix + "*/*/*_counter_collection.csv")):
+for d in sorted(glob.glob(prefix + "*/**/*_counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(d)):
         if "spmv_tiled_kernel<0, false, false" in r["Kernel_Name"]:
@@ -24,7 +24,7 @@ for d in sorted(glob.glob(prefix + "*/*/*_counter_collection.csv")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in agg.items():
         out[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-    name = os.path.basename(os.path.dirname(os.path.dirname(d)))
+    name = [c for c in d.split(os.sep) if c.startswith(os.path.basename(prefix))][0]
     shutil.copy(d, os.path.join("profiles", "%s_%s.csv" % (tag, name)))
 fetch = out["FETCH_SIZE"]["mean_per_launch"] * 1024
 write = out["WRITE_SIZE"]["mean_per_launch"] * 1024
