@@ -100,6 +100,8 @@ struct SpmvPlan
    int   num_tiles = 0;
    int  *d_tile_row = nullptr;       // [num_tiles+1] first row of every tile
    int  *d_tile_k   = nullptr;       // [num_tiles+1] Ai[tile_row[b]]
+   int  *d_tile_perm = nullptr;      // [num_tiles] workgroup -> tile for band-aware XCD placement (or null)
+   int   band = 0;                   // the far-coupling distance that placement was built for (0: none)
    int   prod_elems = 0;             // LDS product slots per tile: TILE + max row + pad
    bool  tiled = false;              // false -> wave-per-row kernel (long rows)
    // cached explicit transpose (built on first MatvecT)
@@ -142,6 +144,7 @@ struct SpmvArgs
    int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
    int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
+   const int           *tile_perm;   // workgroup -> tile table (overrides xcd_map), or null
 };
 void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 
@@ -151,6 +154,8 @@ void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t 
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
                         int *d_tile_k, hipStream_t s);
 int  device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s);
+// largest |col - row| of `nsamples` evenly spaced rows, copied to the host (structure probe of the plan builder)
+void sample_row_bands(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int num_rows, int nsamples, int *host_out, hipStream_t s);
 
 // BLAS-1 kernels
 void launch_set(double *y, double v, size_t n, hipStream_t s);

@@ -40,6 +40,57 @@ void spmv_default_flags(SpmvArgs &a)
    a.gather_t = gt; a.xcd_map = xcd;
 }
 
+// Band-aware XCD placement.  Workgroup g runs on XCD g % 8 and every XCD has its own L2.  A matrix from a
+// structured grid couples row i to rows i +- B (the next grid plane, B rows away): with tiles dealt to the XCDs in
+// runs, the three planes that share an x value are streamed by different XCDs and every XCD fetches its own copy
+// (measured on the 256^3 7-point operator: 2.0 GB of L2 misses per product against 1.74 GB of compulsory traffic).
+// When the far couplings of sampled rows agree on one distance B, the rows are cut into 8 slabs by (row mod B) and
+// XCD c is handed the tiles of slab c, plane after plane: the x values it fetched as the upper neighbours of plane p
+// are still in its L2 when plane p + 1 and p + 2 read them again.  Irregular matrices (coarse levels, interpolation)
+// do not pass the agreement test and keep the run-of-8 placement.  HYPRE_AMD_SPMV_BAND=0 switches it off.
+static void build_band_placement(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
+{
+   static int enabled = -1;
+   if (enabled < 0) { const char *e = getenv("HYPRE_AMD_SPMV_BAND"); enabled = e ? atoi(e) : 1; }
+   if (!enabled || p->num_tiles < 2048 || A->num_rows != A->num_cols) { return; }
+   const int ns = 1024;
+   std::vector<int> far((size_t) ns);
+   sample_row_bands(A->i, A->j, A->num_rows, ns, far.data(), s);
+   std::vector<int> sorted(far);
+   std::sort(sorted.begin(), sorted.end());
+   const int B = sorted[(size_t) ns / 2];
+   int agree = 0;
+   for (int f : far) { if (std::abs(f - B) * 50 <= B) { agree++; } }
+   const long long rows_per_tile = std::max(1LL, (long long) A->num_rows / p->num_tiles);
+   // one distance for most rows, at least four planes, slabs of at least 8 tiles
+   if (B <= 0 || agree * 10 < ns * 6 || 4LL * B > A->num_rows || (long long) B < 8 * 8 * rows_per_tile) { return; }
+   std::vector<int> trow((size_t) p->num_tiles + 1);
+   HIP_CHECK(hipMemcpyAsync(trow.data(), p->d_tile_row, sizeof(int) * ((size_t) p->num_tiles + 1), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   std::vector<std::vector<int>> cls(8);
+   for (int t = 0; t < p->num_tiles; t++)
+   {
+      const int c = (int) (((long long) (trow[(size_t) t] % B) * 8) / B);
+      cls[(size_t) std::min(std::max(c, 0), 7)].push_back(t);
+   }
+   // workgroup 8k + c -> k-th tile of slab c; slabs that run out borrow from the tail of the longest one
+   std::vector<int> perm((size_t) p->num_tiles, -1);
+   std::vector<size_t> next(8, 0);
+   std::vector<int> leftovers;
+   for (int g = 0; g < p->num_tiles; g++)
+   {
+      const size_t c = (size_t) (g & 7);
+      if (next[c] < cls[c].size()) { perm[(size_t) g] = cls[c][next[c]++]; }
+   }
+   for (size_t c = 0; c < 8; c++) { for (size_t k = next[c]; k < cls[c].size(); k++) { leftovers.push_back(cls[c][k]); } }
+   size_t lo = 0;
+   for (int g = 0; g < p->num_tiles; g++) { if (perm[(size_t) g] < 0) { perm[(size_t) g] = leftovers[lo++]; } }
+   HIP_CHECK(hipMalloc((void **) &p->d_tile_perm, sizeof(int) * (size_t) p->num_tiles));
+   HIP_CHECK(hipMemcpyAsync(p->d_tile_perm, perm.data(), sizeof(int) * (size_t) p->num_tiles, hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   p->band = B;
+}
+
 static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> &plan_table()
 {
    static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> t;
@@ -51,6 +102,7 @@ static void free_plan(SpmvPlan *p)
    if (!p) { return; }
    if (p->d_tile_row) { HIP_CHECK(hipFree(p->d_tile_row)); }
    if (p->d_tile_k) { HIP_CHECK(hipFree(p->d_tile_k)); }
+   if (p->d_tile_perm) { HIP_CHECK(hipFree(p->d_tile_perm)); }
    if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
    if (p->Lstrict) { hypre_CSRMatrixDestroy(p->Lstrict); }
@@ -103,6 +155,7 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
          p->prod_elems = SPMV_TILE + ((p->max_row_nnz + 3) & ~3) + 8;
          launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
          p->max_tile_rows = device_max_row_nnz(p->d_tile_row, p->num_tiles, s);     // max over tiles of tile_row[b+1] - tile_row[b]
+         build_band_placement(p, A, s);
       }
    }
    t[A] = p;

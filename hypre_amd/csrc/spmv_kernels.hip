@@ -245,7 +245,8 @@ template <bool F32>
 __device__ __forceinline__ void stream_issue_spill(const SpmvArgs &p, int ka, int k1, TileStream &s)
 {
    const int kC = ka + 8 * SPMV_THREADS + (int) threadIdx.x;
-   const int qC = min(kC < k1 ? kC : ka + 8 * SPMV_THREADS, p.last_quad);
+   // a spill entry is an entry of the matrix (kC < k1 <= nnz): only the stand-in address needs the clamp
+   const int qC = kC < k1 ? kC : min(ka + 8 * SPMV_THREADS, p.last_quad);
    s.cC = p.Aj[qC];
    s.vC = F32 ? (double) p.Aa32[qC] : p.Aa[qC];
 }
@@ -418,7 +419,8 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    // consecutive tiles; xcd_map < 0: one contiguous eighth of the tiles per XCD.
    // Speed only: any placement is correct.
    int tile = (int) blockIdx.x;
-   if (p.xcd_map > 0)
+   if (p.tile_perm) { tile = p.tile_perm[blockIdx.x]; }
+   else if (p.xcd_map > 0)
    {
       const int g = blockIdx.x >> 3, c = blockIdx.x & 7, C = p.xcd_map;
       tile = (g / C) * (8 * C) + c * C + (g % C);
@@ -562,6 +564,27 @@ void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tile
                       num_tiles, d_tile_row, d_tile_k);
 }
 
+__global__ void sample_row_bands_kernel(const HYPRE_Int *__restrict__ Ai, const HYPRE_Int *__restrict__ Aj, int num_rows,
+                                        int nsamples, int *__restrict__ out)
+{
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= nsamples) { return; }
+   const int row = (int) ((long long) num_rows * t / nsamples);
+   int far = 0;
+   for (int k = Ai[row]; k < Ai[row + 1]; k++) { far = max(far, abs(Aj[k] - row)); }
+   out[t] = far;
+}
+
+void sample_row_bands(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int num_rows, int nsamples, int *host_out, hipStream_t s)
+{
+   int *d_out = nullptr;
+   HIP_CHECK(hipMalloc((void **) &d_out, sizeof(int) * (size_t) nsamples));
+   hipLaunchKernelGGL(sample_row_bands_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, s, Ai, Aj, num_rows, nsamples, d_out);
+   HIP_CHECK(hipMemcpyAsync(host_out, d_out, sizeof(int) * (size_t) nsamples, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(d_out));
+}
+
 int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
 {
    if (num_rows <= 0) { return 0; }
@@ -644,6 +667,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    if (plan->num_rows <= 0) { return; }
    SpmvArgs a = args;
    a.last_quad = (plan->nnz > 0 ? (int) (plan->nnz - 1) : 0) & ~3;
+   a.tile_perm = plan->d_tile_perm;
    if (handle().fp32_values && !a.Aa32 && plan->nnz > 0)
    {
       // mixed precision: matrix values stream as fp32 (converted once per matrix), vectors and

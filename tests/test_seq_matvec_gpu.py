@@ -214,3 +214,21 @@ def test_multivectors_column_by_column(gpu_lib, oracle, par):
         zr = Bm[:, k].copy()
         oracle.csr_matvecT(-0.4, oA, X[:, k].copy(), 0.5, zr)
         assert np.all(np.abs(Z[:, k] - zr) <= _bound(A.T.tocsr(), X[:, k], -0.4, 0.5, Bm[:, k]))
+
+
+@pytest.mark.parametrize("total", [2049, 2050, 2051, 2052, 2053, 4099, 2048 + 255, 2048 + 256, 2048 + 257, 2048 + 600])
+def test_last_row_spills_past_the_streamed_window(gpu_lib, oracle, total):
+    """The tiled kernel streams 2048 entries per tile and fetches what the tile's last row has beyond that window
+    separately (one entry per lane, then a strided loop): the spill may end in the matrix's last, partial 16-byte quad
+    and may be longer than the 256 lanes."""
+    rng = np.random.default_rng(total)
+    n_short = 340
+    lens = [6] * n_short                     # 2040 entries in short rows, then one long row to `total`
+    lens.append(total - 6 * n_short)
+    ncols = 5000
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cols = np.concatenate([np.sort(rng.choice(ncols, size=l, replace=False)) for l in lens]).astype(np.int32)
+    vals = rng.uniform(-1.0, 1.0, size=indptr[-1])
+    A = sp.csr_matrix((vals, cols, indptr), shape=(len(lens), ncols))
+    _run(gpu_lib, oracle, A, 1.0, 0.0, seed=total)
+    _run(gpu_lib, oracle, A, -0.7, 1.3, seed=total + 1)
