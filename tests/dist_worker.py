@@ -18,7 +18,9 @@ def main():
     from hypre_amd import binding as B, ij, distributed
     import pyoracle as O
 
-    case = json.loads(sys.argv[1])
+    spec = json.loads(sys.argv[1])
+    # {"batch": [case, ...]}: several cases behind one launch (process start-up and the torch import dominate a case)
+    cases = spec["batch"] if "batch" in spec else [spec]
     # a rank that stops making progress dumps its Python stack and exits instead of hanging the suite
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("HYPRE_AMD_TEST_WATCHDOG", "300")), exit=True)
@@ -28,6 +30,13 @@ def main():
     comm = distributed.create_callback_comm(dist, rank, world) if world > 1 else 0     # 0: hypre_MPI_COMM_WORLD of one rank
     if world > 1 and L.hypre_amd_CommSelfTest(comm, 4099) != 0:
         raise SystemExit("communicator self-test failed on rank %d" % rank)
+    for case in cases:
+        run_case(case, L, B, ij, O, dist, comm, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_case(case, L, B, ij, O, dist, comm, rank, world):
     opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
     for name in ("fromfile", "rhsfromfile"):          # the reference's input files live beside the goldens
         if getattr(opt, name):
@@ -138,9 +147,11 @@ def main():
                        matvecT_err=float(np.max(np.abs(zd - zr)) / np.max(np.abs(zr))),
                        dot_err=float(abs(parts[0]["dev_dot"] - float(np.dot(xt, yr))) / abs(float(np.dot(xt, yr)))),
                        x_err=float(np.max(np.abs(xd - xg)) / np.max(np.abs(xg))))
+        if "name" in case:
+            out["name"] = case["name"]
         print("RESULT " + json.dumps(out), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+    L.HYPRE_BoomerAMGDestroy(s)
+    L.hypre_ParCSRMatrixDestroy(A)
 
 
 if __name__ == "__main__":
