@@ -33,9 +33,9 @@ namespace {
 // host halo helpers over a comm package
 // ---------------------------------------------------------------------------
 template <class T> struct HaloJob;
-template <> struct HaloJob<double>       { static const int fwd = 1,  rev = 2; };
-template <> struct HaloJob<HYPRE_Int>    { static const int fwd = 11, rev = 12; };
-template <> struct HaloJob<HYPRE_BigInt> { static const int fwd = 21, rev = 22; };
+template <> struct HaloJob<double>       { static constexpr int fwd = 1,  rev = 2; };
+template <> struct HaloJob<HYPRE_Int>    { static constexpr int fwd = 11, rev = 12; };
+template <> struct HaloJob<HYPRE_BigInt> { static constexpr int fwd = 21; };      // ghost -> owner is never needed for indices
 
 // owner values -> ghost array (offd column order)
 template <class T>

@@ -668,7 +668,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       {
          // ascend: u_f += P u_c, written to whichever buffer lets the
          // post-smoothing sweeps end in the level's home vector
-         const int fine = level - 1, coarse = level;
+         const int fine = level - 1;
          LevelVec &uf = lv[(size_t) fine];
          int flips = 0;
          {
