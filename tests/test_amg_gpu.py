@@ -69,6 +69,38 @@ def test_single_sweep(gpu_lib, oracle, relax_type, relax_points, w, zero, level)
     lib.HYPRE_BoomerAMGDestroy(s)
 
 
+@pytest.mark.parametrize("level", [0, 1])
+def test_two_stage_gs_tends_to_the_gauss_seidel_sweep(gpu_lib, level):
+    """The reference's regression set has no job with relax 11 / 12, so beside the oracle comparison the
+    two-stage sweep is tied to the golden-pinned hybrid Gauss-Seidel through the identity it is built on
+    (par_relax.c:1506-1588): u + sum_{j<=k} (-D^-1 L)^j D^-1 (f - A u)  ->  u + (D + L)^-1 (f - A u), the forward
+    Gauss-Seidel sweep, as the number of inner iterations k grows (here rho(D^-1 L) <= 1/2 and k = 60)."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    opt, A0, s = _setup(lib, n=(11, 10, 9), relax_type=11, coarsen_type=8)
+    A, cf, l1 = _level(lib, s, level)                      # relax 11/12: l1 holds the diagonal (ams.c:695-726, option 5)
+    n = A.contents.diag.contents.num_rows
+    f, u0 = rand_vector(n, 7), rand_vector(n, 8)
+    du, df = B.parvec_from_numpy(u0), B.parvec_from_numpy(f)
+    dr, dz = B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(np.zeros(n))
+    lib.hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(A, df, 1.0, 1.0, l1, du, dr, dz, 60)
+    B.check()
+    u_ts = B.parvec_to_numpy(du)
+    dg, dv, dw = B.parvec_from_numpy(u0), B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(np.zeros(n))
+    lib.hypre_BoomerAMGRelax(A, df, None, 3, 0, 1.0, 1.0, None, dg, dv, dw)          # forward Gauss-Seidel on one rank
+    B.check()
+    u_gs = B.parvec_to_numpy(dg)
+    assert np.max(np.abs(u_ts - u_gs)) <= 1e-12 * np.max(np.abs(u_gs))
+    # and the sweeps the cycle uses are the first partial sums of that series
+    for k, relax_type in ((1, 11), (2, 12)):
+        da, db = B.parvec_from_numpy(u0), B.parvec_from_numpy(u0)
+        lib.hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(A, df, 1.0, 1.0, l1, da, dr, dz, k)
+        lib.hypre_BoomerAMGRelax(A, df, None, relax_type, 0, 1.0, 1.0, l1, db, dv, dw)
+        B.check()
+        assert np.array_equal(B.parvec_to_numpy(da), B.parvec_to_numpy(db))
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
 @pytest.mark.parametrize("relax_type", [3, 4, 6, 8, 13, 14, 88, 89])
 @pytest.mark.parametrize("relax_points,w,omega", [(0, 1.0, 1.0), (1, 1.0, 1.0), (-1, 1.0, 1.0), (0, 0.8, 1.2), (1, 0.9, 1.0)])
 @pytest.mark.parametrize("level", [0, 1])
