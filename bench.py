@@ -69,6 +69,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     dist = None
+    if world > 1:
+        # a rank that stops making progress (a peer died, a collective never completes) dumps its Python stack and
+        # exits instead of hanging the launcher; HYPRE_AMD_BENCH_WATCHDOG seconds, default 20 minutes
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("HYPRE_AMD_BENCH_WATCHDOG", "1200")), exit=True)
     # HYPRE_AMD_BENCH_TRANSPORT=gloo: rehearsal mode (ranks may share one GPU, halo traffic staged
     # over the host through torch.distributed/gloo).  Default: RCCL over xGMI, one GPU per rank.
     transport = os.environ.get("HYPRE_AMD_BENCH_TRANSPORT", "rccl")
