@@ -254,6 +254,57 @@ HYPRE_Int HYPRE_BoomerAMGSetLevelOuterWt(HYPRE_Solver s, HYPRE_Real v, HYPRE_Int
 }
 HYPRE_Int HYPRE_BoomerAMGSetPrintLevel(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->print_level = v; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGSetLogging(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); d->logging = v; return hypre_error_flag; }
+
+// ---- option gates -------------------------------------------------------------------------------------------------
+// Setters of HYPRE_parcsr_amg.c that an application written against hypre calls as a matter of course, for options
+// whose non-default branches are not built here.  The value that selects what this library implements is accepted;
+// anything else raises HYPRE_ERROR_ARG on argument 2 with a message, it is never dropped silently.
+namespace {
+HYPRE_Int gate(const char *what, bool ok)
+{
+   if (!ok)
+   {
+      hypre_error_in_arg(2);
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, what);
+   }
+   return hypre_error_flag;
+}
+}  // namespace
+HYPRE_Int HYPRE_BoomerAMGSetMeasureType(HYPRE_Solver s, HYPRE_Int v)       // local (0) or global (1) measures of the first HMIS pass
+{
+   AMG_DATA(s, d);
+   if (v != 0 && v != 1) { hypre_error_in_arg(2); return hypre_error_flag; }
+   d->measure_type = v;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_BoomerAMGSetDebugFlag(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); (void) d; (void) v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetNumPaths(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); (void) d; (void) v; return hypre_error_flag; }      // aggressive coarsening only
+HYPRE_Int HYPRE_BoomerAMGSetAggNumLevels(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetAggNumLevels: aggressive coarsening is not built (0 only)", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetNodal(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetNodal: nodal systems coarsening is not built (0 only)", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetSeqThreshold(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetSeqThreshold: the sequential coarse solve is not built (0 only; see hypre_amd_BoomerAMGSetReplicateThreshold)", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetRedundant(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetRedundant: 0 only", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetRAP2(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetRAP2: the coarse operator is the Galerkin triple product (0 only)", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetRestriction(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetRestriction: R = P^T (0 only)", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetSmoothNumLevels(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetSmoothNumLevels: Schwarz / ILU / FSAI / ParaSails smoothers are not built (0 only)", v == 0); }
+HYPRE_Int HYPRE_BoomerAMGSetSmoothType(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); (void) d; (void) v; return hypre_error_flag; }    // inert while SmoothNumLevels is 0
+HYPRE_Int HYPRE_BoomerAMGSetSmoothNumSweeps(HYPRE_Solver s, HYPRE_Int v) { AMG_DATA(s, d); (void) d; (void) v; return hypre_error_flag; }
+HYPRE_Int HYPRE_BoomerAMGSetAdditive(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetAdditive: additive cycles are not built (-1 only)", v == -1); }
+HYPRE_Int HYPRE_BoomerAMGSetMultAdditive(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetMultAdditive: additive cycles are not built (-1 only)", v == -1); }
+HYPRE_Int HYPRE_BoomerAMGSetSimple(HYPRE_Solver s, HYPRE_Int v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetSimple: additive cycles are not built (-1 only)", v == -1); }
+HYPRE_Int HYPRE_BoomerAMGSetNonGalerkinTol(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetNonGalerkinTol: non-Galerkin coarse operators are not built (0.0 only)", v == 0.0); }
+HYPRE_Int HYPRE_BoomerAMGSetADropTol(HYPRE_Solver s, HYPRE_Real v)
+{ AMG_DATA(s, d); (void) d; return gate("HYPRE_BoomerAMGSetADropTol: dropping from coarse operators is not built (0.0 only)", v == 0.0); }
 HYPRE_Int HYPRE_BoomerAMGGetNumIterations(HYPRE_Solver s, HYPRE_Int *v)
 { AMG_DATA(s, d); *v = d->num_iterations; return hypre_error_flag; }
 HYPRE_Int HYPRE_BoomerAMGGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v)

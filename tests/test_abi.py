@@ -108,3 +108,33 @@ def test_hot_kernels_keep_full_occupancy():
         assert r["VGPRs"] <= 64 and r["Occupancy"] == 8, r
     for r in rows:
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, r
+
+
+def test_option_gates_accept_the_built_branch_and_refuse_the_rest(lib):
+    """Setters for options whose other branches are not built: the supported value passes, anything else is an
+    argument error with a message (never silently ignored)."""
+    import ctypes as C
+    s = C.c_void_p()
+    lib.HYPRE_BoomerAMGCreate(C.byref(s))
+    lib.HYPRE_ClearAllErrors()
+    for name, ok, bad in (("AggNumLevels", 0, 1), ("Nodal", 0, 4), ("SeqThreshold", 0, 100), ("RAP2", 0, 1),
+                          ("Restriction", 0, 1), ("SmoothNumLevels", 0, 3), ("Additive", -1, 0), ("MultAdditive", -1, 0),
+                          ("Simple", -1, 0), ("Redundant", 0, 1)):
+        fn = getattr(lib, "HYPRE_BoomerAMGSet" + name)
+        assert fn(s, ok) == 0 and lib.HYPRE_GetError() == 0, name
+        fn(s, bad)
+        assert lib.HYPRE_GetError() & 4 and lib.HYPRE_GetErrorArg() == 2, name
+        assert name.encode() in lib.hypre_amd_LastErrorMessage()
+        lib.HYPRE_ClearAllErrors()
+    for name in ("NonGalerkinTol", "ADropTol"):
+        fn = getattr(lib, "HYPRE_BoomerAMGSet" + name)
+        assert fn(s, 0.0) == 0 and lib.HYPRE_GetError() == 0
+        fn(s, 0.05)
+        assert lib.HYPRE_GetError() & 4
+        lib.HYPRE_ClearAllErrors()
+    for name, v in (("MeasureType", 1), ("DebugFlag", 3), ("NumPaths", 2), ("SmoothType", 6), ("SmoothNumSweeps", 2)):
+        assert getattr(lib, "HYPRE_BoomerAMGSet" + name)(s, v) == 0 and lib.HYPRE_GetError() == 0
+    lib.HYPRE_BoomerAMGSetMeasureType(s, 5)
+    assert lib.HYPRE_GetError() & 4
+    lib.HYPRE_ClearAllErrors()
+    lib.HYPRE_BoomerAMGDestroy(s)
