@@ -78,6 +78,14 @@ HYPRE_Int HYPRE_GMRESSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn precond, HY
    d->precond = precond; d->precond_setup = precond_setup; d->precond_data = precond_solver;
    return hypre_error_flag;
 }
+HYPRE_Int HYPRE_GMRESSetLogging(HYPRE_Solver s, HYPRE_Int v) { (void) s; (void) v; return hypre_error_flag; }       // accepted, inert
+HYPRE_Int HYPRE_GMRESSetPrintLevel(HYPRE_Solver s, HYPRE_Int v) { (void) s; (void) v; return hypre_error_flag; }
+HYPRE_Int HYPRE_GMRESSetRelChange(HYPRE_Solver s, HYPRE_Int v)
+{
+   (void) s;
+   if (v != 0) { hypre_error_in_arg(2); hypre_error_w_msg(HYPRE_ERROR_GENERIC, "HYPRE_GMRESSetRelChange: the relative-change stopping test is not built (0 only)"); }
+   return hypre_error_flag;
+}
 HYPRE_Int HYPRE_GMRESGetNumIterations(HYPRE_Solver s, HYPRE_Int *v) { *v = ((hypre_amd_GMRESData *) s)->num_iterations; return hypre_error_flag; }
 HYPRE_Int HYPRE_GMRESGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v) { *v = ((hypre_amd_GMRESData *) s)->rel_residual_norm; return hypre_error_flag; }
 HYPRE_Int HYPRE_GMRESGetConverged(HYPRE_Solver s, HYPRE_Int *v) { *v = ((hypre_amd_GMRESData *) s)->converged; return hypre_error_flag; }

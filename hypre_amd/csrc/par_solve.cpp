@@ -847,6 +847,22 @@ HYPRE_Int HYPRE_PCGSetPrecond(HYPRE_Solver s, HYPRE_PtrToSolverFcn precond, HYPR
    d->precond = precond; d->precond_setup = precond_setup; d->precond_data = precond_solver;
    return hypre_error_flag;
 }
+// options of krylov/HYPRE_pcg.c an application sets routinely: logging and printing are accepted and inert (this PCG
+// keeps no residual history and prints nothing); the relative-change and recomputed-residual variants are not built
+HYPRE_Int HYPRE_PCGSetLogging(HYPRE_Solver s, HYPRE_Int v) { (void) s; (void) v; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGSetPrintLevel(HYPRE_Solver s, HYPRE_Int v) { (void) s; (void) v; return hypre_error_flag; }
+HYPRE_Int HYPRE_PCGSetRelChange(HYPRE_Solver s, HYPRE_Int v)
+{
+   (void) s;
+   if (v != 0) { hypre_error_in_arg(2); hypre_error_w_msg(HYPRE_ERROR_GENERIC, "HYPRE_PCGSetRelChange: the relative-change stopping test is not built (0 only)"); }
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_PCGSetRecomputeResidual(HYPRE_Solver s, HYPRE_Int v)
+{
+   (void) s;
+   if (v != 0) { hypre_error_in_arg(2); hypre_error_w_msg(HYPRE_ERROR_GENERIC, "HYPRE_PCGSetRecomputeResidual: 0 only"); }
+   return hypre_error_flag;
+}
 HYPRE_Int HYPRE_PCGGetNumIterations(HYPRE_Solver s, HYPRE_Int *v) { *v = ((hypre_amd_PCGData *) s)->num_iterations; return hypre_error_flag; }
 HYPRE_Int HYPRE_PCGGetFinalRelativeResidualNorm(HYPRE_Solver s, HYPRE_Real *v) { *v = ((hypre_amd_PCGData *) s)->rel_residual_norm; return hypre_error_flag; }
 
