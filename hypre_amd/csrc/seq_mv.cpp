@@ -277,9 +277,11 @@ HYPRE_Int hypre_CSRMatrixSetRownnz(hypre_CSRMatrix *m)
 
 static void migrate_array(void **p, size_t bytes, HYPRE_MemoryLocation from, HYPRE_MemoryLocation to)
 {
-   if (!*p || !bytes) { return; }
-   void *q = hypre_MAlloc(bytes, to);
-   hypre_Memcpy(q, *p, bytes, to, from);
+   if (!*p) { return; }
+   // an empty array may still own a (minimal) allocation: it has to change memory space with its header, or it is
+   // later freed in the wrong one (a rank without rows on a coarse level: hipFree of a host pointer)
+   void *q = hypre_MAlloc(bytes ? bytes : 8, to);
+   if (bytes) { hypre_Memcpy(q, *p, bytes, to, from); }
    hypre_Free(*p, from);
    *p = q;
 }

@@ -151,7 +151,9 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             out["name"] = case["name"]
         print("RESULT " + json.dumps(out), flush=True)
     L.HYPRE_BoomerAMGDestroy(s)
+    B.check()                      # a free with the wrong memory space or a double free shows up here
     L.hypre_ParCSRMatrixDestroy(A)
+    B.check()
 
 
 if __name__ == "__main__":
