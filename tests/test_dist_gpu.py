@@ -5,20 +5,53 @@ the CPU oracle running the same hierarchy as virtual ranks.  (The RCCL transport
 needs one GPU per rank and is exercised by bench.py --gpus N.)"""
 import pytest
 
-from test_dist_golden import GOLD, run_ranks
+import json
+import os
+import subprocess
+import sys
+
+from test_dist_golden import GOLD, HERE, run_ranks
 
 pytestmark = pytest.mark.gpu
 
+DEVICE_CASES = ["smoother.out.10", "smoother.out.9", "solvers.out.21", "default.out.1",
+                "smoother.out.0", "smoother.out.3", "smoother.out.11", "smoother.out.11.2",
+                "smoother.out.12", "smoother.out.16", "smoother.out.17", "smoother.out.23",
+                "matrix.out.11", "solvers.out.404", "solvers.out.405",
+                "solvers.out.2", "solvers.out.20", "solvers.out.22", "elast.out.7",
+                "solvers.out.sysu", "solvers.out.29", "solvers.out.30", "smoother.out.18", "smoother.out.19",
+                "smoother.out.20", "smoother.out.14", "smoother.out.15", "solvers.out.25"]
+_batches = {}
 
-@pytest.mark.parametrize("name", ["smoother.out.10", "smoother.out.9", "solvers.out.21", "default.out.1",
-                                  "smoother.out.0", "smoother.out.3", "smoother.out.11", "smoother.out.11.2",
-                                  "smoother.out.12", "smoother.out.16", "smoother.out.17", "smoother.out.23",
-                                  "matrix.out.11", "solvers.out.404", "solvers.out.405",
-                                  "solvers.out.2", "solvers.out.20", "solvers.out.22", "elast.out.7",
-                                  "solvers.out.sysu", "solvers.out.29", "solvers.out.30", "smoother.out.18", "smoother.out.19", "smoother.out.20", "smoother.out.14", "smoother.out.15", "solvers.out.25"])
+
+def device_batch_result(name):
+    """The device cases of one rank count share a launch: one process per rank solves them one after the other (which
+    also exercises create / solve / destroy cycles inside one process), ranks share the card."""
+    nranks = GOLD[name]["ranks"]
+    if nranks not in _batches:
+        from conftest import free_port
+        names = [k for k in DEVICE_CASES if GOLD[k]["ranks"] == nranks]
+        spec = {"batch": [{"name": k, "options": GOLD[k]["options"], "device": 1} for k in names]}
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
+               json.dumps(spec)]
+        env = dict(os.environ, OMP_NUM_THREADS="1", HYPRE_AMD_TEST_WATCHDOG="900")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+        res = {}
+        for line in r.stdout.splitlines():
+            if line.startswith("RESULT "):
+                d = json.loads(line[len("RESULT "):])
+                res[d["name"]] = d
+        _batches[nranks] = (r.returncode, res, r.stdout[-2000:] + r.stderr[-2000:])
+    rc, res, tail = _batches[nranks]
+    assert name in res, "no result for %s (worker exit code %d)\n%s" % (name, rc, tail)
+    return res[name]
+
+
+@pytest.mark.parametrize("name", DEVICE_CASES)
 def test_two_or_three_ranks_on_device(name):
     case = dict(GOLD[name])
-    out = run_ranks(case["ranks"], {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1})
+    out = device_batch_result(name)
     exp = case["expect"]
     assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
     assert out["dev_iterations"] == out["iterations"]
