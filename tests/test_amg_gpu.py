@@ -377,3 +377,45 @@ def test_host_hierarchy_fails_loudly(gpu_lib):
     lib.HYPRE_BoomerAMGSolve(s, A, hb, hx)
     with pytest.raises(B.HypreAmdError, match="host execution is not part of this library"):
         B.check()
+
+
+def test_solver_life_cycle_leaves_no_error(gpu_lib, oracle):
+    """Set up, solve, set up again on another matrix with another smoother, solve, destroy everything: every free must
+    happen in the memory space the object lives in (the sticky error flag stays clear), and the second hierarchy is
+    not contaminated by the first."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    lib.HYPRE_ClearAllErrors()
+    opt1 = ij.IJOptions(n=(10, 9, 8), relax_type=16, coarsen_type=8)           # scaled Chebyshev: per-level vectors
+    opt2 = ij.IJOptions(n=(7, 7, 7), relax_type=13, coarsen_type=10, problem="27pt")
+    A1, A2 = ij.build_matrix(opt1), ij.build_matrix(opt2)
+    s = ij.create_amg(opt1, memory_location=B.HYPRE_MEMORY_DEVICE)
+    lib.HYPRE_BoomerAMGSetup(s, A1, None, None)
+    lib.hypre_ParCSRMatrixMigrate(A1, B.HYPRE_MEMORY_DEVICE)
+    b1, x1 = B.parvec_from_numpy(np.ones(720)), B.parvec_from_numpy(np.zeros(720))
+    lib.HYPRE_BoomerAMGSolve(s, A1, b1, x1)
+    B.check()
+    # same solver object, new problem, new smoother family
+    lib.HYPRE_BoomerAMGSetRelaxType(s, 13)
+    lib.HYPRE_BoomerAMGSetCycleRelaxType(s, 14, 2)
+    lib.HYPRE_BoomerAMGSetCoarsenType(s, 10)
+    lib.HYPRE_BoomerAMGSetup(s, A2, None, None)
+    lib.hypre_ParCSRMatrixMigrate(A2, B.HYPRE_MEMORY_DEVICE)
+    b2, x2 = B.parvec_from_numpy(np.ones(343)), B.parvec_from_numpy(np.zeros(343))
+    lib.HYPRE_BoomerAMGSolve(s, A2, b2, x2)
+    B.check()
+    its, rel = C.c_int(), C.c_double()
+    lib.HYPRE_BoomerAMGGetNumIterations(s, C.byref(its))
+    lib.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+    amg = oracle.amg_from_solvers([s])
+    xo = np.zeros(343)
+    oits, orel, _, _ = amg.solve(np.ones(343), xo, tol=opt2.tol, max_iter=opt2.mg_max_iter)
+    assert its.value == oits and abs(rel.value - orel) <= 1e-6 * orel
+    lib.hypre_ParCSRMatrixDestroy(A1)          # the first matrix may go while the solver lives on the second
+    B.check()
+    lib.HYPRE_BoomerAMGDestroy(s)
+    B.check()
+    lib.hypre_ParCSRMatrixDestroy(A2)
+    for v in (b1, x1, b2, x2):
+        lib.hypre_ParVectorDestroy(v)
+    B.check()
