@@ -104,3 +104,14 @@ def test_rccl_provider_single_rank_round_trip():
     assert L.hypre_amd_CommSelfTest(comm, 24) == 0
     B.check()
     L.hypre_amd_CommDestroy(comm)
+
+
+def test_rank_without_rows_on_device():
+    """Three grid points across four ranks: one rank owns nothing on any level.  Empty blocks, empty halos and empty
+    device arrays must go through setup, migration, the distributed solve and destruction without an error."""
+    opts = {"n": [3, 5, 4], "P": [4, 1, 1], "relax_type": 18, "coarsen_type": 8}
+    out = run_ranks(4, {"options": opts, "device": 1}, timeout=600, extra={"device": 1})
+    assert out["sizes"][0] == 60
+    assert out["dev_iterations"] == out["iterations"]
+    assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
+    assert out["x_err"] < 1e-9
