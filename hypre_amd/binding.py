@@ -155,6 +155,7 @@ PROTOTYPES = {
     "hypre_amd_CommDestroy": (Int, [Int]),
     "hypre_amd_RCCLGetUniqueId": (Int, [C.c_void_p]),
     "hypre_amd_CommCreateRCCL": (Int, [C.c_void_p, C.c_int, C.c_int]),
+    "hypre_amd_CommCreateStreamStaged": (Int, [Int]),
     "hypre_MPI_Comm_rank": (Int, [Int, IntP]),
     "hypre_MPI_Comm_size": (Int, [Int, IntP]),
     "hypre_amd_CommSelfTest": (Int, [Int, Int]),
@@ -183,6 +184,9 @@ PROTOTYPES = {
     "hypre_CSRMatrixMatvecDevice": (Int, [Int, Real, CSRp, Vecp, Real, Vecp, Vecp, Int]),
     "hypre_CSRMatrixSpMVDevice": (Int, [Int, Real, CSRp, Vecp, Real, Vecp, Int]),
     "hypre_amd_CSRMatrixInvalidatePlan": (Int, [CSRp]),
+    "hypre_amd_SpmvSetBandPolicy": (Int, [Int, Int, Int]),
+    "hypre_amd_SpmvSetVariant": (Int, [Int, Int]),
+    "hypre_amd_CSRMatrixPlanInfo": (Int, [CSRp, IntP, IntP]),
     "hypre_SeqVectorSetConstantValues": (Int, [Vecp, Real]),
     "hypre_SeqVectorCopy": (Int, [Vecp, Vecp]),
     "hypre_SeqVectorScale": (Int, [Real, Vecp]),

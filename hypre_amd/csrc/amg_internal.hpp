@@ -23,6 +23,10 @@ struct AmgPrivate
    std::vector<double *> u_alt;     // [num_levels], device
    std::vector<int>      u_alt_len;
 
+   // mixed precision: fp64 residual and correction of the outer solve loop (a cycle on fp32-rounded operators applied
+   // to a non-zero iterate must work on the error equation, or the iteration converges to the rounded system's solution)
+   hypre_ParVector *mp_r = nullptr, *mp_e = nullptr;
+
    // relax 15: one unpreconditioned-CG solver per level, created at the first cycle that needs it
    std::vector<HYPRE_Solver> cg_smoothers;
 

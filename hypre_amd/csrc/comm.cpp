@@ -149,6 +149,109 @@ void rccl_destroy(void *vctx)
    delete c;
 }
 
+
+// ---------------------------------------------------------------------------
+// Stream-staged provider: device-buffer semantics on top of a host-buffer transport.
+//
+// What an application whose MPI cannot take device pointers plugs in (the reference's own device path
+// stages its halo buffers the same way, par_csr_communication.c:483-526 with hypre_TMemcpy around the
+// MPI calls) — and what lets the library's device-buffer flow (pack -> event -> exchange on the
+// communication stream -> event -> ghost product) run between ranks that share one GPU, where RCCL
+// refuses to form a communicator.  exchange(on_device = 1, stream):
+//    device -> pinned host on `stream`; wait for `stream` (and with it for everything the caller
+//    ordered before the exchange, i.e. the pack event); inner host exchange; pinned host -> device
+//    enqueued on `stream`, NOT waited for: the caller's event after the call covers it.
+// ---------------------------------------------------------------------------
+struct StagedCtx
+{
+   hypre_amd_CommOps inner{};
+   char  *h_stage = nullptr;     // pinned
+   size_t h_len = 0;
+   hipEvent_t done = nullptr;    // recorded behind the last host -> device copies: the staging buffer is busy until then
+   char *stage(size_t n)
+   {
+      if (done) { (void) hipEventSynchronize(done); }
+      if (h_len < n)
+      {
+         if (h_stage) { (void) hipHostFree(h_stage); }
+         size_t len = n < (1u << 16) ? (1u << 16) : n;
+         if (hipHostMalloc((void **) &h_stage, len, hipHostMallocDefault) != hipSuccess) { h_stage = nullptr; h_len = 0; return nullptr; }
+         h_len = len;
+      }
+      return h_stage;
+   }
+};
+
+int staged_exchange(void *vctx, int ns, const int *dest, void *const *sbuf, const size_t *sbytes,
+                    int nr, const int *src, void *const *rbuf, const size_t *rbytes, int on_device, void *vstream)
+{
+   StagedCtx *c = (StagedCtx *) vctx;
+   if (!on_device) { return c->inner.exchange(c->inner.ctx, ns, dest, sbuf, sbytes, nr, src, rbuf, rbytes, 0, nullptr); }
+   hipStream_t s = (hipStream_t) vstream;
+   if (!s) { s = hamd::handle().comm_stream; }
+   size_t tot = 0;
+   for (int i = 0; i < ns; i++) { tot += (sbytes[i] + 15) & ~(size_t) 15; }
+   for (int i = 0; i < nr; i++) { tot += (rbytes[i] + 15) & ~(size_t) 15; }
+   char *st = c->stage(tot + 16);
+   if (!st) { hypre_error_w_msg(HYPRE_ERROR_MEMORY, "stream-staged transport: pinned staging allocation failed"); return 1; }
+   std::vector<void *> hs((size_t) ns), hr((size_t) nr);
+   size_t off = 0;
+   for (int i = 0; i < ns; i++)
+   {
+      hs[(size_t) i] = st + off;
+      if (sbytes[i]) { HIP_CHECK(hipMemcpyAsync(st + off, sbuf[i], sbytes[i], hipMemcpyDeviceToHost, s)); }
+      off += (sbytes[i] + 15) & ~(size_t) 15;
+   }
+   for (int i = 0; i < nr; i++) { hr[(size_t) i] = st + off; off += (rbytes[i] + 15) & ~(size_t) 15; }
+   HIP_CHECK(hipStreamSynchronize(s));
+   const int rc = c->inner.exchange(c->inner.ctx, ns, dest, hs.data(), sbytes, nr, src, hr.data(), rbytes, 0, nullptr);
+   for (int i = 0; i < nr; i++)
+   {
+      if (rbytes[i]) { HIP_CHECK(hipMemcpyAsync(rbuf[i], hr[(size_t) i], rbytes[i], hipMemcpyHostToDevice, s)); }
+   }
+   if (!c->done) { HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming)); }
+   HIP_CHECK(hipEventRecord(c->done, s));
+   return rc;
+}
+
+int staged_allreduce(void *vctx, double *buf, int count, int on_device, void *vstream)
+{
+   StagedCtx *c = (StagedCtx *) vctx;
+   if (!on_device) { return c->inner.allreduce_sum(c->inner.ctx, buf, count, 0, nullptr); }
+   hipStream_t s = (hipStream_t) vstream;
+   if (!s) { s = hamd::handle().comm_stream; }
+   const size_t bytes = sizeof(double) * (size_t) count;
+   char *st = c->stage(bytes + 16);
+   if (!st) { return 1; }
+   HIP_CHECK(hipMemcpyAsync(st, buf, bytes, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   const int rc = c->inner.allreduce_sum(c->inner.ctx, (double *) st, count, 0, nullptr);
+   HIP_CHECK(hipMemcpyAsync(buf, st, bytes, hipMemcpyHostToDevice, s));
+   if (!c->done) { HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming)); }
+   HIP_CHECK(hipEventRecord(c->done, s));
+   return rc;
+}
+
+int staged_allgather(void *vctx, const void *sbuf, void *rbuf, size_t bytes)
+{
+   StagedCtx *c = (StagedCtx *) vctx;
+   return c->inner.allgather(c->inner.ctx, sbuf, rbuf, bytes);
+}
+
+int staged_barrier(void *vctx)
+{
+   StagedCtx *c = (StagedCtx *) vctx;
+   return c->inner.barrier ? c->inner.barrier(c->inner.ctx) : 0;
+}
+
+void staged_destroy(void *vctx)
+{
+   StagedCtx *c = (StagedCtx *) vctx;
+   if (c->done) { (void) hipEventSynchronize(c->done); (void) hipEventDestroy(c->done); }
+   if (c->h_stage) { (void) hipHostFree(c->h_stage); }
+   delete c;      // the inner communicator stays the caller's
+}
+
 }  // namespace
 
 namespace hamd {
@@ -222,6 +325,32 @@ MPI_Comm hypre_amd_CommCreateRCCL(const void *id_bytes, int rank, int size)
    ops.allgather = rccl_allgather;
    ops.barrier = rccl_barrier;
    ops.destroy = rccl_destroy;
+   ops.device_buffers = 1;
+   return hypre_amd_CommCreate(&ops);
+}
+
+MPI_Comm hypre_amd_CommCreateStreamStaged(MPI_Comm inner)
+{
+   const hypre_amd_CommOps *io = hamd::comm_ops(inner);
+   if (!io || !io->exchange || !io->allreduce_sum || !io->allgather)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_ARG, "hypre_amd_CommCreateStreamStaged: the inner communicator lacks a host transport");
+      return hypre_MPI_COMM_NULL;
+   }
+   if (!hamd::ensure_device())
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_amd_CommCreateStreamStaged: no HIP device");
+      return hypre_MPI_COMM_NULL;
+   }
+   StagedCtx *c = new StagedCtx();
+   c->inner = *io;
+   hypre_amd_CommOps ops{};
+   ops.ctx = c; ops.rank = io->rank; ops.size = io->size;
+   ops.exchange = staged_exchange;
+   ops.allreduce_sum = staged_allreduce;
+   ops.allgather = staged_allgather;
+   ops.barrier = staged_barrier;
+   ops.destroy = staged_destroy;
    ops.device_buffers = 1;
    return hypre_amd_CommCreate(&ops);
 }

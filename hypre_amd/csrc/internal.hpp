@@ -115,6 +115,8 @@ struct SpmvPlan
 SpmvPlan *get_plan(hypre_CSRMatrix *A);
 hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A);   // device CSR of {a_ij : j < i}, cached in A's plan
 void      drop_plan(hypre_CSRMatrix *A);
+const float *fp32_values_of(hypre_CSRMatrix *A);         // fp32 copy of the values, cached in A's plan (mixed precision)
+void      set_strict_lower(hypre_CSRMatrix *A, hypre_CSRMatrix *L);   // A's plan takes ownership of L
 
 // epilogue selector of the tiled SpMV family
 enum SpmvOp
@@ -142,9 +144,12 @@ struct SpmvArgs
    int                  fill;     // HYPRE_SPMV_FILL_*
    int                  row_offset;
    int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
+   int                  x_last;      // num_cols - 1: largest valid index into x
    int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
    const int           *tile_perm;   // workgroup -> tile table (overrides xcd_map), or null
+   int                  variant;     // 0: one workgroup per tile; 1: persistent workgroups with the next tile's stream prefetched
+   int                  pipe_wgs;    // variant 1: workgroups per CU
 };
 void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 
@@ -181,6 +186,8 @@ void launch_pcg_update(double a, double na, const double *p, const double *s, do
                        double *d_out, hipStream_t stream);
 void launch_pcg_direction(double beta, const double *s, double *p, size_t n, hipStream_t stream);
 double global_sum(MPI_Comm comm, double v);     // scalar all-reduce over a communicator (identity on one rank)
+void   dev_allreduce_sum(MPI_Comm comm, double *d_buf, int n);                 // in place, device memory, stream-ordered
+void   dev_global_sums(MPI_Comm comm, double *d_vals, int n, double *h_out);   // n <= 8 device partials -> global sums on the host
 void launch_scale_copy(double b, const double *x, double *y, size_t n, hipStream_t s);   // y = b*x
 
 }  // namespace hamd

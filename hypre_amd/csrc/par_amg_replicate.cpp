@@ -15,8 +15,11 @@
 // gathers the coarse OPERATOR and builds a new sequential hierarchy under it.
 // Here the distributed hierarchy itself is gathered, so the arithmetic is that
 // of the distributed cycle (Jacobi-type smoothers do not depend on how rows are
-// spread over ranks); only the association of row sums changes (a row is summed
-// in one piece instead of diag block + ghost block).
+// spread over ranks; the two-stage Gauss-Seidel sweeps keep the triangle of every
+// rank's own diagonal block); only the association of row sums changes (a row is
+// summed in one piece instead of diag block + ghost block).  In mixed precision
+// every matrix value of the cycle — diagonal and ghost blocks alike — is the
+// fp32-rounded one, so the gathered rows carry the same values as the distributed ones.
 #include "amg_internal.hpp"
 #include <algorithm>
 #include <vector>
@@ -88,9 +91,41 @@ hypre_ParCSRMatrix *replicate_matrix(hypre_ParCSRMatrix *M)
    return R;
 }
 
-// smoothers whose result does not depend on how the rows are spread over ranks
-bool jacobi_like(int t) { return t == 0 || t == 7 || t == 18 || t == 16; }
+// smoothers whose result does not depend on how the rows are spread over ranks — or, for the two-stage
+// Gauss-Seidel sweeps 11 / 12 (par_relax.c:1506-1588: residual with the whole operator, inner steps with the strict
+// lower triangle of the rank's OWN diagonal block), depends on it only through that triangle, which the tail keeps
+// rank block by rank block (block_strict_lower below)
+bool jacobi_like(int t) { return t == 0 || t == 7 || t == 18 || t == 16 || t == 11 || t == 12; }
 bool ge_like(int t) { return t == 9 || t == 19 || t == 98 || t == 99 || t == 198 || t == 199; }
+
+// {a_ij : j < i, j owned by the rank that owns i} of a replicated host matrix, as a device CSR matrix
+hypre_CSRMatrix *block_strict_lower(hypre_CSRMatrix *R, const std::vector<int> &first_row /* [ranks + 1] */)
+{
+   const HYPRE_Int n = R->num_rows;
+   std::vector<HYPRE_Int> li((size_t) n + 1, 0), lj;
+   std::vector<HYPRE_Complex> la;
+   size_t b = 0;
+   for (HYPRE_Int i = 0; i < n; i++)
+   {
+      while (b + 1 < first_row.size() && i >= first_row[b + 1]) { b++; }
+      const HYPRE_Int lo = first_row[b];
+      for (HYPRE_Int k = R->i[i]; k < R->i[i + 1]; k++)
+      {
+         const HYPRE_Int c = R->j[k];
+         if (c >= lo && c < i) { lj.push_back(c); la.push_back(R->data[k]); }
+      }
+      li[(size_t) i + 1] = (HYPRE_Int) lj.size();
+   }
+   hypre_CSRMatrix *L = hypre_CSRMatrixCreate(n, R->num_cols, (HYPRE_Int) lj.size());
+   hypre_CSRMatrixInitialize_v2(L, 0, HYPRE_MEMORY_DEVICE);
+   hypre_TMemcpy(L->i, li.data(), HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   if (!lj.empty())
+   {
+      hypre_TMemcpy(L->j, lj.data(), HYPRE_Int, lj.size(), HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      hypre_TMemcpy(L->data, la.data(), HYPRE_Complex, la.size(), HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   }
+   return L;
+}
 
 hypre_ParVector *self_vec(HYPRE_BigInt n, HYPRE_MemoryLocation loc)
 {
@@ -117,7 +152,6 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
    if (d->cycle_type != 1 || d->fcycle || d->grid_relax_points) { return; }
    const HYPRE_Int *gt = d->grid_relax_type;
    if (!jacobi_like(gt[1]) || !jacobi_like(gt[2]) || !(ge_like(gt[3]) || jacobi_like(gt[3]))) { return; }
-   if (pv->mixed_precision) { return; }
    int Lr = -1;
    for (int l = 1; l < L; l++) { if (hostA[(size_t) l]->global_num_rows <= (HYPRE_BigInt) pv->replicate_rows) { Lr = l; break; } }
    if (Lr < 0) { return; }
@@ -128,7 +162,10 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
    AmgPrivate *tp = (AmgPrivate *) t->amd_private;
    tp->replicate_rows = 0;
    tp->emulated_threads = pv->emulated_threads;
+   tp->mixed_precision = pv->mixed_precision;
    const int TL = L - Lr;
+   const bool two_stage = gt[1] == 11 || gt[1] == 12 || gt[2] == 11 || gt[2] == 12 || gt[3] == 11 || gt[3] == 12;
+   std::vector<hypre_CSRMatrix *> tail_lower((size_t) TL, nullptr);
    t->memory_location = d->memory_location;
    t->max_levels = std::max(TL, 1);
    t->num_levels = TL;
@@ -154,6 +191,14 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
       t->omega[l] = d->omega[g];
       t->A_array[l] = replicate_matrix(hostA[(size_t) g]);
       if (g < L - 1) { t->P_array[l] = replicate_matrix(d->P_array[g]); }
+      if (two_stage && d->memory_location == HYPRE_MEMORY_DEVICE)
+      {
+         int mine = (int) hostA[(size_t) g]->row_starts[0];
+         std::vector<int> first((size_t) o->size + 1, 0);
+         o->allgather(o->ctx, &mine, first.data(), sizeof(int));
+         first[(size_t) o->size] = (int) hostA[(size_t) g]->global_num_rows;
+         tail_lower[(size_t) l] = block_strict_lower(t->A_array[l]->diag, first);
+      }
       const HYPRE_BigInt n = t->A_array[l]->global_num_rows;
       t->F_array[l] = self_vec(n, HYPRE_MEMORY_HOST);
       t->U_array[l] = self_vec(n, HYPRE_MEMORY_HOST);
@@ -221,6 +266,7 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
       for (int l = 0; l < TL; l++)
       {
          hypre_ParCSRMatrixMigrate(t->A_array[l], HYPRE_MEMORY_DEVICE);
+         if (tail_lower[(size_t) l]) { set_strict_lower(t->A_array[l]->diag, tail_lower[(size_t) l]); }
          if (t->P_array[l])
          {
             hypre_amd_ParCSRMatrixKeepTranspose(t->P_array[l]);

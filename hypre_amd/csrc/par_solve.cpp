@@ -34,6 +34,8 @@ void AmgPrivate::release_device()
    if (d_coarse_lu) { hypre_Free(d_coarse_lu, HYPRE_MEMORY_DEVICE); d_coarse_lu = nullptr; }
    if (d_coarse_rhs) { hypre_Free(d_coarse_rhs, HYPRE_MEMORY_DEVICE); d_coarse_rhs = nullptr; }
    coarse_n = 0;
+   if (mp_r) { hypre_ParVectorDestroy(mp_r); mp_r = nullptr; }
+   if (mp_e) { hypre_ParVectorDestroy(mp_e); mp_e = nullptr; }
 }
 
 // ---------------------------------------------------------------------------
@@ -104,7 +106,8 @@ void dev_jacobi_sweep(hypre_ParCSRMatrix *A, const double *f, const int *cf_mark
    if (nprocs > 1 && offd->num_cols > 0 && offd->num_nonzeros > 0)
    {
       SpmvArgs o{};
-      o.Ai = offd->i; o.Aj = offd->j; o.Aa = offd->data; o.Aa32 = nullptr;
+      o.Ai = offd->i; o.Aj = offd->j; o.Aa = offd->data;
+      o.Aa32 = handle().fp32_values ? fp32_values_of(offd) : nullptr;     // mixed precision covers the ghost block too
       o.x = A->comm_pkg->tmp_data; o.y = u_out; o.d = d;
       o.marker = (relax_points != 0) ? cf_marker : nullptr; o.marker_val = relax_points;
       o.alpha = -w;
@@ -369,17 +372,9 @@ HYPRE_Int hypre_GaussElimSolve(hypre_ParAMGData *d, HYPRE_Int level, HYPRE_Int r
       // gather the (<= max_coarse_size) right-hand side on every rank: zero-fill,
       // drop the own slice in, sum over ranks (one tiny all-reduce instead of an
       // Allgatherv through the host, par_gauss_elim.c:575)
-      const hypre_amd_CommOps *o = comm_ops(A->comm);
       HIP_CHECK(hipMemsetAsync(pv->d_coarse_rhs, 0, sizeof(double) * (size_t) n, s));
       if (nloc) { HIP_CHECK(hipMemcpyAsync(pv->d_coarse_rhs + pv->coarse_first_row, fd, sizeof(double) * (size_t) nloc, hipMemcpyDeviceToDevice, s)); }
-      if (o->device_buffers) { o->allreduce_sum(o->ctx, pv->d_coarse_rhs, n, 1, (void *) s); }
-      else
-      {
-         std::vector<double> h((size_t) n);
-         hypre_TMemcpy(h.data(), pv->d_coarse_rhs, double, n, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
-         o->allreduce_sum(o->ctx, h.data(), n, 0, nullptr);
-         hypre_TMemcpy(pv->d_coarse_rhs, h.data(), double, n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-      }
+      dev_allreduce_sum(A->comm, pv->d_coarse_rhs, n);
       launch_coarse_solve(pv->d_coarse_lu, pv->d_coarse_rhs, n, s);
       if (nloc) { HIP_CHECK(hipMemcpyAsync(ud, pv->d_coarse_rhs + pv->coarse_first_row, sizeof(double) * (size_t) nloc, hipMemcpyDeviceToDevice, s)); }
    }
@@ -409,19 +404,12 @@ int run_replicated_tail(hypre_ParAMGData *d, AmgPrivate *pv, const double *f_loc
    const int ng = (int) t->A_array[0]->global_num_rows;
    hipStream_t s = stream();
    double *g = pv->d_tail_f;
-   const hypre_amd_CommOps *o = comm_ops(Al->comm);
    HIP_CHECK(hipMemsetAsync(g, 0, sizeof(double) * (size_t) ng, s));
    if (nloc) { HIP_CHECK(hipMemcpyAsync(g + first, f_local, sizeof(double) * (size_t) nloc, hipMemcpyDeviceToDevice, s)); }
-   if (o->device_buffers) { o->allreduce_sum(o->ctx, g, ng, 1, (void *) s); }
-   else
-   {
-      std::vector<double> h((size_t) ng);
-      hypre_TMemcpy(h.data(), g, double, (size_t) ng, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
-      o->allreduce_sum(o->ctx, h.data(), ng, 0, nullptr);
-      hypre_TMemcpy(g, h.data(), double, (size_t) ng, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-   }
+   dev_allreduce_sum(Al->comm, g, ng);
    HIP_CHECK(hipMemcpyAsync(t->F_array[0]->local_vector->data, g, sizeof(double) * (size_t) ng, hipMemcpyDeviceToDevice, s));
    hypre_ParVectorSetZeros(t->U_array[0]);
+   ((AmgPrivate *) t->amd_private)->mixed_precision = pv->mixed_precision;     // may have been switched after setup
    t->cycle_op_count = 0;
    const int err = hypre_BoomerAMGCycle(t, t->F_array, t->U_array);
    if (nloc)
@@ -767,7 +755,34 @@ HYPRE_Int hypre_BoomerAMGSolve(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    while ((relative_resid >= tol || cycle_count < d->min_iter) && cycle_count < d->max_iter)
    {
       d->cycle_op_count = 0;
-      hypre_BoomerAMGCycle(d, d->F_array, d->U_array);
+      AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+      if (pv->mixed_precision && !u->all_zeros)
+      {
+         // Mixed precision from an iterate that is not known to be zero: the cycle's operators carry fp32-rounded
+         // values, so it is applied to the error equation — residual with the exact operator in fp64, cycle from a zero
+         // guess, correction added in fp64 ("fp32 SpMV / fp64 residual").  From a zero guess (every preconditioner
+         // call) the residual is f itself and the cycle runs on (f, u) directly.
+         const HYPRE_Int nloc = A->diag->num_rows;
+         if (pv->mp_r && pv->mp_r->local_vector->size != nloc)
+         {
+            hypre_ParVectorDestroy(pv->mp_r); hypre_ParVectorDestroy(pv->mp_e);
+            pv->mp_r = pv->mp_e = nullptr;
+         }
+         if (!pv->mp_r)
+         {
+            pv->mp_r = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts);
+            pv->mp_e = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts);
+            hypre_ParVectorInitialize_v2(pv->mp_r, HYPRE_MEMORY_DEVICE);
+            hypre_ParVectorInitialize_v2(pv->mp_e, HYPRE_MEMORY_DEVICE);
+         }
+         hypre_ParCSRMatrixMatvecOutOfPlace(-1.0, A, u, 1.0, f, pv->mp_r);
+         hypre_ParVectorSetZeros(pv->mp_e);
+         d->F_array[0] = pv->mp_r; d->U_array[0] = pv->mp_e;
+         hypre_BoomerAMGCycle(d, d->F_array, d->U_array);
+         d->F_array[0] = f; d->U_array[0] = u;
+         hypre_ParVectorAxpy(1.0, pv->mp_e, u);
+      }
+      else { hypre_BoomerAMGCycle(d, d->F_array, d->U_array); }
       if (d->print_level > 1 || d->logging > 1 || tol > 0.)
       {
          old_resid = resid_nrm;
@@ -938,16 +953,16 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
                         r->local_vector->data, (size_t) r->local_vector->size, d_rr, stream());
       x->all_zeros = 0; r->all_zeros = 0;
       precond(r, s);
-      gamma = hypre_ParVectorInnerProd(r, s);
-      if (d->flex) { delta = gamma - hypre_ParVectorInnerProd(d->r_old, s); }      // pcg.c:720-723
-      if (d->two_norm)
+      // gamma = <r, s> and, for the two-norm test, <r, r> (left on the device by the fused update): ONE all-reduce of
+      // two values and one read-back per iteration (pcg.c:716-760 reduces them separately)
+      launch_dot(r->local_vector->data, s->local_vector->data, (size_t) r->local_vector->size, d_rr + 1, stream());
       {
-         double *h = handle().h_reduce;
-         HIP_CHECK(hipMemcpyAsync(h + 1, d_rr, sizeof(double), hipMemcpyDeviceToHost, stream()));
-         HIP_CHECK(hipStreamSynchronize(stream()));
-         i_prod = global_sum(r->comm, h[1]);
+         double sums[2];
+         dev_global_sums(r->comm, d_rr, 2, sums);
+         gamma = sums[1];
+         i_prod = d->two_norm ? sums[0] : gamma;
       }
-      else { i_prod = gamma; }
+      if (d->flex) { delta = gamma - hypre_ParVectorInnerProd(d->r_old, s); }      // pcg.c:720-723
       if (i_prod / bi_prod < eps) { d->converged = 1; break; }
       if (gamma <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero gamma value in PCG"); break; }
       beta = (d->flex ? delta : gamma) / gamma_old;                 // pcg.c:957-965

@@ -31,25 +31,70 @@ double global_sum(MPI_Comm comm, double v)
 
 namespace {
 
-// events used to order the two streams; created once
-struct HaloEvents
+// Event pairs that order the compute and the communication stream around one exchange.  Every exchange in
+// flight owns a pair (handed out round-robin from a pool deep enough for the few a cycle can have open at once,
+// and remembered in its hypre_ParCSRCommHandle): `pack` is recorded on the compute stream when the send buffer is
+// ready, `halo` on the communication stream when the transfers have been enqueued.
+struct EventPair { hipEvent_t pack = nullptr, halo = nullptr; };
+constexpr int EVENT_POOL = 16;
+EventPair *next_event_pair()
 {
-   hipEvent_t pack = nullptr, halo = nullptr;
-   bool ok = false;
-};
-HaloEvents &halo_events()
-{
-   static HaloEvents e;
-   if (!e.ok && ensure_device())
+   static EventPair pool[EVENT_POOL];
+   static int next = 0;
+   EventPair *e = &pool[next];
+   next = (next + 1) % EVENT_POOL;
+   if (!e->pack)
    {
-      HIP_CHECK(hipEventCreateWithFlags(&e.pack, hipEventDisableTiming));
-      HIP_CHECK(hipEventCreateWithFlags(&e.halo, hipEventDisableTiming));
-      e.ok = true;
+      HIP_CHECK(hipEventCreateWithFlags(&e->pack, hipEventDisableTiming));
+      HIP_CHECK(hipEventCreateWithFlags(&e->halo, hipEventDisableTiming));
    }
    return e;
 }
 
 }  // namespace
+
+namespace hamd {
+// In-place sum over the ranks of `comm` of n doubles in DEVICE memory, ordered behind the work already queued on the
+// compute stream and ahead of what is queued after the call; no host synchronisation when the transport takes
+// device buffers.  All traffic of a communicator goes through the communication stream (one stream per RCCL
+// communicator: halo exchanges and reductions never race on it).
+void dev_allreduce_sum(MPI_Comm comm, double *d_buf, int n)
+{
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   if (!o || o->size <= 1 || n <= 0) { return; }
+   Handle &hd = handle();
+   if (o->device_buffers)
+   {
+      EventPair *ev = next_event_pair();
+      HIP_CHECK(hipEventRecord(ev->pack, hd.compute_stream));
+      HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, ev->pack, 0));
+      o->allreduce_sum(o->ctx, d_buf, n, 1, (void *) hd.comm_stream);
+      HIP_CHECK(hipEventRecord(ev->halo, hd.comm_stream));
+      HIP_CHECK(hipStreamWaitEvent(hd.compute_stream, ev->halo, 0));
+   }
+   else
+   {
+      std::vector<double> h((size_t) n);
+      hypre_TMemcpy(h.data(), d_buf, double, (size_t) n, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      o->allreduce_sum(o->ctx, h.data(), n, 0, nullptr);
+      hypre_TMemcpy(d_buf, h.data(), double, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   }
+}
+
+// Sum over the ranks of n (<= 8) doubles that sit in device memory, returned on the host: one device all-reduce and
+// one read-back when the transport takes device buffers (otherwise read back, then reduce on the host).
+void dev_global_sums(MPI_Comm comm, double *d_vals, int n, double *h_out)
+{
+   const hypre_amd_CommOps *o = comm_ops(comm);
+   Handle &hd = handle();
+   double *h = hd.h_reduce;
+   if (o && o->size > 1 && o->device_buffers) { dev_allreduce_sum(comm, d_vals, n); }
+   HIP_CHECK(hipMemcpyAsync(h, d_vals, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, hd.compute_stream));
+   HIP_CHECK(hipStreamSynchronize(hd.compute_stream));
+   for (int k = 0; k < n; k++) { h_out[k] = h[k]; }
+   if (o && o->size > 1 && !o->device_buffers && o->allreduce_sum) { o->allreduce_sum(o->ctx, h_out, n, 0, nullptr); }
+}
+}  // namespace hamd
 
 extern "C" {
 
@@ -279,9 +324,19 @@ HYPRE_Int hypre_ParVectorAxpyz(HYPRE_Complex alpha, hypre_ParVector *x, HYPRE_Co
 }
 HYPRE_Real hypre_ParVectorInnerProd(hypre_ParVector *x, hypre_ParVector *y)
 {
-   // local dot + one scalar all-reduce (par_vector.c:513-533)
-   double local = hypre_SeqVectorInnerProd(x->local_vector, y->local_vector);
-   return global_sum(x->comm, local);
+   // local dot + one scalar all-reduce (par_vector.c:513-533); with a device-buffer transport the partial sum is
+   // reduced where it is and read back once
+   hypre_Vector *xl = x->local_vector, *yl = y->local_vector;
+   if (xl->memory_location != HYPRE_MEMORY_DEVICE || yl->memory_location != HYPRE_MEMORY_DEVICE)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParVectorInnerProd: operand is not in device memory; host execution is not part of this library");
+      return 0.0;
+   }
+   double *d_out = reduce_scratch(2048);
+   launch_dot(xl->data, yl->data, (size_t) xl->size * (size_t) xl->num_vectors, d_out, stream());
+   double r = 0.0;
+   dev_global_sums(x->comm, d_out, 1, &r);
+   return r;
 }
 HYPRE_Int hypre_ParVectorElmdivpy(hypre_ParVector *x, hypre_ParVector *b, hypre_ParVector *y)
 {
@@ -484,14 +539,15 @@ hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate_v2(HYPRE_Int job, hypre_Par
    }
    if (dev && !stage)
    {
-      HaloEvents &ev = halo_events();
+      EventPair *ev = next_event_pair();
       Handle &hd = handle();
-      HIP_CHECK(hipEventRecord(ev.pack, hd.compute_stream));
-      HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, ev.pack, 0));
+      HIP_CHECK(hipEventRecord(ev->pack, hd.compute_stream));
+      HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, ev->pack, 0));
       o->exchange(o->ctx, ns, sprocs, sb.data(), sbytes.data(), nr, rprocs, rb.data(), rbytes.data(), 1,
                   (void *) hd.comm_stream);
-      HIP_CHECK(hipEventRecord(ev.halo, hd.comm_stream));
+      HIP_CHECK(hipEventRecord(ev->halo, hd.comm_stream));
       h->num_requests = 1;   // marks "device exchange in flight"
+      h->requests = ev;      // ... and the event pair that belongs to it
    }
    else
    {
@@ -513,10 +569,9 @@ hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate(HYPRE_Int job, hypre_ParCSR
 HYPRE_Int hypre_ParCSRCommHandleDestroy(hypre_ParCSRCommHandle *h)
 {
    if (!h) { return hypre_error_flag; }
-   if (h->num_requests)
+   if (h->num_requests && h->requests)
    {
-      HaloEvents &ev = halo_events();
-      HIP_CHECK(hipStreamWaitEvent(handle().compute_stream, ev.halo, 0));
+      HIP_CHECK(hipStreamWaitEvent(handle().compute_stream, ((EventPair *) h->requests)->halo, 0));
    }
    free(h);
    return hypre_error_flag;

@@ -20,6 +20,20 @@ using namespace hamd;
 // ===========================================================================
 namespace hamd {
 
+// kernel variant of the tiled family (hypre_amd_SpmvSetVariant, or HYPRE_AMD_SPMV_VARIANT / HYPRE_AMD_SPMV_PIPE_WGS read once)
+struct SpmvVariant { int variant, pipe_wgs; };
+static SpmvVariant &spmv_variant()
+{
+   static SpmvVariant v = {-1, 4};
+   if (v.variant < 0)
+   {
+      const char *e = getenv("HYPRE_AMD_SPMV_VARIANT");
+      v.variant = e ? atoi(e) : 0;
+      if ((e = getenv("HYPRE_AMD_SPMV_PIPE_WGS"))) { v.pipe_wgs = atoi(e); }
+   }
+   return v;
+}
+
 // Tuning knobs (A/B-testable without rebuilding): HYPRE_AMD_SPMV_GT, HYPRE_AMD_SPMV_XCD.
 void spmv_default_flags(SpmvArgs &a)
 {
@@ -38,6 +52,7 @@ void spmv_default_flags(SpmvArgs &a)
       xcd = e ? atoi(e) : 8;
    }
    a.gather_t = gt; a.xcd_map = xcd;
+   a.variant = spmv_variant().variant; a.pipe_wgs = spmv_variant().pipe_wgs;
 }
 
 // Band-aware XCD placement.  Workgroup g runs on XCD g % 8 and every XCD has its own L2.  A matrix from a
@@ -48,11 +63,27 @@ void spmv_default_flags(SpmvArgs &a)
 // XCD c is handed the tiles of slab c, plane after plane: the x values it fetched as the upper neighbours of plane p
 // are still in its L2 when plane p + 1 and p + 2 read them again.  Irregular matrices (coarse levels, interpolation)
 // do not pass the agreement test and keep the run-of-8 placement.  HYPRE_AMD_SPMV_BAND=0 switches it off.
+// Policy (hypre_amd_SpmvSetBandPolicy, or HYPRE_AMD_SPMV_BAND / HYPRE_AMD_SPMV_BAND_MIN_TILES / HYPRE_AMD_SPMV_BAND_FORCE
+// read once): `min_tiles` is the size below which the table is not worth building; `force` also drops the lower bound
+// on the slab size, so that small test matrices go through the same code as the benchmark's.
+struct BandPolicy { int enabled, min_tiles, force; };
+static BandPolicy &band_policy()
+{
+   static BandPolicy bp = {-1, 2048, 0};
+   if (bp.enabled < 0)
+   {
+      const char *e = getenv("HYPRE_AMD_SPMV_BAND");
+      bp.enabled = e ? atoi(e) : 1;
+      if ((e = getenv("HYPRE_AMD_SPMV_BAND_MIN_TILES"))) { bp.min_tiles = atoi(e); }
+      if ((e = getenv("HYPRE_AMD_SPMV_BAND_FORCE"))) { bp.force = atoi(e); }
+   }
+   return bp;
+}
+
 static void build_band_placement(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
 {
-   static int enabled = -1;
-   if (enabled < 0) { const char *e = getenv("HYPRE_AMD_SPMV_BAND"); enabled = e ? atoi(e) : 1; }
-   if (!enabled || p->num_tiles < 2048 || A->num_rows != A->num_cols) { return; }
+   const BandPolicy &bp = band_policy();
+   if (!bp.enabled || p->num_tiles < bp.min_tiles || p->num_tiles < 8 || A->num_rows != A->num_cols) { return; }
    const int ns = 1024;
    std::vector<int> far((size_t) ns);
    sample_row_bands(A->i, A->j, A->num_rows, ns, far.data(), s);
@@ -63,7 +94,8 @@ static void build_band_placement(SpmvPlan *p, const hypre_CSRMatrix *A, hipStrea
    for (int f : far) { if (std::abs(f - B) * 50 <= B) { agree++; } }
    const long long rows_per_tile = std::max(1LL, (long long) A->num_rows / p->num_tiles);
    // one distance for most rows, at least four planes, slabs of at least 8 tiles
-   if (B <= 0 || agree * 10 < ns * 6 || 4LL * B > A->num_rows || (long long) B < 8 * 8 * rows_per_tile) { return; }
+   if (B <= 0 || agree * 10 < ns * 6 || 4LL * B > A->num_rows) { return; }
+   if (!bp.force && (long long) B < 8 * 8 * rows_per_tile) { return; }
    std::vector<int> trow((size_t) p->num_tiles + 1);
    HIP_CHECK(hipMemcpyAsync(trow.data(), p->d_tile_row, sizeof(int) * ((size_t) p->num_tiles + 1), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
@@ -162,6 +194,28 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
    return p;
 }
 
+// fp32 copy of a device matrix's values (mixed precision), converted once and cached in the plan
+const float *fp32_values_of(hypre_CSRMatrix *A)
+{
+   if (!A || A->num_nonzeros <= 0 || !A->data) { return nullptr; }
+   SpmvPlan *p = get_plan(A);
+   if (!p->a32)
+   {
+      HIP_CHECK(hipMalloc((void **) &p->a32, sizeof(float) * (((size_t) A->num_nonzeros + 3) & ~(size_t) 3)));
+      launch_f64_to_f32(A->data, p->a32, (size_t) A->num_nonzeros, stream());
+   }
+   return p->a32;
+}
+
+// Hand a matrix its strictly-lower copy ready made (replicated tail: the triangle of every rank's own diagonal
+// block, which is what the distributed two-stage sweep multiplies by, not the triangle of the gathered matrix).
+void set_strict_lower(hypre_CSRMatrix *A, hypre_CSRMatrix *L)
+{
+   SpmvPlan *plan = get_plan(A);
+   if (plan->Lstrict && plan->Lstrict != L) { hypre_CSRMatrixDestroy(plan->Lstrict); }
+   plan->Lstrict = L;
+}
+
 // Strictly lower triangular part of a device matrix as its own CSR matrix (entries in stored
 // order), cached in the plan: counted and filled by one lane per row, row offsets scanned on the host.
 hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A)
@@ -186,6 +240,39 @@ hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A)
 }
 
 }  // namespace hamd
+
+// Band-aware tile placement policy of the plans built from now on (existing plans keep theirs): enabled 0/1,
+// min_tiles = smallest matrix (in 2048-entry tiles) that gets a table, force != 0 drops the minimum slab size.
+// Negative arguments leave a field as it is.  Speed only — except that tests use it to put small matrices through
+// the placement-table code the benchmark sizes run.
+extern "C" HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int min_tiles, HYPRE_Int force)
+{
+   hamd::BandPolicy &bp = hamd::band_policy();
+   if (enabled >= 0) { bp.enabled = enabled; }
+   if (min_tiles >= 0) { bp.min_tiles = min_tiles; }
+   if (force >= 0) { bp.force = force; }
+   return hypre_error_flag;
+}
+
+// Kernel variant of the tiled SpMV family from now on: 0 = one workgroup per tile, 1 = persistent software-pipelined
+// workgroups, `pipe_wgs` of them per CU (0: leave; < 0: a grid of 8 * |pipe_wgs| workgroups whatever the device).  Speed only; same results up to nothing (same summation order).
+extern "C" HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int pipe_wgs)
+{
+   hamd::SpmvVariant &v = hamd::spmv_variant();
+   if (variant >= 0) { v.variant = variant; }
+   if (pipe_wgs != 0) { v.pipe_wgs = pipe_wgs; }
+   return hypre_error_flag;
+}
+
+// 1 when the plan of A (built on demand) carries a placement table, with the band distance it was built for
+extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanInfo(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Int *band)
+{
+   if (A->memory_location != HYPRE_MEMORY_DEVICE) { if (num_tiles) { *num_tiles = 0; } if (band) { *band = 0; } return 0; }
+   hamd::SpmvPlan *p = hamd::get_plan(A);
+   if (num_tiles) { *num_tiles = p->tiled ? p->num_tiles : 0; }
+   if (band) { *band = p->band; }
+   return p->d_tile_perm != nullptr;
+}
 
 extern "C" HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A)
 {
@@ -556,6 +643,7 @@ static void spmv_device_core(HYPRE_Complex alpha, hypre_CSRMatrix *A, const HYPR
    // sparse-row path: only a few rows hold entries (off-diagonal blocks)
    if (fill == HYPRE_SPMV_FILL_WHOLE && A->rownnz && (double) A->num_rownnz < 0.7 * (double) nr)
    {
+      if (handle().fp32_values) { a.Aa32 = fp32_values_of(A); }
       if (beta == 0.0) { launch_set(y, 0.0, (size_t) nr, s); }
       else if (b == y) { if (beta != 1.0) { launch_scale(y, beta, (size_t) nr, s); } }
       else { launch_scale_copy(beta, b, y, (size_t) nr, s); }

@@ -418,8 +418,15 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    // each XCD with its own L2.  xcd_map > 0: every XCD takes chunks of xcd_map
    // consecutive tiles; xcd_map < 0: one contiguous eighth of the tiles per XCD.
    // Speed only: any placement is correct.
+   // The grid may be padded past num_tiles (launch_tiled_gt): a padding workgroup must leave before it touches the
+   // placement table, which holds num_tiles entries.  Every tile is visited exactly once — the in-place epilogues
+   // (OP_TSGS adds into aux, OP_AXPBY with b == y) rely on it — so a table entry outside [0, num_tiles) is dropped too.
    int tile = (int) blockIdx.x;
-   if (p.tile_perm) { tile = p.tile_perm[blockIdx.x]; }
+   if (p.tile_perm)
+   {
+      if (tile >= num_tiles) { return; }
+      tile = p.tile_perm[tile];
+   }
    else if (p.xcd_map > 0)
    {
       const int g = blockIdx.x >> 3, c = blockIdx.x & 7, C = p.xcd_map;
@@ -429,7 +436,7 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    {
       tile = (blockIdx.x & 7) * ((num_tiles + 7) >> 3) + (blockIdx.x >> 3);
    }
-   if (tile >= num_tiles) { return; }
+   if ((unsigned) tile >= (unsigned) num_tiles) { return; }
 
    // The tile's entries [k0, k1) start inside [tile*TILE, tile*TILE + longest row): the first
    // TILE entries from tile*TILE on are requested before the tile's bounds are known, so the
@@ -461,6 +468,203 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
    if (GT) { stream_consume_gt<F32>(p, k0, k1, ka, S, prod); } else { stream_consume<F32>(p, k0, k1, ka, S, prod); }
    __syncthreads();
    tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
+}
+
+// ---------------------------------------------------------------------------
+// Persistent, software-pipelined form of the tiled kernel.
+//
+// One workgroup per tile leaves the matrix stream idle for most of a tile's life: a tile is a chain of dependent
+// round trips (stream -> column gathers -> reduction -> store) and only the first of them moves matrix bytes.  Here a
+// workgroup walks over tiles vb, vb + gridDim, ... and requests the (col, val) quads of the NEXT tile right after it
+// has issued the gathers of the current one, so the stream of tile i + 1 is in flight while tile i gathers, reduces and
+// stores.  Order matters: a wave's vector-memory results return in issue order and are waited for by count
+// (s_waitcnt vmcnt(N)), so the prefetch has to be issued AFTER the loads the current tile still waits for (gathers,
+// row pointers, epilogue operands); issued before them it would be waited for with them and nothing would overlap.
+// The next tile's bounds are wave-uniform scalar loads (own counter).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int map_tile(const SpmvArgs &p, int vb, int num_tiles)
+{
+   int tile = vb;
+   if (p.tile_perm) { tile = vb < num_tiles ? p.tile_perm[vb] : -1; }
+   else if (p.xcd_map > 0)
+   {
+      const int g = vb >> 3, c = vb & 7, C = p.xcd_map;
+      tile = (g / C) * (8 * C) + c * C + (g % C);
+   }
+   else if (p.xcd_map < 0) { tile = (vb & 7) * ((num_tiles + 7) >> 3) + (vb >> 3); }
+   return ((unsigned) tile < (unsigned) num_tiles) ? tile : -1;
+}
+
+// Reduction + epilogue of the pipelined kernel's one-lane-per-row path with the epilogue operands of the first three
+// passes (rows tid, tid + 256, tid + 512 of the tile) fetched by the caller BEFORE the next tile's stream was requested:
+// a load issued here would be waited for together with that prefetch.
+template <int OP, bool HASFILL>
+__device__ __forceinline__ void tile_reduce_pipe(const SpmvArgs &p, int r0, int nrows, int k0, int k1, int ka,
+                                                 const double *prod, double *rowsum, const int *rp, int rp_cap,
+                                                 const RowOps &ops0, const RowOps &ops1, const RowOps &ops2)
+{
+   const int tid = threadIdx.x;
+   const int avg = (k1 - k0) / nrows;
+   if (avg > 12) { tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops0); return; }
+   for (int rr = tid, pass = 0; rr < nrows; rr += SPMV_THREADS, pass++)
+   {
+      const int row = r0 + rr;
+      const int s = (rr     <= rp_cap) ? rp[rr]     : p.Ai[row];
+      const int e = (rr + 1 <= rp_cap) ? rp[rr + 1] : p.Ai[row + 1];
+      double sum = 0.0;
+      for (int k = s; k < e; k++)
+      {
+         double t = prod[k - ka];
+         if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
+         sum += t;
+      }
+      if (pass == 0)      { row_epilogue<OP>(p, row, sum, ops0); }
+      else if (pass == 1) { row_epilogue<OP>(p, row, sum, ops1); }
+      else if (pass == 2) { row_epilogue<OP>(p, row, sum, ops2); }
+      else { const RowOps o = load_row_ops<OP>(p, row); row_epilogue<OP>(p, row, sum, o); }
+   }
+}
+
+// epilogue operands of row r0 + tid + pass * SPMV_THREADS, clamped into the tile so the loads are unconditional
+template <int OP>
+__device__ __forceinline__ RowOps tile_row_ops_pass(const SpmvArgs &p, int r0, int nrows, int pass)
+{
+   const int rr = min((int) threadIdx.x + pass * SPMV_THREADS, nrows - 1);
+   return load_row_ops<OP>(p, max(r0 + rr, 0));
+}
+
+template <int OP, bool F32, bool HASFILL>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_pipe_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
+                      int num_tiles, int padded_tiles, int prod_elems, int rowsum_elems, int rp_cap)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *prod   = reinterpret_cast<double *>(smem_raw);
+   double *rowsum = prod + prod_elems;
+   int    *rp     = reinterpret_cast<int *>(rowsum + rowsum_elems);
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int G = (int) gridDim.x;
+   const unsigned x_last = (unsigned) p.x_last;
+   constexpr int RPJ = (RP_CAP + SPMV_THREADS) / SPMV_THREADS;
+
+   // first tile of this workgroup (padding slots of the placement map hold none)
+   int vb = (int) blockIdx.x, tile = -1;
+   for (; vb < padded_tiles; vb += G) { tile = map_tile(p, vb, num_tiles); if (tile >= 0) { break; } }
+   if (tile < 0) { return; }
+   TileStream S;
+   int r0 = tile_row[tile], r1 = tile_row[tile + 1], k0 = tile_k[tile], k1 = tile_k[tile + 1];
+   stream_issue<F32>(p, tile * SPMV_TILE, 0x7fffffff, S);
+   stream_issue_spill<F32>(p, tile * SPMV_TILE, k1, S);
+
+   while (true)
+   {
+      const int ka = tile * SPMV_TILE;
+      const int nrows = r1 - r0;
+      // The tile after this one and its bounds (wave-uniform scalar loads, needed only when its spill is requested below).
+      // None: the prefetch re-reads this tile, which costs nothing worth a branch — every vector load between the gathers
+      // and the product stores is unconditional, so that the compiler can count (s_waitcnt vmcnt(N)) exactly the loads
+      // this tile waits for and leave the prefetch in flight.
+      int ntile = -1;
+      for (vb += G; vb < padded_tiles; vb += G) { ntile = map_tile(p, vb, num_tiles); if (ntile >= 0) { break; } }
+      const int ptile = ntile >= 0 ? ntile : tile;
+      const int nr0 = tile_row[ptile], nr1 = tile_row[ptile + 1], nk0 = tile_k[ptile], nk1 = tile_k[ptile + 1];
+
+      TileStream N;
+      if (nrows > 0)
+      {
+         // row pointers (to LDS further down: nothing needs them before the reduction) and the epilogue operands
+         const int lim = min(nrows, rp_cap);
+         int rpv[RPJ];
+#pragma unroll
+         for (int j = 0; j < RPJ; j++) { rpv[j] = p.Ai[r0 + min(tid + j * SPMV_THREADS, lim)]; }
+         const RowOps ops0 = tile_row_ops_pass<OP>(p, r0, nrows, 0);
+         const RowOps ops1 = tile_row_ops_pass<OP>(p, r0, nrows, 1);
+         const RowOps ops2 = tile_row_ops_pass<OP>(p, r0, nrows, 2);
+
+         // columns through the wave's own LDS slice -> 2 x 4 gathers of 64 consecutive entries each.  Slots outside
+         // [k0, k1) hold entries of neighbouring tiles or, in the matrix's last quad, no entry at all: their columns
+         // are clamped into x (one v_min each, no branch) and their products are never read.
+         double *chunk0 = prod + 256 * wave, *chunk1 = prod + 4 * SPMV_THREADS + 256 * wave;
+         int *ci0 = reinterpret_cast<int *>(chunk0), *ci1 = reinterpret_cast<int *>(chunk1);
+         *reinterpret_cast<v4i *>(ci0 + 4 * lane) = S.cA;
+         *reinterpret_cast<v4i *>(ci1 + 4 * lane) = S.cB;
+         __builtin_amdgcn_wave_barrier();
+         const unsigned a0 = min((unsigned) ci0[lane],       x_last), a1 = min((unsigned) ci0[64 + lane],  x_last);
+         const unsigned a2 = min((unsigned) ci0[128 + lane], x_last), a3 = min((unsigned) ci0[192 + lane], x_last);
+         const unsigned b0 = min((unsigned) ci1[lane],       x_last), b1 = min((unsigned) ci1[64 + lane],  x_last);
+         const unsigned b2 = min((unsigned) ci1[128 + lane], x_last), b3 = min((unsigned) ci1[192 + lane], x_last);
+         const int kC = ka + 8 * SPMV_THREADS + tid;
+         const double xa0 = p.x[a0], xa1 = p.x[a1], xa2 = p.x[a2], xa3 = p.x[a3];
+         const double xb0 = p.x[b0], xb1 = p.x[b1], xb2 = p.x[b2], xb3 = p.x[b3];
+         const double xC = p.x[min((unsigned) S.cC, x_last)];
+
+         // everything this tile still waits for has been requested: now the next tile's stream (the scheduler must not
+         // move a load of this tile behind it: results return in issue order)
+         __builtin_amdgcn_sched_barrier(0);
+         stream_issue<F32>(p, ptile * SPMV_TILE, 0x7fffffff, N);
+         stream_issue_spill<F32>(p, ptile * SPMV_TILE, nk1, N);
+         __builtin_amdgcn_sched_barrier(0);
+
+         {
+            const int lim2 = lim;
+#pragma unroll
+            for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim2)] = rpv[j]; }
+         }
+         __builtin_amdgcn_wave_barrier();
+         chunk0[lane] = xa0; chunk0[64 + lane] = xa1; chunk0[128 + lane] = xa2; chunk0[192 + lane] = xa3;
+         chunk1[lane] = xb0; chunk1[64 + lane] = xb1; chunk1[128 + lane] = xb2; chunk1[192 + lane] = xb3;
+         __builtin_amdgcn_wave_barrier();
+         {
+            const v2d xa = *reinterpret_cast<const v2d *>(chunk0 + 4 * lane);
+            const v2d xb = *reinterpret_cast<const v2d *>(chunk0 + 4 * lane + 2);
+            const v2d ya = *reinterpret_cast<const v2d *>(chunk1 + 4 * lane);
+            const v2d yb = *reinterpret_cast<const v2d *>(chunk1 + 4 * lane + 2);
+            v2d lo0, hi0, lo1, hi1;
+            if (F32)
+            {
+               lo0.x = (double) S.fA.x * xa.x; lo0.y = (double) S.fA.y * xa.y; hi0.x = (double) S.fA.z * xb.x; hi0.y = (double) S.fA.w * xb.y;
+               lo1.x = (double) S.fB.x * ya.x; lo1.y = (double) S.fB.y * ya.y; hi1.x = (double) S.fB.z * yb.x; hi1.y = (double) S.fB.w * yb.y;
+            }
+            else
+            {
+               lo0 = S.vA01 * xa; hi0 = S.vA23 * xb; lo1 = S.vB01 * ya; hi1 = S.vB23 * yb;
+            }
+            *reinterpret_cast<v2d *>(chunk0 + 4 * lane)     = lo0;
+            *reinterpret_cast<v2d *>(chunk0 + 4 * lane + 2) = hi0;
+            *reinterpret_cast<v2d *>(chunk1 + 4 * lane)     = lo1;
+            *reinterpret_cast<v2d *>(chunk1 + 4 * lane + 2) = hi1;
+         }
+         if (kC < k1) { prod[kC - ka] = S.vC * xC; }
+         // tail of a tile whose last row runs past the spill entries as well (rare; waits for the prefetch too)
+         for (int k = ka + 9 * SPMV_THREADS + 4 * tid; k < k1; k += 4 * SPMV_THREADS)
+         {
+            const v4i c = stream_load<v4i>(p.Aj + k);
+            double v0, v1, v2, v3;
+            if (F32) { const v4f f = stream_load<v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
+            else
+            {
+               const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
+               v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+            }
+            double *dst = prod + (k - ka);
+            if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
+            if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
+            if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
+            if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
+         }
+         __syncthreads();
+         tile_reduce_pipe<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops0, ops1, ops2);
+      }
+      else
+      {
+         stream_issue<F32>(p, ptile * SPMV_TILE, 0x7fffffff, N);
+         stream_issue_spill<F32>(p, ptile * SPMV_TILE, nk1, N);
+      }
+      if (ntile < 0) { break; }
+      __syncthreads();          // the next tile overwrites rp[], prod[] and rowsum[]
+      S = N;
+      tile = ntile; r0 = nr0; r1 = nr1; k0 = nk0; k1 = nk1;
+   }
 }
 
 // ---------------------------------------------------------------------------
@@ -620,15 +824,35 @@ static void launch_tiled_gt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t
 {
    int rowsum_elems, rp_cap;
    const size_t lds = tiled_lds_bytes(plan, rowsum_elems, rp_cap);
-   const int unit = a.xcd_map > 0 ? 8 * a.xcd_map : 8;
+   // the chunked tile -> XCD map covers whole groups of 8 * xcd_map workgroups; a placement table is one workgroup per tile
+   const int unit = a.tile_perm ? 1 : (a.xcd_map > 0 ? 8 * a.xcd_map : 8);
    const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
    hipLaunchKernelGGL((spmv_tiled_kernel<OP, F32, FILL, GT>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
                       plan->d_tile_row, plan->d_tile_k, plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap);
 }
 
 template <int OP, bool F32, bool FILL>
+static void launch_pipe(const SpmvPlan *plan, const SpmvArgs &a, int grid, hipStream_t s)
+{
+   int rowsum_elems, rp_cap;
+   const size_t lds = tiled_lds_bytes(plan, rowsum_elems, rp_cap);
+   const int unit = a.tile_perm ? 1 : (a.xcd_map > 0 ? 8 * a.xcd_map : 8);
+   const int padded = ((plan->num_tiles + unit - 1) / unit) * unit;
+   hipLaunchKernelGGL((spmv_pipe_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
+                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, padded, plan->prod_elems, rowsum_elems, rp_cap);
+}
+
+template <int OP, bool F32, bool FILL>
 static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
+   // persistent pipelined kernel: only when every workgroup gets at least two tiles (otherwise there is nothing to
+   // prefetch); the grid is a multiple of 8 so that a workgroup's tiles all belong to its own XCD's share
+   if (a.variant == 1 && a.gather_t)
+   {
+      // pipe_wgs > 0: workgroups per CU; < 0: the grid itself, in units of 8 workgroups (tests: small matrices)
+      const int grid = a.pipe_wgs < 0 ? -8 * a.pipe_wgs : (hamd::handle().num_cus * (a.pipe_wgs > 0 ? a.pipe_wgs : 4)) & ~7;
+      if (grid >= 8 && plan->num_tiles >= 2 * grid) { launch_pipe<OP, F32, FILL>(plan, a, grid, s); return; }
+   }
    if (a.gather_t) { launch_tiled_gt<OP, F32, FILL, true>(plan, a, s); }
    else { launch_tiled_gt<OP, F32, FILL, false>(plan, a, s); }
 }
@@ -667,6 +891,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    if (plan->num_rows <= 0) { return; }
    SpmvArgs a = args;
    a.last_quad = (plan->nnz > 0 ? (int) (plan->nnz - 1) : 0) & ~3;
+   a.x_last = plan->num_cols > 0 ? plan->num_cols - 1 : 0;
    a.tile_perm = plan->d_tile_perm;
    if (handle().fp32_values && !a.Aa32 && plan->nnz > 0)
    {

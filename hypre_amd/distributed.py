@@ -34,6 +34,21 @@ def create_rccl_comm(dist, rank, world):
     return comm
 
 
+def create_stream_staged_comm(dist, rank, world):
+    """Device-buffer communicator over torch.distributed host traffic (hypre_amd_CommCreateStreamStaged on top of
+    create_callback_comm): the library runs its production halo flow — pack kernel, event, exchange enqueued on the
+    communication stream, event, ghost product; all-reduces on device buffers — while the bytes travel through host
+    memory.  Ranks may share one GPU, which RCCL does not allow: this is how the multi-rank device path is tested on
+    a one-GPU box, and the rehearsal transport of bench.py."""
+    L = B.load_library()
+    inner = create_callback_comm(dist, rank, world)
+    comm = L.hypre_amd_CommCreateStreamStaged(inner)
+    B.check()
+    if comm < 0:
+        raise B.HypreAmdError("hypre_amd_CommCreateStreamStaged failed")
+    return comm
+
+
 def _view(ptr, nbytes):
     return np.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=np.uint8)
 

@@ -65,6 +65,15 @@ HYPRE_Int hypre_amd_CommDestroy(MPI_Comm comm);
 HYPRE_Int hypre_amd_RCCLGetUniqueId(void *id_out);
 MPI_Comm  hypre_amd_CommCreateRCCL(const void *id, int rank, int size);
 
+/* Device-buffer semantics on top of a host-buffer communicator `inner` (one made by
+ * hypre_amd_CommCreate from MPI or torch.distributed callbacks; it must outlive the new one):
+ * halo buffers are copied device -> pinned host on the stream the exchange is given, the host
+ * transport runs once that stream has drained, and the received data is copied back
+ * asynchronously on the same stream.  The library then drives it exactly like the RCCL provider
+ * (pack kernel -> event -> exchange on the communication stream -> event -> ghost product), which is
+ * what an application without a device-aware MPI wants, and what lets several ranks share one GPU. */
+MPI_Comm  hypre_amd_CommCreateStreamStaged(MPI_Comm inner);
+
 /* Collective health check of a communicator (no reference counterpart; the
  * reference trusts MPI): ring shift of nbytes through exchange() with host and,
  * if the provider takes them, device buffers, a sum all-reduce and an

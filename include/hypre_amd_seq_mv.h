@@ -132,6 +132,18 @@ HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_
  * Call after changing i/j/data in place or before freeing arrays that the
  * library does not own. */
 HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A);
+/* Tile -> XCD placement policy of the plans built from now on (speed only; no reference
+ * counterpart): enabled 0/1, min_tiles = smallest matrix, in 2048-entry tiles, that gets a
+ * placement table, force != 0 also drops the minimum slab size so that small (test) matrices
+ * take the code path of the benchmark sizes.  A negative argument leaves its field unchanged. */
+HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int min_tiles, HYPRE_Int force);
+/* Kernel variant of the tiled SpMV family (speed only): 0 one workgroup per 2048-entry tile, 1 persistent
+ * workgroups (pipe_wgs per CU; pipe_wgs < 0: a grid of 8 * |pipe_wgs| workgroups) that prefetch the next tile's matrix
+ * stream.  variant < 0 / pipe_wgs == 0: unchanged. */
+HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int pipe_wgs);
+/* Returns 1 when the plan of the device matrix A carries a placement table; fills the tile
+ * count of the plan and the band distance the table was built for (0: none). */
+HYPRE_Int hypre_amd_CSRMatrixPlanInfo(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Int *band);
 
 /* ---- BLAS-1 (seq_mv/vector.c dispatchers + vector_device.c bodies) ---- */
 HYPRE_Int hypre_SeqVectorSetConstantValues(hypre_Vector *v, HYPRE_Complex value);

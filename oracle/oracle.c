@@ -571,7 +571,12 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
       }
       if (relax_type == 11 || relax_type == 12)
       {
-         /* par_relax.c:1506-1588 */
+         /* par_relax.c:1506-1588.  Divisor: the host loop divides by the stored diagonal entry
+          * A_diag_data[A_diag_i[i]]; the reference's device routine (par_relax_device.c:97-155) by the smoother-diagonal
+          * vector the cycle hands it (l1_norms option 5 = that diagonal, 0 -> 1; ams.c:695-726).  In fp64 the two are the
+          * same bits.  They differ only in the product's mixed-precision mode, where the matrix values (diagonal entry
+          * included) are fp32-rounded and the smoother diagonal stays fp64: like the device routine, the vector is
+          * used when one is given. */
          const int num_inner = relax_type == 11 ? 1 : 2;
          for (int r = 0; r < R; r++)
          {
@@ -583,11 +588,12 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
          {
             const long long r0 = A->row_starts[r];
             const ocsr *D = &A->diag[r];
+            const double *dg = l1 ? l1 + r0 : NULL;
             double *ur = u + r0, *vt = vtemp + r0;
             double mult = 1.0;
             for (int i = 0; i < D->nrows; i++)
             {
-               vt[i] /= D->a[D->i[i]];
+               vt[i] /= (dg ? dg[i] : D->a[D->i[i]]);
                ur[i] += mult * vt[i];
             }
             mult *= -1.0;
@@ -601,7 +607,7 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
                      const int ii = D->j[jj];
                      if (ii < i) { res += D->a[jj] * vt[ii]; }
                   }
-                  vt[i] = res / D->a[D->i[i]];
+                  vt[i] = res / (dg ? dg[i] : D->a[D->i[i]]);
                   ur[i] += mult * vt[i];
                }
                mult *= -1.0;
@@ -936,13 +942,19 @@ int oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol, in
                      int converge_type, int u_all_zeros, double *rel_resid_out, int *conv_err,
                      double *resid_hist)
 {
-   const opar *A0 = &amg->A[0];
+   const opar *A0 = amg->A_outer ? amg->A_outer : &amg->A[0];
    const long long n = A0->row_starts[A0->nranks];
    double **F = amg->F, **U = amg->U;
    double *f_save = F[0], *u_save = U[0];
    F[0] = (double *) f; U[0] = u;
    double resid_nrm = 1.0, resid_init = 1.0, rhs_norm = 0.0, relative_resid = 1.0, old_resid;
    int cycle_count = 0, az = u_all_zeros;
+   double *mp_r = NULL, *mp_e = NULL;
+   if (amg->A_outer)
+   {
+      mp_r = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+      mp_e = (double *) malloc(sizeof(double) * (size_t) (n > 0 ? n : 1));
+   }
    double *vtemp = amg->vtemp;
    if (conv_err) { *conv_err = 0; }
    if (tol > 0.0)
@@ -962,7 +974,18 @@ int oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol, in
    }
    while ((relative_resid >= tol || cycle_count < min_iter) && cycle_count < max_iter)
    {
-      oracle_amg_cycle(amg, F, U, &az);
+      if (amg->A_outer && !az)
+      {
+         /* mixed precision, correction form: fp64 residual with the exact operator, cycle from zero, add */
+         oracle_par_matvec(-1.0, A0, u, 1.0, f, mp_r);
+         for (long long q = 0; q < n; q++) { mp_e[q] = 0.0; }
+         int ez = 1;
+         F[0] = mp_r; U[0] = mp_e;
+         oracle_amg_cycle(amg, F, U, &ez);
+         F[0] = (double *) f; U[0] = u;
+         for (long long q = 0; q < n; q++) { u[q] += mp_e[q]; }
+      }
+      else { oracle_amg_cycle(amg, F, U, &az); }
       if (tol > 0.0)
       {
          old_resid = resid_nrm;
@@ -978,6 +1001,7 @@ int oracle_amg_solve(const oamg *amg, const double *f, double *u, double tol, in
    if (cycle_count == max_iter && tol > 0.0 && conv_err) { *conv_err = 1; }
    if (rel_resid_out) { *rel_resid_out = relative_resid; }
    F[0] = f_save; U[0] = u_save;
+   free(mp_r); free(mp_e);
    return cycle_count;
 }
 
@@ -995,7 +1019,7 @@ int oracle_pcg_amg(const oamg *amg, const double *b, double *x, double r_tol, do
 int oracle_pcg_amg_flex(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
                         int two_norm, int precond_cycles, int flex, double *rel_resid_out, int *converged_out)
 {
-   const opar *A = &amg->A[0];
+   const opar *A = amg->A_outer ? amg->A_outer : &amg->A[0];
    const long long n = A->row_starts[A->nranks];
    double *p = (double *) calloc((size_t) n, sizeof(double));
    double *s = (double *) calloc((size_t) n, sizeof(double));
@@ -1072,7 +1096,7 @@ int oracle_pcg_amg_flex(const oamg *amg, const double *b, double *x, double r_to
 int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
                      int k_dim, int precond_cycles, double *rel_resid_out, int *converged_out)
 {
-   const opar *A = &amg->A[0];
+   const opar *A = amg->A_outer ? amg->A_outer : &amg->A[0];
    const long long n = A->row_starts[A->nranks];
    const double epsmac = 1.e-16;
    double **p = (double **) calloc((size_t) k_dim + 1, sizeof(double *));

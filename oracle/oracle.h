@@ -46,6 +46,11 @@ typedef struct
    int       cheby_order, cheby_scale;
    double  **cheby_coefs;        /* [num_levels][order + 1] or NULL */
    double  **cheby_ds;           /* [num_levels] global arrays or NULL */
+   /* The product's mixed-precision mode (no reference counterpart): A[] / P[] hold the fp32-rounded values the cycle
+    * works with, A_outer the exact fine-level operator everything outside the cycle uses (the solver's residual, the
+    * Krylov products).  NULL: A[0] serves both.  With A_outer set, a cycle from a guess that is not known to be zero
+    * is applied in correction form: r = f - A_outer u (fp64), e = cycle(r) from zero, u += e. */
+   opar     *A_outer;
 } oamg;
 
 /* OpenMP threads of the independent row loops (timed CPU baseline); results are

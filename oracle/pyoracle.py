@@ -35,7 +35,7 @@ class OAMG(C.Structure):
                 ("relax_order", C.c_int), ("user_relax_type", C.c_int), ("relax_weight", RealP),
                 ("omega", RealP), ("cycle_type", C.c_int), ("fcycle", C.c_int), ("num_threads", C.c_int),
                 ("cheby_order", C.c_int), ("cheby_scale", C.c_int), ("cheby_coefs", C.POINTER(RealP)),
-                ("cheby_ds", C.POINTER(RealP))]
+                ("cheby_ds", C.POINTER(RealP)), ("A_outer", C.POINTER(OPAR))]
 
 
 def build():
@@ -177,9 +177,11 @@ class Amg:
 
     def __init__(self, A_levels, P_levels, cf_markers, l1_norms, num_grid_sweeps, grid_relax_type,
                  relax_order=0, relax_weight=None, omega=None, cycle_type=1, fcycle=0, num_threads=1,
-                 max_levels=25, user_relax_type=-1, grid_relax_points=None, cheby=None):
-        """cheby: None or dict(order=, scale=, coefs=[per level array or None], ds=[per level array or None])."""
+                 max_levels=25, user_relax_type=-1, grid_relax_points=None, cheby=None, A_outer=None):
+        """cheby: None or dict(order=, scale=, coefs=[per level array or None], ds=[per level array or None]).
+        A_outer: the exact fine-level operator when A_levels hold fp32-rounded values (mixed precision)."""
         L = len(A_levels)
+        self.A_outer = A_outer
         self.A_levels, self.P_levels = A_levels, P_levels
         self.cf = [None if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in cf_markers]
         self.l1 = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in l1_norms]
@@ -203,6 +205,9 @@ class Amg:
         self.c = OAMG(L, max_levels, self._A, self._P, self._cf, self._l1, self._F, self._U, _rp(self.vtemp),
                       (C.c_int * 4)(*num_grid_sweeps), (C.c_int * 4)(*grid_relax_type), self._grp, relax_order,
                       user_relax_type, _rp(self.rw), _rp(self.om), cycle_type, fcycle, num_threads)
+        if A_outer is not None:
+            self._Ao = (OPAR * 1)(A_outer.c)
+            self.c.A_outer = self._Ao
         if cheby is not None:
             self.cheby_coefs = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in cheby["coefs"]]
             self.cheby_ds = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in cheby["ds"]]
@@ -293,8 +298,8 @@ def relax(A, f, cf_marker, relax_type, relax_points, w, omega, l1, u, num_thread
 def par_from_handles(handles, fp32_diag_values=False):
     """handles: list (one per rank, rank order) of hypre_ParCSRMatrix pointers
     (ctypes POINTER(ParCSRMatrix) or raw addresses) living in this process.
-    fp32_diag_values: round the diag-block values to fp32 (the product's mixed-precision mode streams
-    fp32 copies of those values and accumulates in fp64, which is this matrix in exact arithmetic)."""
+    fp32_diag_values: round the matrix values (diagonal and ghost block) to fp32 (the product's mixed-precision mode
+    streams fp32 copies of those values and accumulates in fp64, which is this matrix in exact arithmetic)."""
     import ctypes as C
     from hypre_amd import binding as B
     blocks, rs, cs = [], [], []
@@ -307,6 +312,8 @@ def par_from_handles(handles, fp32_diag_values=False):
         if fp32_diag_values:
             da = da.astype(np.float32).astype(np.float64)
         oi, oj, oa = B.csr_to_arrays(m.offd)
+        if fp32_diag_values:
+            oa = oa.astype(np.float32).astype(np.float64)
         nco = m.offd.contents.num_cols
         cmap = np.array([m.col_map_offd[k] for k in range(nco)], dtype=np.int64)
         rn = np.nonzero(np.diff(oi))[0].astype(np.int32)
@@ -389,9 +396,10 @@ def amg_from_solvers(solvers, num_threads=1, mixed_precision=False):
     rw = np.array([d.relax_weight[k] for k in range(nl)])
     om = np.array([d.omega[k] for k in range(nl)])
     cheby = _merge_cheby([_export_cheby(s, nl) for s in solvers])
+    A_outer = par_from_handles([L.hypre_amd_BoomerAMGGetA(s, 0) for s in solvers]) if mixed_precision else None
     return Amg(A_levels, P_levels, cfs, l1s, sweeps, types, relax_order=d.relax_order, relax_weight=rw, omega=om,
                cycle_type=d.cycle_type, fcycle=d.fcycle, num_threads=num_threads, max_levels=d.max_levels,
-               user_relax_type=d.user_relax_type, cheby=cheby)
+               user_relax_type=d.user_relax_type, cheby=cheby, A_outer=A_outer)
 
 
 def export_par(h):
@@ -410,13 +418,15 @@ def export_par(h):
                 cs=(int(m.col_starts[0]), int(m.col_starts[1])))
 
 
-def par_from_exports(parts):
+def par_from_exports(parts, fp32_diag_values=False):
     blocks, rs, cs = [], [], []
     for d in parts:
         rn = np.nonzero(np.diff(d["oi"]))[0].astype(np.int32)
         with_rn = rn if (0 < len(rn) < d["nrows"]) else None
-        blocks.append((Csr(d["nrows"], d["ncols"], d["di"], d["dj"], d["da"]),
-                       Csr(d["nrows"], d["nco"], d["oi"], d["oj"], d["oa"], with_rn), d["cmap"]))
+        da = d["da"].astype(np.float32).astype(np.float64) if fp32_diag_values else d["da"]
+        oa = d["oa"].astype(np.float32).astype(np.float64) if fp32_diag_values else d["oa"]
+        blocks.append((Csr(d["nrows"], d["ncols"], d["di"], d["dj"], da),
+                       Csr(d["nrows"], d["nco"], d["oi"], d["oj"], oa, with_rn), d["cmap"]))
         rs.append(d["rs"][0]); cs.append(d["cs"][0])
     rs.append(parts[-1]["rs"][1]); cs.append(parts[-1]["cs"][1])
     return Par(blocks, rs, cs)
@@ -456,22 +466,24 @@ def export_solver(s):
     return out
 
 
-def amg_from_exports(parts, num_threads=1):
-    """parts: export_solver() dicts of all ranks in rank order."""
+def amg_from_exports(parts, num_threads=1, mixed_precision=False):
+    """parts: export_solver() dicts of all ranks in rank order.  mixed_precision as in amg_from_solvers."""
     p0 = parts[0]
     nl = p0["num_levels"]
-    A_levels = [par_from_exports([p["A"][l] for p in parts]) for l in range(nl)]
-    P_levels = [par_from_exports([p["P"][l] for p in parts]) for l in range(nl - 1)]
+    A_levels = [par_from_exports([p["A"][l] for p in parts], fp32_diag_values=mixed_precision and l < nl - 1)
+                for l in range(nl)]
+    P_levels = [par_from_exports([p["P"][l] for p in parts], fp32_diag_values=mixed_precision) for l in range(nl - 1)]
     cfs, l1s = [], []
     for l in range(nl):
         c = [p["cf"][l] for p in parts]
         cfs.append(np.concatenate(c) if all(x is not None for x in c) else None)
         v = [p["l1"][l] for p in parts]
         l1s.append(np.concatenate(v) if all(x is not None for x in v) else None)
+    A_outer = par_from_exports([p["A"][0] for p in parts]) if mixed_precision else None
     return Amg(A_levels, P_levels, cfs, l1s, p0["sweeps"], p0["types"], relax_order=p0["relax_order"],
                relax_weight=p0["rw"], omega=p0["om"], cycle_type=p0["cycle_type"], fcycle=p0["fcycle"],
                num_threads=num_threads, max_levels=p0["max_levels"], user_relax_type=p0["user_relax_type"],
-               cheby=_merge_cheby([p.get("cheby") for p in parts]))
+               cheby=_merge_cheby([p.get("cheby") for p in parts]), A_outer=A_outer)
 
 
 class AmgDataView(C.Structure):

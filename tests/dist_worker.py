@@ -27,7 +27,12 @@ def main():
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     L = B.load_library()
-    comm = distributed.create_callback_comm(dist, rank, world) if world > 1 else 0     # 0: hypre_MPI_COMM_WORLD of one rank
+    # transport "staged": device-buffer communicator (the library's production halo flow: pack, event, exchange enqueued
+    # on the communication stream, event; device all-reduces) whose bytes travel over gloo — ranks may share the card
+    if world > 1 and spec.get("transport") == "staged":
+        comm = distributed.create_stream_staged_comm(dist, rank, world)
+    else:
+        comm = distributed.create_callback_comm(dist, rank, world) if world > 1 else 0     # 0: hypre_MPI_COMM_WORLD of one rank
     if world > 1 and L.hypre_amd_CommSelfTest(comm, 4099) != 0:
         raise SystemExit("communicator self-test failed on rank %d" % rank)
     for case in cases:
@@ -46,6 +51,9 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE if device else B.HYPRE_MEMORY_HOST)
     if "replicate" in case:
         L.hypre_amd_BoomerAMGSetReplicateThreshold(s, int(case["replicate"]))
+    mixed = bool(case.get("mixed", 0))
+    if mixed:
+        L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
     B.check()
     g, o = C.c_double(), C.c_double()
@@ -110,12 +118,12 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
     parts = [None] * world if rank == 0 else None
     dist.gather_object(mine, parts, dst=0)
     if rank == 0:
-        amg = O.amg_from_exports([p["h"] for p in parts], num_threads=opt.num_threads)
+        amg = O.amg_from_exports([p["h"] for p in parts], num_threads=opt.num_threads, mixed_precision=mixed)
         n = amg.A_levels[0].nrows
         xg = np.concatenate([p["x"] for p in parts])
         if parts[0]["b"] is None:
             bg = np.zeros(n)
-            O.par_matvec(1.0, amg.A_levels[0], np.ones(n), 0.0, bg, bg)
+            O.par_matvec(1.0, amg.A_outer or amg.A_levels[0], np.ones(n), 0.0, bg, bg)
         else:
             bg = np.concatenate([p["b"] for p in parts])
         out = {"grid": g.value, "operator": o.value, "levels": amg.c.num_levels,
@@ -132,7 +140,7 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
                                      precond_cycles=opt.precon_cycles, flex=opt.flex)
             out.update(iterations=its, rel_resid=rel)
         if device:
-            A0 = amg.A_levels[0]
+            A0 = amg.A_outer or amg.A_levels[0]        # mixed precision: products outside the cycle use the exact operator
             xt = np.concatenate([p["xt"] for p in parts])
             yr = np.zeros(n)
             O.par_matvec(2.0, A0, xt, 0.0, yr, yr)

@@ -238,7 +238,9 @@ def test_mixed_precision_cycle(gpu_lib, oracle, kw):
         B.check()
         u = B.parvec_to_numpy(du)
         u32, u64 = u0.copy(), u0.copy()
-        amg32.cycle(f, u32, u_all_zeros=zero)
+        # one pass of the solve loop: from a non-zero guess the mixed cycle works on the error equation (fp64 residual
+        # with the exact operator, cycle from zero, fp64 correction)
+        amg32.solve(f, u32, tol=0.0, max_iter=1, u_all_zeros=zero)
         amg64.cycle(f, u64, u_all_zeros=zero)
         scale = np.max(np.abs(u64))
         assert np.max(np.abs(u - u32)) <= 1e-11 * scale, (kw, zero)

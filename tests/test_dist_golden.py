@@ -13,6 +13,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "ij_saved.json")))
 
 
+def _tail(r):
+    """What a failed launch has to say: the first Python traceback of a rank (the launcher's own summary, which ends
+    the stream, names no cause) and the end of both streams."""
+    err = r.stderr
+    k = err.find("Traceback (most recent call last)")
+    first = err[k:k + 3000] if k >= 0 else ""
+    return r.stdout[-1500:] + "\n--- first traceback ---\n" + first + "\n--- stderr tail ---\n" + err[-1500:]
+
+
 def run_ranks(nranks, case, timeout=240, extra=None, omp=None):
     from conftest import free_port
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
@@ -22,7 +31,7 @@ def run_ranks(nranks, case, timeout=240, extra=None, omp=None):
     env = dict(os.environ, OMP_NUM_THREADS=str(omp) if omp else os.environ.get("HYPRE_AMD_TEST_OMP", "1"))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and lines, _tail(r)
     return json.loads(lines[-1][len("RESULT "):])
 
 
@@ -46,7 +55,7 @@ def batch_result(name):
             if line.startswith("RESULT "):
                 d = json.loads(line[len("RESULT "):])
                 res[d["name"]] = d
-        _batches[nranks] = (r.returncode, res, r.stdout[-2000:] + r.stderr[-2000:])
+        _batches[nranks] = (r.returncode, res, _tail(r))
     rc, res, tail = _batches[nranks]
     assert name in res, "no result for %s (worker exit code %d)\n%s" % (name, rc, tail)
     return res[name]

@@ -1,8 +1,13 @@
-"""GPU, two ranks sharing the card (gloo as the transport, halo buffers staged over the
-host): the distributed DEVICE path — pack kernel, overlapped interior product, ghost
-product, transpose product with scatter-add, distributed cycle, coarse gather — against
-the CPU oracle running the same hierarchy as virtual ranks.  (The RCCL transport itself
-needs one GPU per rank and is exercised by bench.py --gpus N.)"""
+"""GPU, two to four ranks sharing the card: the distributed DEVICE path — pack kernel, overlapped interior
+product, ghost product, transpose product with scatter-add, distributed cycle, coarse gather, replicated tail —
+against the CPU oracle running the same hierarchy as virtual ranks.
+
+Transport: the stream-staged device-buffer communicator (hypre_amd_CommCreateStreamStaged over gloo).  The library
+drives it exactly as it drives RCCL — send buffer packed on the compute stream, event, exchange enqueued on the
+communication stream, event, compute stream waits; all-reduces of device buffers — so the production branch of
+hypre_ParCSRCommHandleCreate_v2 / Destroy, dev_allreduce_sum and the event pool run between real ranks here.  (RCCL
+itself refuses two ranks on one device; its provider is covered by the size-1 self-test below and by bench.py
+--gpus N.)  A few cases also run over the blocking host-staged branch (device_buffers = 0)."""
 import pytest
 
 import json
@@ -10,7 +15,7 @@ import os
 import subprocess
 import sys
 
-from test_dist_golden import GOLD, HERE, run_ranks
+from test_dist_golden import GOLD, HERE, run_ranks, _tail
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +36,7 @@ def device_batch_result(name):
     if nranks not in _batches:
         from conftest import free_port
         names = [k for k in DEVICE_CASES if GOLD[k]["ranks"] == nranks]
-        spec = {"batch": [{"name": k, "options": GOLD[k]["options"], "device": 1} for k in names]}
+        spec = {"batch": [{"name": k, "options": GOLD[k]["options"], "device": 1} for k in names], "transport": "staged"}
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
                json.dumps(spec)]
@@ -42,7 +47,7 @@ def device_batch_result(name):
             if line.startswith("RESULT "):
                 d = json.loads(line[len("RESULT "):])
                 res[d["name"]] = d
-        _batches[nranks] = (r.returncode, res, r.stdout[-2000:] + r.stderr[-2000:])
+        _batches[nranks] = (r.returncode, res, _tail(r))
     rc, res, tail = _batches[nranks]
     assert name in res, "no result for %s (worker exit code %d)\n%s" % (name, rc, tail)
     return res[name]
@@ -65,13 +70,92 @@ def test_two_or_three_ranks_on_device(name):
         assert abs(out["conv_factor"] - exp["conv_factor"]) < 5.1e-7
 
 
+HOST_STAGED_CASES = ["smoother.out.10", "solvers.out.21", "smoother.out.0"]
+
+
+@pytest.mark.parametrize("name", HOST_STAGED_CASES)
+def test_blocking_host_staged_branch(name):
+    """device_buffers = 0: hypre_ParCSRCommHandleCreate_v2 copies the halo buffers through host memory around a
+    blocking exchange (what the reference's device path does).  Same goldens."""
+    case = dict(GOLD[name])
+    out = run_ranks(case["ranks"], {"options": case["options"]}, timeout=600, extra={"device": 1})
+    exp = case["expect"]
+    assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
+    assert out["dev_iterations"] == out["iterations"]
+    if "iterations" in exp:
+        assert out["dev_iterations"] == exp["iterations"]
+        assert abs(out["dev_rel_resid"] - exp["rel_resid"]) <= 5e-7 * exp["rel_resid"]
+
+
+# The three multi-rank BASELINE configurations at sizes the oracle solves in seconds, ranks in the reference's
+# P x Q x R box layout: C3 (7-point, l1-Jacobi, replicated tail), C4 (27-point, two-stage Gauss-Seidel: every level
+# stays distributed), C5 (anisotropic diffusion, fp32 matrix values in the cycle).  AMG alone and under PCG.
+BASELINE_CASES = {
+    "c3_pcg_4ranks": (4, dict(n=[24, 24, 12], P=[2, 2, 1], relax_type=18, coarsen_type=8, solver=1), {}),
+    "c3_amg_4ranks": (4, dict(n=[24, 24, 12], P=[2, 2, 1], relax_type=18, coarsen_type=8), {}),
+    "c3_amg_4ranks_no_tail": (4, dict(n=[24, 24, 12], P=[2, 2, 1], relax_type=18, coarsen_type=8), {"replicate": 0}),
+    "c4_amg_relax11_2ranks": (2, dict(n=[16, 16, 16], P=[2, 1, 1], problem="27pt", relax_type=11, coarsen_type=8), {}),
+    "c4_pcg_relax11_4ranks": (4, dict(n=[20, 20, 10], P=[2, 2, 1], problem="27pt", relax_type=11, coarsen_type=8, solver=1), {}),
+    "c4_pcg_relax12_4ranks": (4, dict(n=[20, 20, 10], P=[2, 2, 1], problem="27pt", relax_type=12, coarsen_type=8, solver=1), {}),
+    "c4_pcg_relax11_4ranks_no_tail": (4, dict(n=[20, 20, 10], P=[2, 2, 1], problem="27pt", relax_type=11, coarsen_type=8, solver=1),
+                                      {"replicate": 0}),
+    "c4_amg_relax12_2ranks_no_tail": (2, dict(n=[16, 16, 16], P=[2, 1, 1], problem="27pt", relax_type=12, coarsen_type=8),
+                                      {"replicate": 0}),
+    "c5_amg_mixed_2ranks": (2, dict(n=[20, 20, 20], P=[1, 1, 2], problem="difconv", c=[1.0, 1.0, 0.001], a=[0.0, 0.0, 0.0],
+                                    relax_type=18, coarsen_type=8), {"mixed": 1}),
+    "c5_pcg_mixed_4ranks": (4, dict(n=[20, 20, 20], P=[2, 2, 1], problem="difconv", c=[1.0, 1.0, 0.001], a=[0.0, 0.0, 0.0],
+                                    relax_type=18, coarsen_type=8, solver=1), {"mixed": 1}),
+    "c5_pcg_mixed_relax11_4ranks": (4, dict(n=[16, 16, 16], P=[2, 2, 1], problem="27pt", relax_type=11, coarsen_type=8, solver=1),
+                                    {"mixed": 1}),
+    "c5_amg_mixed_2ranks_no_tail": (2, dict(n=[20, 20, 20], P=[1, 1, 2], problem="difconv", c=[1.0, 1.0, 0.001], a=[0.0, 0.0, 0.0],
+                                            relax_type=18, coarsen_type=8), {"mixed": 1, "replicate": 0}),
+}
+_baseline = {}
+
+
+def _baseline_result(name):
+    nranks = BASELINE_CASES[name][0]
+    if nranks not in _baseline:
+        from conftest import free_port
+        names = [k for k, v in BASELINE_CASES.items() if v[0] == nranks]
+        spec = {"batch": [dict({"name": k, "options": BASELINE_CASES[k][1], "device": 1}, **BASELINE_CASES[k][2])
+                          for k in names], "transport": "staged"}
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
+               json.dumps(spec)]
+        env = dict(os.environ, OMP_NUM_THREADS="1", HYPRE_AMD_TEST_WATCHDOG="900")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+        res = {}
+        for line in r.stdout.splitlines():
+            if line.startswith("RESULT "):
+                d = json.loads(line[len("RESULT "):])
+                res[d["name"]] = d
+        _baseline[nranks] = (r.returncode, res, _tail(r))
+    rc, res, tail = _baseline[nranks]
+    assert name in res, "no result for %s (worker exit code %d)\n%s" % (name, rc, tail)
+    return res[name]
+
+
+@pytest.mark.parametrize("name", sorted(BASELINE_CASES))
+def test_baseline_multi_rank_configs_on_device(name):
+    out = _baseline_result(name)
+    assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
+    assert out["dev_iterations"] == out["iterations"] and out["iterations"] > 3
+    assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
+    assert out["x_err"] < 1e-9
+    # the small levels run on every rank's replica (one all-reduce per cycle instead of four halo exchanges per
+    # level) for all three configurations: two-stage GS keeps the triangles of the ranks' diagonal blocks there,
+    # mixed precision the fp32-rounded values
+    assert (out["replicated_level"] == -1) == ("no_tail" in name)
+
+
 def test_replicated_tail_is_used_and_optional():
     """Jacobi-type V-cycles on several ranks run their small levels on a replicated copy (one all-reduce instead of
     four halo exchanges per level); switched off, the same solve goes through the distributed levels.  Both
     reproduce the reference's golden (smoother.out.9: relax 18 with CF ordering, 3 ranks)."""
     case = dict(GOLD["smoother.out.9"])
-    on = run_ranks(3, {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1})
-    off = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1, "replicate": 0})
+    on = run_ranks(3, {"options": case["options"], "device": 1}, timeout=600, extra={"device": 1, "transport": "staged"})
+    off = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1, "replicate": 0, "transport": "staged"})
     assert on["replicated_level"] >= 1 and off["replicated_level"] == -1
     for out in (on, off):
         assert out["dev_iterations"] == case["expect"]["iterations"]
@@ -82,7 +166,7 @@ def test_replicated_tail_is_used_and_optional():
 
 def test_pcg_three_ranks_on_device():
     case = dict(GOLD["solvers.out.19"])
-    out = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1})
+    out = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1, "transport": "staged"})
     assert out["dev_iterations"] == case["expect"]["iterations"] == out["iterations"]
     assert abs(out["dev_rel_resid"] - case["expect"]["rel_resid"]) <= 5e-7 * case["expect"]["rel_resid"]
 
@@ -110,7 +194,7 @@ def test_rank_without_rows_on_device():
     """Three grid points across four ranks: one rank owns nothing on any level.  Empty blocks, empty halos and empty
     device arrays must go through setup, migration, the distributed solve and destruction without an error."""
     opts = {"n": [3, 5, 4], "P": [4, 1, 1], "relax_type": 18, "coarsen_type": 8}
-    out = run_ranks(4, {"options": opts, "device": 1}, timeout=600, extra={"device": 1})
+    out = run_ranks(4, {"options": opts, "device": 1}, timeout=600, extra={"device": 1, "transport": "staged"})
     assert out["sizes"][0] == 60
     assert out["dev_iterations"] == out["iterations"]
     assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]

@@ -1,12 +1,12 @@
 """Per-level kernel timing of a BoomerAMG hierarchy (HIP events on the library's stream).
 
-    python tools/bench_levels.py [n] [reps]
+    python tools/bench_levels.py [n] [reps] [--variants 0,1:4,1:6] [--problem laplacian|27pt] [--levels 4]
 
-Builds the benchmark hierarchy (n^3 7-pt Laplacian, PMIS / ext+i(4) / l1-Jacobi) and times, level
-by level, y = A x, the fused l1-Jacobi sweep, the prolongation P x and the restriction P^T x,
-printing algorithmic GB/s (SURVEY.md 8d byte formulas).  Tuning knobs (HYPRE_AMD_SPMV_*) are read
-once per process, so A/B runs are separate invocations.
+Builds the benchmark hierarchy (n^3 7-pt Laplacian, PMIS / ext+i(4) / l1-Jacobi) once and times, level by level and
+for every kernel variant asked for (hypre_amd_SpmvSetVariant: `v` or `v:workgroups-per-CU`), y = A x, the fused
+l1-Jacobi sweep, the prolongation P x and the restriction P^T x, printing algorithmic GB/s (SURVEY.md 8d byte formulas).
 """
+import argparse
 import ctypes as C
 import os
 import sys
@@ -17,10 +17,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hypre_amd import binding as B, ij   # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ap = argparse.ArgumentParser()
+ap.add_argument("n", type=int, nargs="?", default=256)
+ap.add_argument("reps", type=int, nargs="?", default=20)
+ap.add_argument("--variants", default="0")
+ap.add_argument("--problem", default="laplacian")
+ap.add_argument("--levels", type=int, default=99, help="time the first LEVELS levels only")
+ap.add_argument("--relax", type=int, default=18)
+args = ap.parse_args()
+n, reps = args.n, args.reps
 L = B.load_library()
-opt = ij.IJOptions(n=(n, n, n), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=18, num_sweeps=1)
+opt = ij.IJOptions(n=(n, n, n), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=args.relax, num_sweeps=1,
+                   problem=args.problem)
 t0 = time.time()
 A = ij.build_matrix(opt)
 s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
@@ -42,8 +50,28 @@ def timed(fn):
     return L.hypre_amd_EventTimerStopMs() / reps
 
 
-tot = 0.0
-for l in range(nl):
+variants = []
+for tok in args.variants.split(","):
+    v = tok.split(":")
+    variants.append((int(v[0]), int(v[1]) if len(v) > 1 else 0))
+
+# one V(1,1) cycle per variant first (what the benchmark times)
+b = B.parvec_from_numpy(np.ones(n ** 3))
+u = B.parvec_from_numpy(np.zeros(n ** 3))
+L.HYPRE_BoomerAMGSetTol(s, 0.0)
+L.HYPRE_BoomerAMGSetMaxIter(s, 1)
+
+
+def cycle():
+    L.hypre_ParVectorSetZeros(u)
+    L.HYPRE_BoomerAMGSolve(s, A, b, u)
+
+
+for var, wgs in variants:
+    L.hypre_amd_SpmvSetVariant(var, wgs)
+    print("variant %d:%d  V-cycle %.4f ms" % (var, wgs, timed(cycle)), flush=True)
+
+for l in range(min(nl, args.levels)):
     Al = C.cast(L.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
     d = Al.contents.diag.contents
     nr, nnz = d.num_rows, d.num_nonzeros
@@ -53,27 +81,26 @@ for l in range(nl):
     v = B.parvec_from_numpy(np.zeros(nr))
     l1p = L.hypre_amd_BoomerAMGGetL1Norms(s, l)
     l1 = C.cast(l1p, C.POINTER(B.Vector)).contents.data if l1p else None
-    ms_a = timed(lambda: L.hypre_ParCSRMatrixMatvec(1.0, Al, x, 0.0, y))
-    by_a = nnz * 12 + (nr + 1) * 4 + nr * 16
-    line = "L%d rows=%9d nnz=%10d (%.1f/row)  A x: %.4f ms %6.0f GB/s" % (l, nr, nnz, nnz / max(nr, 1), ms_a, by_a / ms_a / 1e6)
-    if l1 is not None and l < nl - 1:
-        ms_j = timed(lambda: L.hypre_BoomerAMGRelax(Al, f, None, 18, 0, 1.0, 1.0, l1, x, v, v))
-        by_j = nnz * 12 + (nr + 1) * 4 + nr * 32
-        line += " | l1-Jacobi (+copy back): %.4f ms %6.0f GB/s" % (ms_j, (by_j + nr * 16) / ms_j / 1e6)
-        tot += ms_j
-    if l < nl - 1:
-        Pl = C.cast(L.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
-        pd = Pl.contents.diag.contents
-        nc = pd.num_cols
-        xc = B.parvec_from_numpy(np.random.default_rng(l + 50).uniform(-1, 1, nc))
-        yc = B.parvec_from_numpy(np.zeros(nc))
-        ms_p = timed(lambda: L.hypre_ParCSRMatrixMatvec(1.0, Pl, xc, 1.0, y))
-        ms_r = timed(lambda: L.hypre_ParCSRMatrixMatvecT(1.0, Pl, x, 0.0, yc))
-        by_p = pd.num_nonzeros * 12 + (nr + 1) * 4 + nc * 8 + nr * 16
-        by_r = pd.num_nonzeros * 12 + (nc + 1) * 4 + nr * 8 + nc * 8
-        line += " | P x: %.4f ms %6.0f GB/s | P^T x: %.4f ms %6.0f GB/s" % (ms_p, by_p / ms_p / 1e6, ms_r, by_r / ms_r / 1e6)
-        tot += ms_p + ms_r
-    tot += ms_a
-    print(line, flush=True)
+    print("L%d rows=%9d nnz=%10d (%.1f/row)" % (l, nr, nnz, nnz / max(nr, 1)), flush=True)
+    for var, wgs in variants:
+        L.hypre_amd_SpmvSetVariant(var, wgs)
+        ms_a = timed(lambda: L.hypre_ParCSRMatrixMatvec(1.0, Al, x, 0.0, y))
+        by_a = nnz * 12 + (nr + 1) * 4 + nr * 16
+        line = "   v%d:%d  A x: %.4f ms %6.0f GB/s" % (var, wgs, ms_a, by_a / ms_a / 1e6)
+        if l1 is not None and l < nl - 1:
+            ms_j = timed(lambda: L.hypre_BoomerAMGRelax(Al, f, None, 18, 0, 1.0, 1.0, l1, x, v, v))
+            by_j = nnz * 12 + (nr + 1) * 4 + nr * 32
+            line += " | l1-Jacobi (+copy back): %.4f ms %6.0f GB/s" % (ms_j, (by_j + nr * 16) / ms_j / 1e6)
+        if l < nl - 1:
+            Pl = C.cast(L.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+            pd = Pl.contents.diag.contents
+            nc = pd.num_cols
+            xc = B.parvec_from_numpy(np.random.default_rng(l + 50).uniform(-1, 1, nc))
+            yc = B.parvec_from_numpy(np.zeros(nc))
+            ms_p = timed(lambda: L.hypre_ParCSRMatrixMatvec(1.0, Pl, xc, 1.0, y))
+            ms_r = timed(lambda: L.hypre_ParCSRMatrixMatvecT(1.0, Pl, x, 0.0, yc))
+            by_p = pd.num_nonzeros * 12 + (nr + 1) * 4 + nc * 8 + nr * 16
+            by_r = pd.num_nonzeros * 12 + (nc + 1) * 4 + nr * 8 + nc * 8
+            line += " | P x: %.4f ms %6.0f GB/s | P^T x: %.4f ms %6.0f GB/s" % (ms_p, by_p / ms_p / 1e6, ms_r, by_r / ms_r / 1e6)
+        print(line, flush=True)
 B.check()
-print("sum of timed kernels %.3f ms" % tot)
