@@ -24,6 +24,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PARITY_TOL = 1.0e-11       # device V-cycle vs the oracle's on the same hierarchy, relative max-norm (fp64)
+# the reference's own CPU path, 256^3 7-pt, 8 MPI ranks on the 8 cores of the survey container
+REFERENCE_CPU_SURVEY = {"config": "ij -n 256 256 256 -P 2 2 2 -solver 1 -rlx 18 -pmis -interptype 6 -keepT 1; 8 MPI ranks, 8 cores",
+                        "spmv_ms": 37.8, "spmv_GBps": 46.0, "pcg_s_per_iteration": 0.44, "pcg_iterations": 23,
+                        "MDOF_per_s_per_pcg_iteration": 38.0,
+                        "port_in_same_container": "profiles/r02_cpu_port_vs_reference_survey_container.json"}
 
 
 def parse():
@@ -62,6 +67,9 @@ def proc_grid(n):
 
 
 def main():
+    # pin the OpenMP threads of the CPU baseline (must be in the environment before the OpenMP runtime starts)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -269,7 +277,10 @@ def main():
 
         cores = max(1, min(len(os.sched_getaffinity(0)), args.cpu_threads))
         cpu_1 = cpu_cycles(1, args.cpu_cycles)
-        cpu_s = cpu_cycles(cores, 10 * args.cpu_cycles) if cores > 1 else cpu_1
+        # threaded: median of 5 samples of 4 cycles each (threads pinned: OMP_PROC_BIND / OMP_PLACES set at start-up);
+        # run to run the mean of one long sample moved by +-25 % on the GPU box's shared host
+        samples = sorted(cpu_cycles(cores, 2 * args.cpu_cycles) for _ in range(5)) if cores > 1 else [cpu_1]
+        cpu_s = samples[len(samples) // 2]
         O.set_num_threads(1)
         O.drop_transposes()
         step()                                       # u = one cycle from zero again (the PCG run above reused u)
@@ -277,9 +288,15 @@ def main():
         ug = B.parvec_to_numpy(u)
         parity = float(np.max(np.abs(ug - ur)) / np.max(np.abs(ur)))
         cpu = {"value": nglob / cpu_s, "unit": "DOF/s", "cores": cores, "kind": "port",
-               "sample": "%d full V(1,1) cycles of the same %d^3 hierarchy (oracle/oracle.c, OpenMP row loops, "
-                         "%d threads)" % (10 * args.cpu_cycles if cores > 1 else args.cpu_cycles, n1, cores),
+               "sample": "median of %d samples of %d full V(1,1) cycles of the same %d^3 hierarchy (oracle/oracle.c, "
+                         "OpenMP row loops, %d threads, OMP_PROC_BIND=%s OMP_PLACES=%s)"
+                         % (len(samples), 2 * args.cpu_cycles if cores > 1 else args.cpu_cycles, n1, cores,
+                            os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
+               "samples_DOF_per_s": [nglob / t for t in samples],
                "single_thread_value": nglob / cpu_1,
+               # the reference itself cannot run on the GPU box; what it did in the survey's container (8 cores), and the
+               # port timed beside it there (tools/cpu_baseline_check.py -> profiles/r02_cpu_port_vs_reference_*.json)
+               "reference_cpu_survey_container": REFERENCE_CPU_SURVEY,
                "gpu_vs_cpu_cycle_rel_max_diff": parity}
 
     # parity gate: a fast cycle whose result differs from the oracle's is not a result

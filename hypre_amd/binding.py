@@ -187,6 +187,7 @@ PROTOTYPES = {
     "hypre_amd_SpmvSetBandPolicy": (Int, [Int, Int, Int]),
     "hypre_amd_SpmvSetVariant": (Int, [Int, Int]),
     "hypre_amd_CSRMatrixPlanInfo": (Int, [CSRp, IntP, IntP]),
+    "hypre_amd_CSRMatrixPlanStaging": (Int, [CSRp, IntP, RealP]),
     "hypre_SeqVectorSetConstantValues": (Int, [Vecp, Real]),
     "hypre_SeqVectorCopy": (Int, [Vecp, Vecp]),
     "hypre_SeqVectorScale": (Int, [Real, Vecp]),
@@ -221,6 +222,7 @@ PROTOTYPES = {
     "hypre_ParVectorMigrate": (Int, [ParVecp, Int]),
     "hypre_MatvecCommPkgCreate": (Int, [ParCSRp]),
     "hypre_MatvecCommPkgDestroy": (Int, [C.POINTER(CommPkg)]),
+    "hypre_ParCSRCommPkgUpdateVecStarts": (Int, [C.POINTER(CommPkg), Int, Int, Int]),
     "hypre_ParCSRCommPkgCreate_core": (Int, [Int, BigIntP, BigInt, BigIntP, Int, Int, IntP, C.POINTER(IntP),
                                              C.POINTER(IntP), IntP, C.POINTER(IntP), C.POINTER(IntP),
                                              C.POINTER(IntP)]),

@@ -111,6 +111,13 @@ struct SpmvPlan
    hypre_CSRMatrix *Lstrict = nullptr;
    // fp32 copy of the values for the mixed-precision path (lazily built)
    float *a32 = nullptr;
+   // x staging (spmv_xs_kernel): per tile the number of column segments that cover its entries (0: they do not fit, gather
+   // instead) and their descriptors (2 * SPMV_XS_SEGS ints per tile); per entry the index of its column in the tile's
+   // staged copy
+   int            *d_xs_cnt = nullptr;
+   int            *d_xs_desc = nullptr;
+   unsigned short *d_lidx   = nullptr;
+   int             xs_tiles = 0;       // tiles with a chunk list
 };
 SpmvPlan *get_plan(hypre_CSRMatrix *A);
 hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A);   // device CSR of {a_ij : j < i}, cached in A's plan
@@ -148,8 +155,10 @@ struct SpmvArgs
    int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
    const int           *tile_perm;   // workgroup -> tile table (overrides xcd_map), or null
-   int                  variant;     // 0: one workgroup per tile; 1: persistent workgroups with the next tile's stream prefetched
-   int                  pipe_wgs;    // variant 1: workgroups per CU
+   const int           *rowmap;      // epilogue row indirection (multicolour sweeps: row r of the matrix is row rowmap[r] of
+                                     // the vectors b, d, x, y, marker), or null
+   int                  variant;     // 0: x gathered through the cache; 2: x staged through LDS from the plan's chunk lists
+   int                  pipe_wgs;    // unused
 };
 void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 
@@ -158,6 +167,9 @@ void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs 
 void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s);
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
                         int *d_tile_k, hipStream_t s);
+void launch_build_xs(const HYPRE_Int *Aj, const int *d_tile_k, int num_tiles, int *xs_cnt, int *xs_desc, unsigned short *lidx,
+                     hipStream_t s);
+constexpr int SPMV_XS_SEGS = 32;     // column segments a staged tile may have
 int  device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s);
 // largest |col - row| of `nsamples` evenly spaced rows, copied to the host (structure probe of the plan builder)
 void sample_row_bands(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int num_rows, int nsamples, int *host_out, hipStream_t s);
@@ -178,6 +190,10 @@ void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipSt
 void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s);
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s);
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
+void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows, int ncols, int nnz, int *Ti, int *tj, double *ta,
+                      hipStream_t s);     // device CSR transpose, rows of the result in ascending source-row order
+void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s);   // [entry][component] -> column by column
+void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s);
 void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s);
 void launch_fill_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, const double *Aa, const HYPRE_Int *Li, HYPRE_Int *Lj,
                        double *La, int n, hipStream_t s);

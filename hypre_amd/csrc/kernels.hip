@@ -261,6 +261,88 @@ __global__ void scatter_add_kernel(const double *__restrict__ in, const int *__r
    if (i < n) { atomicAdd(&y[idx[i]], in[i]); }
 }
 
+// ---------------------------------------------------------------------------
+// CSR transpose on the device (seq_mv/csr_matop.c:1043-1270 gives the host result this reproduces: row c of A^T lists
+// the rows of A that hold column c in ascending order).  Count per column, exclusive scan, scatter with per-column
+// cursors (order within a column arbitrary), then every row of A^T is put in order by ranking its entries.
+// ---------------------------------------------------------------------------
+__global__ void count_columns_kernel(const int *__restrict__ Aj, int nnz, int *__restrict__ cnt)
+{
+   const size_t stride = (size_t) gridDim.x * blockDim.x;
+   for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < (size_t) nnz; k += stride) { atomicAdd(&cnt[Aj[k]], 1); }
+}
+
+// in-place exclusive scan of data[0..n) with the total in data[n]; one workgroup walks the array (setup-time utility)
+__global__ __launch_bounds__(1024) void scan_exclusive_kernel(int *__restrict__ data, int n)
+{
+   __shared__ int wsum[16];
+   __shared__ int carry;
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   if (tid == 0) { carry = 0; }
+   __syncthreads();
+   for (int base = 0; base < n; base += 4096)
+   {
+      int v[4], t = 0;
+      for (int q = 0; q < 4; q++) { const int i = base + 4 * tid + q; v[q] = i < n ? data[i] : 0; t += v[q]; }
+      int inc = t;
+      for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off, 64); if (lane >= off) { inc += u; } }
+      if (lane == 63) { wsum[wave] = inc; }
+      __syncthreads();
+      int before = carry;
+      for (int w = 0; w < wave; w++) { before += wsum[w]; }
+      int run = before + inc - t;
+      for (int q = 0; q < 4; q++) { const int i = base + 4 * tid + q; if (i < n) { data[i] = run; } run += v[q]; }
+      __syncthreads();
+      if (tid == 1023) { carry = run; }
+      __syncthreads();
+   }
+   if (tid == 0) { data[n] = carry; }
+}
+
+__global__ void scatter_transpose_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa,
+                                         int nrows, int *__restrict__ cursor, int *__restrict__ tj, double *__restrict__ ta)
+{
+   // 8 lanes per row
+   const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+   if (g >= nrows) { return; }
+   for (int k = Ai[g] + sub; k < Ai[g + 1]; k += 8)
+   {
+      const int q = atomicAdd(&cursor[Aj[k]], 1);
+      tj[q] = g;
+      if (Aa) { ta[q] = Aa[k]; }
+   }
+}
+
+// row c of the scattered transpose -> ascending source rows: entry i goes to slot (number of entries of the row with a
+// smaller source row); source rows are distinct within a row.  One wave per row.
+__global__ void order_rows_kernel(const int *__restrict__ Ti, int ncols, const int *__restrict__ tj_in, const double *__restrict__ ta_in,
+                                  int *__restrict__ tj, double *__restrict__ ta)
+{
+   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+   if (row >= ncols) { return; }
+   const int s = Ti[row], e = Ti[row + 1];
+   for (int i = s + lane; i < e; i += 64)
+   {
+      const int mine = tj_in[i];
+      int rank = 0;
+      for (int k = s; k < e; k++) { rank += tj_in[k] < mine ? 1 : 0; }
+      tj[s + rank] = mine;
+      if (ta_in) { ta[s + rank] = ta_in[i]; }
+   }
+}
+
+// ghost data of a multivector exchange arrives entry by entry ([ghost][component]); the products want it column by column
+__global__ void deinterleave_kernel(const double *__restrict__ in, double *__restrict__ out, int n, int nv)
+{
+   const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < (size_t) n * nv) { const int g = (int) (i / nv), j = (int) (i % nv); out[(size_t) j * n + g] = in[i]; }
+}
+__global__ void interleave_kernel(const double *__restrict__ in, double *__restrict__ out, int n, int nv)
+{
+   const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < (size_t) n * nv) { const int g = (int) (i / nv), j = (int) (i % nv); out[i] = in[(size_t) j * n + g]; }
+}
+
 __global__ void f64_to_f32_kernel(const double *__restrict__ x, float *__restrict__ y, size_t n)
 {
    const size_t stride = (size_t) gridDim.x * blockDim.x;
@@ -369,6 +451,32 @@ void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStr
 { if (n > 0) hipLaunchKernelGGL(diag_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aa, d, n); }
 void launch_coarse_solve(const double *lu, double *x, int n, hipStream_t s)
 { if (n > 0) hipLaunchKernelGGL(coarse_solve_kernel, dim3(1), dim3(64), 0, s, lu, x, n); }
+// A (nrows x ncols, device) -> Ti[ncols + 1], tj[nnz], ta[nnz] (device, allocated by the caller); Aa / ta may be null
+void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows, int ncols, int nnz, int *Ti, int *tj, double *ta,
+                      hipStream_t s)
+{
+   HIP_CHECK(hipMemsetAsync(Ti, 0, sizeof(int) * ((size_t) ncols + 1), s));
+   if (nnz <= 0 || nrows <= 0) { return; }
+   int grid = (int) std::min<size_t>(((size_t) nnz + 255) / 256, 65536);
+   hipLaunchKernelGGL(count_columns_kernel, dim3(grid), dim3(256), 0, s, Aj, nnz, Ti);
+   hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, Ti, ncols);
+   int *cursor = nullptr, *tj0 = nullptr;
+   double *ta0 = nullptr;
+   HIP_CHECK(hipMalloc((void **) &cursor, sizeof(int) * ((size_t) ncols + 1)));
+   HIP_CHECK(hipMalloc((void **) &tj0, sizeof(int) * (size_t) nnz));
+   if (Aa) { HIP_CHECK(hipMalloc((void **) &ta0, sizeof(double) * (size_t) nnz)); }
+   HIP_CHECK(hipMemcpyAsync(cursor, Ti, sizeof(int) * ((size_t) ncols + 1), hipMemcpyDeviceToDevice, s));
+   hipLaunchKernelGGL(scatter_transpose_kernel, dim3(((size_t) nrows * 8 + 255) / 256), dim3(256), 0, s, Ai, Aj, Aa, nrows, cursor, tj0, ta0);
+   hipLaunchKernelGGL(order_rows_kernel, dim3(((size_t) ncols * 64 + 255) / 256), dim3(256), 0, s, Ti, ncols, tj0, ta0, tj, ta);
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(cursor));
+   HIP_CHECK(hipFree(tj0));
+   if (ta0) { HIP_CHECK(hipFree(ta0)); }
+}
+void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s)
+{ if (n > 0 && nv > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(((size_t) n * nv + 255) / 256), dim3(256), 0, s, in, out, n, nv); }
+void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s)
+{ if (n > 0 && nv > 0) hipLaunchKernelGGL(interleave_kernel, dim3(((size_t) n * nv + 255) / 256), dim3(256), 0, s, in, out, n, nv); }
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(f64_to_f32_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, y, n); }
 

@@ -1672,8 +1672,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          else if (last && gt[3] == 88) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 6, nullptr, &l1); }
          if (!last && (gt[1] == 18 || gt[2] == 18)) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 1, cf, &l1); }
          else if (last && gt[3] == 18) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 1, nullptr, &l1); }
-         if (gt[1] == 7 || gt[2] == 7 || (gt[3] == 7 && last) || gt[1] == 11 || gt[2] == 11 || (gt[3] == 11 && last) ||
-             gt[1] == 12 || gt[2] == 12 || (gt[3] == 12 && last))
+         auto diag_smoother = [](HYPRE_Int t) { return t == 7 || t == 11 || t == 12 || t == 21 || t == 22; };
+         if (diag_smoother(gt[1]) || diag_smoother(gt[2]) || (diag_smoother(gt[3]) && last))
          {
             hypre_Free(l1, HYPRE_MEMORY_HOST);
             l1_norms(Al, 5, nullptr, &l1);

@@ -263,6 +263,13 @@ HYPRE_Int hypre_BoomerAMGRelax(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_
          if (relax_type == 13 || relax_type == 89) { hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, 1, 0); }
          if (relax_type == 14 || relax_type == 89) { hypre_BoomerAMGRelaxHybridGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, omega, l1_norms, u, Vtemp, Ztemp, -1, 0); }
          break;
+      // multicolour Gauss-Seidel (no reference counterpart; par_relax_mc.cpp): 21 colours ascending, 22 descending
+      case 21:
+         hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, l1_norms, u, Vtemp, 1);
+         break;
+      case 22:
+         hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(A, f, cf_marker, relax_points, relax_weight, l1_norms, u, Vtemp, -1);
+         break;
       default:
          hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGRelax: relax_type is outside the scope of this library");
          break;

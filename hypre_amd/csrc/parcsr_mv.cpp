@@ -482,7 +482,54 @@ HYPRE_Int hypre_MatvecCommPkgDestroy(hypre_ParCSRCommPkg *pkg)
    hypre_Free(pkg->device_send_map_elmts, HYPRE_MEMORY_DEVICE);
    hypre_Free(pkg->tmp_data, HYPRE_MEMORY_DEVICE);
    hypre_Free(pkg->buf_data, HYPRE_MEMORY_DEVICE);
+   if (pkg->matrix_E) { hypre_CSRMatrixDestroy(pkg->matrix_E); }
    free(pkg);
+   return hypre_error_flag;
+}
+
+// Switch a package between single vectors and multivectors of num_components_in columns (par_csr_communication.c:1054-1154):
+// entry i of a send list becomes num_components_in consecutive entries, component j addressing
+// send_map_elmts[i] * idxstride + j * vecstride of the multivector's data, and every message grows by that factor —
+// one exchange then carries all columns.  The device copies of the lists and the work buffers are dropped (rebuilt at
+// the new size on the next product).
+HYPRE_Int hypre_ParCSRCommPkgUpdateVecStarts(hypre_ParCSRCommPkg *pkg, HYPRE_Int num_components_in, HYPRE_Int vecstride,
+                                             HYPRE_Int idxstride)
+{
+   const HYPRE_Int nc = pkg->num_components > 0 ? pkg->num_components : 1;
+   if (num_components_in < 1) { hypre_error_in_arg(2); return hypre_error_flag; }
+   if (num_components_in == nc) { return hypre_error_flag; }
+   const HYPRE_Int ns = pkg->num_sends, nr = pkg->num_recvs;
+   const HYPRE_Int tot = pkg->send_map_starts[ns];                 // in units of the current component count
+   HYPRE_Int *elmts_new = hypre_CTAlloc(HYPRE_Int, (size_t) std::max(tot / nc * num_components_in, 1), HYPRE_MEMORY_HOST);
+   const HYPRE_Int entries = tot / nc;
+   for (HYPRE_Int i = 0; i < entries; i++)
+   {
+      if (num_components_in > nc)
+      {
+         // growing always starts from the single-vector list (as the reference: index * idxstride + j * vecstride)
+         for (HYPRE_Int j = 0; j < num_components_in; j++)
+         {
+            elmts_new[(size_t) i * num_components_in + j] = pkg->send_map_elmts[(size_t) i * nc] * idxstride + j * vecstride;
+         }
+      }
+      else
+      {
+         for (HYPRE_Int j = 0; j < num_components_in; j++)
+         {
+            elmts_new[(size_t) i * num_components_in + j] = pkg->send_map_elmts[(size_t) i * nc + j];
+         }
+      }
+   }
+   hypre_Free(pkg->send_map_elmts, HYPRE_MEMORY_HOST);
+   pkg->send_map_elmts = elmts_new;
+   hypre_Free(pkg->device_send_map_elmts, HYPRE_MEMORY_DEVICE);
+   pkg->device_send_map_elmts = nullptr;
+   hypre_Free(pkg->tmp_data, HYPRE_MEMORY_DEVICE); pkg->tmp_data = nullptr;
+   hypre_Free(pkg->buf_data, HYPRE_MEMORY_DEVICE); pkg->buf_data = nullptr;
+   // matrix_E is kept: it is defined in single-vector terms (ensure_matrix_E), whatever the component count
+   for (HYPRE_Int i = 0; i <= ns; i++) { pkg->send_map_starts[i] = pkg->send_map_starts[i] / nc * num_components_in; }
+   for (HYPRE_Int i = 0; i <= nr; i++) { pkg->recv_vec_starts[i] = pkg->recv_vec_starts[i] / nc * num_components_in; }
+   pkg->num_components = num_components_in;
    return hypre_error_flag;
 }
 
@@ -577,6 +624,20 @@ HYPRE_Int hypre_ParCSRCommHandleDestroy(hypre_ParCSRCommHandle *h)
    return hypre_error_flag;
 }
 
+// grow-only device scratch of the multivector products (two independent buffers)
+static double *mv_scratch(size_t n, int which)
+{
+   static double *buf[2] = {nullptr, nullptr};
+   static size_t len[2] = {0, 0};
+   if (len[which] < n)
+   {
+      if (buf[which]) { hypre_Free(buf[which], HYPRE_MEMORY_DEVICE); }
+      buf[which] = hypre_TAlloc(double, n, HYPRE_MEMORY_DEVICE);
+      len[which] = n;
+   }
+   return buf[which];
+}
+
 // device work space of a package (allocated on first use, never in the hot loop)
 static void ensure_pkg_device(hypre_ParCSRCommPkg *pkg, HYPRE_Int num_cols_offd)
 {
@@ -588,7 +649,35 @@ static void ensure_pkg_device(hypre_ParCSRCommPkg *pkg, HYPRE_Int num_cols_offd)
                     HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
    }
    if (!pkg->buf_data && tot_send) { pkg->buf_data = hypre_TAlloc(HYPRE_Complex, tot_send, HYPRE_MEMORY_DEVICE); }
-   if (!pkg->tmp_data && num_cols_offd) { pkg->tmp_data = hypre_TAlloc(HYPRE_Complex, num_cols_offd, HYPRE_MEMORY_DEVICE); }
+   const size_t ghosts = (size_t) num_cols_offd * (size_t) std::max(pkg->num_components, 1);
+   if (!pkg->tmp_data && ghosts) { pkg->tmp_data = hypre_TAlloc(HYPRE_Complex, ghosts, HYPRE_MEMORY_DEVICE); }
+}
+
+// The unpack operator of the transpose product (the reference's matrix_E, par_csr_matvec_device.c:470-560): the
+// num_rows x tot_send 0/1 matrix with a one at (send_map_elmts[i], i), kept as a device CSR matrix with its non-empty
+// rows listed, so that  y += E * buf  adds every row's contributions in ONE fixed order (ascending position in the
+// receive buffer) — an atomicAdd per received value would add them in whatever order the lanes happen to run.
+static hypre_CSRMatrix *ensure_matrix_E(hypre_ParCSRCommPkg *pkg, HYPRE_Int num_rows)
+{
+   if (pkg->matrix_E && pkg->matrix_E->num_rows == num_rows) { return pkg->matrix_E; }
+   if (pkg->matrix_E) { hypre_CSRMatrixDestroy(pkg->matrix_E); pkg->matrix_E = nullptr; }
+   // always in single-vector terms: entry i of the lists is component 0 of slot i * num_components
+   const HYPRE_Int nc = std::max(pkg->num_components, 1);
+   const HYPRE_Int tot = pkg->send_map_starts[pkg->num_sends] / nc;
+   hypre_CSRMatrix *E = hypre_CSRMatrixCreate(num_rows, tot, tot);
+   hypre_CSRMatrixInitialize_v2(E, 0, HYPRE_MEMORY_HOST);
+   for (HYPRE_Int i = 0; i < tot; i++) { E->i[pkg->send_map_elmts[(size_t) i * nc] + 1]++; }
+   for (HYPRE_Int r = 0; r < num_rows; r++) { E->i[r + 1] += E->i[r]; }
+   std::vector<HYPRE_Int> pos(E->i, E->i + num_rows);
+   for (HYPRE_Int i = 0; i < tot; i++)
+   {
+      const HYPRE_Int q = pos[(size_t) pkg->send_map_elmts[(size_t) i * nc]]++;
+      E->j[q] = i; E->data[q] = 1.0;
+   }
+   hypre_CSRMatrixSetRownnz(E);
+   hypre_CSRMatrixMigrate(E, HYPRE_MEMORY_DEVICE);
+   pkg->matrix_E = E;
+   return E;
 }
 
 }  // extern "C"
@@ -643,15 +732,48 @@ HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlaceDevice(HYPRE_Complex alpha, hypre_Pa
       }
       const int saved = handle().sync_compute;
       handle().sync_compute = 0;
+      HYPRE_Int np;
+      hypre_MPI_Comm_size(A->comm, &np);
+      if (np > 1 && !A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      hypre_ParCSRCommPkg *pkg = np > 1 ? A->comm_pkg : nullptr;
+      const HYPRE_Int nco = offd->num_cols;
+      hypre_ParCSRCommHandle *ch = nullptr;
+      if (pkg && (pkg->num_sends || pkg->num_recvs))
+      {
+         // ONE halo exchange for all columns (par_csr_matvec.c:89-160): the package is switched to nv components, the
+         // send buffer holds [entry][column], the ghost data arrives in the same shape and is put column by column
+         hypre_ParCSRCommPkgUpdateVecStarts(pkg, nv, xl->vecstride, xl->idxstride);
+         ensure_pkg_device(pkg, nco);
+         const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
+         launch_gather(xl->data, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
+         ch = hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data, HYPRE_MEMORY_DEVICE, pkg->tmp_data);
+      }
       for (HYPRE_Int v = 0; v < nv; v++)
       {
          hypre_Vector xv = *xl, bv = *bl, yv = *yl;
          xv.data += (size_t) v * xl->vecstride; xv.num_vectors = 1;
          bv.data += (size_t) v * bl->vecstride; bv.num_vectors = 1;
          yv.data += (size_t) v * yl->vecstride; yv.num_vectors = 1;
-         hypre_ParVector xp = *x, bp = *b, yp = *y;
-         xp.local_vector = &xv; bp.local_vector = &bv; yp.local_vector = &yv;
-         hypre_ParCSRMatrixMatvecOutOfPlaceDevice(alpha, A, &xp, beta, b == y ? &yp : &bp, &yp);
+         hypre_CSRMatrixMatvecDevice(0, alpha, diag, &xv, beta, b == y ? &yv : &bv, &yv, 0);
+      }
+      if (ch)
+      {
+         hypre_ParCSRCommHandleDestroy(ch);
+         if (nco > 0)
+         {
+            double *cols = mv_scratch((size_t) nco * (size_t) nv, 0);
+            launch_deinterleave(pkg->tmp_data, cols, nco, nv, stream());
+            for (HYPRE_Int v = 0; v < nv; v++)
+            {
+               hypre_Vector gv{}, yv = *yl;
+               gv.data = cols + (size_t) v * nco; gv.size = nco; gv.num_vectors = 1; gv.vecstride = nco; gv.idxstride = 1;
+               gv.memory_location = HYPRE_MEMORY_DEVICE;
+               yv.data += (size_t) v * yl->vecstride; yv.num_vectors = 1;
+               hypre_CSRMatrixMatvecDevice(0, alpha, offd, &gv, 1.0, &yv, &yv, 0);
+            }
+         }
+         HIP_CHECK(hipStreamSynchronize(stream()));          // the buffers go away with the switch back
+         hypre_ParCSRCommPkgUpdateVecStarts(pkg, 1, xl->vecstride, xl->idxstride);
       }
       handle().sync_compute = saved;
       maybe_sync();
@@ -740,14 +862,60 @@ HYPRE_Int hypre_ParCSRMatrixMatvecTDevice(HYPRE_Complex alpha, hypre_ParCSRMatri
       }
       const int saved = handle().sync_compute;
       handle().sync_compute = 0;
+      HYPRE_Int np;
+      hypre_MPI_Comm_size(A->comm, &np);
+      if (np > 1 && !A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+      hypre_ParCSRCommPkg *pkg = np > 1 ? A->comm_pkg : nullptr;
+      const HYPRE_Int nco = offd->num_cols;
+      hypre_ParCSRCommHandle *ch = nullptr;
+      hypre_CSRMatrix *E = nullptr;
+      HYPRE_Int entries = 0;
+      auto column = [](hypre_Vector *l, HYPRE_Int v) { hypre_Vector c = *l; c.data += (size_t) v * l->vecstride; c.num_vectors = 1; return c; };
+      if (pkg && (pkg->num_sends || pkg->num_recvs))
+      {
+         // ghost-row contributions of all columns travel back in ONE reverse exchange
+         entries = pkg->send_map_starts[pkg->num_sends] / std::max(pkg->num_components, 1);
+         if (entries > 0) { E = ensure_matrix_E(pkg, diag->num_cols); }
+         hypre_ParCSRCommPkgUpdateVecStarts(pkg, nv, yl->vecstride, yl->idxstride);
+         ensure_pkg_device(pkg, nco);
+         if (nco > 0)
+         {
+            double *cols = mv_scratch((size_t) nco * (size_t) nv, 0);
+            for (HYPRE_Int v = 0; v < nv; v++)
+            {
+               hypre_Vector xv = column(xl, v), gv{};
+               gv.data = cols + (size_t) v * nco; gv.size = nco; gv.num_vectors = 1; gv.vecstride = nco; gv.idxstride = 1;
+               gv.memory_location = HYPRE_MEMORY_DEVICE;
+               if (A->offdT) { hypre_CSRMatrixMatvecDevice(0, alpha, A->offdT, &xv, 0.0, &gv, &gv, 0); }
+               else          { hypre_CSRMatrixMatvecDevice(1, alpha, offd, &xv, 0.0, &gv, &gv, 0); }
+            }
+            launch_interleave(cols, pkg->tmp_data, nco, nv, stream());
+         }
+         ch = hypre_ParCSRCommHandleCreate_v2(2, pkg, HYPRE_MEMORY_DEVICE, pkg->tmp_data, HYPRE_MEMORY_DEVICE, pkg->buf_data);
+      }
       for (HYPRE_Int v = 0; v < nv; v++)
       {
-         hypre_Vector xv = *xl, yv = *yl;
-         xv.data += (size_t) v * xl->vecstride; xv.num_vectors = 1;
-         yv.data += (size_t) v * yl->vecstride; yv.num_vectors = 1;
-         hypre_ParVector xp = *x, yp = *y;
-         xp.local_vector = &xv; yp.local_vector = &yv;
-         hypre_ParCSRMatrixMatvecTDevice(alpha, A, &xp, beta, &yp);
+         hypre_Vector xv = column(xl, v), yv = column(yl, v);
+         if (A->diagT) { hypre_CSRMatrixMatvecDevice(0, alpha, A->diagT, &xv, beta, &yv, &yv, 0); }
+         else          { hypre_CSRMatrixMatvecDevice(1, alpha, diag, &xv, beta, &yv, &yv, 0); }
+      }
+      if (ch)
+      {
+         hypre_ParCSRCommHandleDestroy(ch);
+         if (entries > 0)
+         {
+            double *recv = mv_scratch((size_t) entries * (size_t) nv, 1);
+            launch_deinterleave(pkg->buf_data, recv, entries, nv, stream());
+            for (HYPRE_Int v = 0; v < nv; v++)
+            {
+               hypre_Vector bv{}, yv = column(yl, v);
+               bv.data = recv + (size_t) v * entries; bv.size = entries; bv.num_vectors = 1; bv.vecstride = entries; bv.idxstride = 1;
+               bv.memory_location = HYPRE_MEMORY_DEVICE;
+               hypre_CSRMatrixMatvecDevice(0, 1.0, E, &bv, 1.0, &yv, &yv, 0);
+            }
+         }
+         HIP_CHECK(hipStreamSynchronize(stream()));
+         hypre_ParCSRCommPkgUpdateVecStarts(pkg, 1, yl->vecstride, yl->idxstride);
       }
       handle().sync_compute = saved;
       maybe_sync();
@@ -787,7 +955,18 @@ HYPRE_Int hypre_ParCSRMatrixMatvecTDevice(HYPRE_Complex alpha, hypre_ParCSRMatri
    {
       hypre_ParCSRCommHandleDestroy(ch);
       const HYPRE_Int tot_send = pkg->send_map_starts[pkg->num_sends];
-      launch_scatter_add(pkg->buf_data, pkg->device_send_map_elmts, yl->data, (size_t) tot_send, stream());
+      if (tot_send > 0)
+      {
+         // y += E * buf: every boundary row sums what its neighbours sent in a fixed order
+         hypre_CSRMatrix *E = ensure_matrix_E(pkg, diag->num_cols);
+         hypre_Vector bufv{};
+         bufv.data = pkg->buf_data; bufv.size = tot_send; bufv.num_vectors = 1; bufv.vecstride = tot_send; bufv.idxstride = 1;
+         bufv.memory_location = HYPRE_MEMORY_DEVICE;
+         const bool mp = handle().fp32_values;
+         handle().fp32_values = false;                  // E holds exact ones; nothing to gain from an fp32 copy
+         hypre_CSRMatrixMatvecDevice(0, 1.0, E, &bufv, 1.0, yl, yl, 0);
+         handle().fp32_values = mp;
+      }
    }
    handle().sync_compute = saved_sync;
    maybe_sync();

@@ -20,7 +20,8 @@ using namespace hamd;
 // ===========================================================================
 namespace hamd {
 
-// kernel variant of the tiled family (hypre_amd_SpmvSetVariant, or HYPRE_AMD_SPMV_VARIANT / HYPRE_AMD_SPMV_PIPE_WGS read once)
+// kernel variant of the tiled family (hypre_amd_SpmvSetVariant, or HYPRE_AMD_SPMV_VARIANT read once): 2 = x staged through
+// LDS (spmv_xs_kernel; plans carry the chunk lists), 0 = x gathered through the cache (spmv_tiled_kernel)
 struct SpmvVariant { int variant, pipe_wgs; };
 static SpmvVariant &spmv_variant()
 {
@@ -28,7 +29,7 @@ static SpmvVariant &spmv_variant()
    if (v.variant < 0)
    {
       const char *e = getenv("HYPRE_AMD_SPMV_VARIANT");
-      v.variant = e ? atoi(e) : 0;
+      v.variant = e ? atoi(e) : 2;
       if ((e = getenv("HYPRE_AMD_SPMV_PIPE_WGS"))) { v.pipe_wgs = atoi(e); }
    }
    return v;
@@ -135,6 +136,9 @@ static void free_plan(SpmvPlan *p)
    if (p->d_tile_row) { HIP_CHECK(hipFree(p->d_tile_row)); }
    if (p->d_tile_k) { HIP_CHECK(hipFree(p->d_tile_k)); }
    if (p->d_tile_perm) { HIP_CHECK(hipFree(p->d_tile_perm)); }
+   if (p->d_xs_cnt) { HIP_CHECK(hipFree(p->d_xs_cnt)); }
+   if (p->d_xs_desc) { HIP_CHECK(hipFree(p->d_xs_desc)); }
+   if (p->d_lidx) { HIP_CHECK(hipFree(p->d_lidx)); }
    if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
    if (p->Lstrict) { hypre_CSRMatrixDestroy(p->Lstrict); }
@@ -142,10 +146,12 @@ static void free_plan(SpmvPlan *p)
 }
 
 void drop_gs_schedule(const hypre_CSRMatrix *A);    // par_relax_gs.cpp
+void drop_mc_plan(const hypre_CSRMatrix *A);        // par_relax_mc.cpp
 
 void drop_plan(hypre_CSRMatrix *A)
 {
    drop_gs_schedule(A);
+   drop_mc_plan(A);
    auto &t = plan_table();
    auto it = t.find(A);
    if (it != t.end())
@@ -188,6 +194,16 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
          launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
          p->max_tile_rows = device_max_row_nnz(p->d_tile_row, p->num_tiles, s);     // max over tiles of tile_row[b+1] - tile_row[b]
          build_band_placement(p, A, s);
+         if (spmv_variant().variant == 2)
+         {
+            // x staging: segment lists and local column indices (one pass over the column array, device side)
+            const size_t nl = ((size_t) A->num_nonzeros + 15) & ~(size_t) 7;
+            HIP_CHECK(hipMalloc((void **) &p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles));
+            HIP_CHECK(hipMalloc((void **) &p->d_xs_desc, sizeof(int) * (size_t) p->num_tiles * 2 * SPMV_XS_SEGS));
+            HIP_CHECK(hipMalloc((void **) &p->d_lidx, sizeof(unsigned short) * nl));
+            HIP_CHECK(hipMemsetAsync(p->d_lidx, 0, sizeof(unsigned short) * nl, s));
+            launch_build_xs(A->j, p->d_tile_k, p->num_tiles, p->d_xs_cnt, p->d_xs_desc, p->d_lidx, s);
+         }
       }
    }
    t[A] = p;
@@ -254,8 +270,8 @@ extern "C" HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int mi
    return hypre_error_flag;
 }
 
-// Kernel variant of the tiled SpMV family from now on: 0 = one workgroup per tile, 1 = persistent software-pipelined
-// workgroups, `pipe_wgs` of them per CU (0: leave; < 0: a grid of 8 * |pipe_wgs| workgroups whatever the device).  Speed only; same results up to nothing (same summation order).
+// Kernel variant of the tiled SpMV family from now on: 2 = x staged through LDS (plans built from now on carry the
+// chunk lists), 0 = x gathered through the cache.  Speed only: same products, same summation order.
 extern "C" HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int pipe_wgs)
 {
    hamd::SpmvVariant &v = hamd::spmv_variant();
@@ -272,6 +288,25 @@ extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanInfo(hypre_CSRMatrix *A, HYPRE_Int *
    if (num_tiles) { *num_tiles = p->tiled ? p->num_tiles : 0; }
    if (band) { *band = p->band; }
    return p->d_tile_perm != nullptr;
+}
+
+// x staging of A's plan (built on demand): returns the number of tiles whose columns fit the staging area (they take
+// the LDS path of spmv_xs_kernel, the others gather), fills the tile count and the mean number of pieces per staged tile
+extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanStaging(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Real *mean_pieces)
+{
+   if (num_tiles) { *num_tiles = 0; }
+   if (mean_pieces) { *mean_pieces = 0.0; }
+   if (A->memory_location != HYPRE_MEMORY_DEVICE) { return 0; }
+   hamd::SpmvPlan *p = hamd::get_plan(A);
+   if (!p->tiled || !p->d_xs_cnt) { return 0; }
+   std::vector<int> cnt((size_t) p->num_tiles);
+   HIP_CHECK(hipStreamSynchronize(hamd::stream()));
+   HIP_CHECK(hipMemcpy(cnt.data(), p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles, hipMemcpyDeviceToHost));
+   long long staged = 0, pieces = 0;
+   for (int c : cnt) { if (c > 0) { staged++; pieces += c; } }
+   if (num_tiles) { *num_tiles = p->num_tiles; }
+   if (mean_pieces && staged) { *mean_pieces = (double) pieces / (double) staged; }
+   return (HYPRE_Int) staged;
 }
 
 extern "C" HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A)
@@ -412,6 +447,18 @@ HYPRE_Int hypre_CSRMatrixTranspose(hypre_CSRMatrix *A, hypre_CSRMatrix **AT_ptr,
 {
    const HYPRE_MemoryLocation loc = A->memory_location;
    const HYPRE_Int nr = A->num_rows, nc = A->num_cols, nnz = A->num_nonzeros;
+   if (loc == HYPRE_MEMORY_DEVICE)
+   {
+      // device matrices are transposed where they are (count / scan / scatter / order: kernels.hip), same result
+      hypre_CSRMatrix *AT = hypre_CSRMatrixCreate(nc, nr, nnz);
+      const bool with_data = data && A->data;
+      hypre_CSRMatrixInitialize_v2(AT, 0, loc);
+      if (!with_data && AT->data) { hypre_Free(AT->data, loc); AT->data = nullptr; }
+      launch_transpose(A->i, A->j, with_data ? A->data : nullptr, nr, nc, nnz, AT->i, AT->j, with_data ? AT->data : nullptr, stream());
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      *AT_ptr = AT;
+      return hypre_error_flag;
+   }
    std::vector<HYPRE_Int> hi, hj;
    std::vector<HYPRE_Complex> ha;
    const HYPRE_Int *Ai = A->i, *Aj = A->j;

@@ -29,6 +29,7 @@
 namespace hamd {
 
 typedef int    v4i __attribute__((ext_vector_type(4)));
+typedef int    v2i __attribute__((ext_vector_type(2)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef float  v4f __attribute__((ext_vector_type(4)));
 
@@ -64,6 +65,7 @@ struct RowOps
 {
    double b, d, x;
    int    m;
+   int    g;      // row of the vectors the epilogue reads and writes (= the matrix row unless a row map is given)
 };
 
 template <int OP>
@@ -71,6 +73,8 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
 {
    RowOps o;
    o.b = 0.0; o.d = 1.0; o.x = 0.0; o.m = 0;
+   if (p.rowmap) { row = p.rowmap[row]; }
+   o.g = row;
    if (OP == OP_AXPBY) { if (p.beta != 0.0) { o.b = p.b[row]; } }
    else if (OP == OP_TSGS) { o.d = p.d[row]; }
    else
@@ -82,8 +86,9 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
 }
 
 template <int OP>
-__device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int row, double sum, const RowOps &o)
+__device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum, const RowOps &o)
 {
+   const int row = o.g;
    if (OP == OP_AXPBY)
    {
       // y = alpha*(A x) + beta*b
@@ -471,199 +476,343 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
 }
 
 // ---------------------------------------------------------------------------
-// Persistent, software-pipelined form of the tiled kernel.
+// x-staged form of the tiled kernel.
 //
-// One workgroup per tile leaves the matrix stream idle for most of a tile's life: a tile is a chain of dependent
-// round trips (stream -> column gathers -> reduction -> store) and only the first of them moves matrix bytes.  Here a
-// workgroup walks over tiles vb, vb + gridDim, ... and requests the (col, val) quads of the NEXT tile right after it
-// has issued the gathers of the current one, so the stream of tile i + 1 is in flight while tile i gathers, reduces and
-// stores.  Order matters: a wave's vector-memory results return in issue order and are waited for by count
-// (s_waitcnt vmcnt(N)), so the prefetch has to be issued AFTER the loads the current tile still waits for (gathers,
-// row pointers, epilogue operands); issued before them it would be waited for with them and nothing would overlap.
-// The next tile's bounds are wave-uniform scalar loads (own counter).
+// Measured on the 256^3 hierarchy (profiles/r02_*): with the x gathers taken out, the tiled kernel streams levels 0 / 1 / 2
+// at 6.2 / 5.6 / 5.7 TB/s; with them, at 5.4 / 4.1 / 3.3.  What the gathers cost is not their bytes (L2 hits) and not
+// their instructions (a first x-staged kernel that fetched per-tile chunk lists and then the chunks ran no faster): a
+// CU's vector-memory pipeline returns data in order, so a load that DEPENDS on an earlier load — a gather on its column
+// index, a chunk on its list entry — queues behind the HBM-bound matrix stream of the eight resident workgroups and
+// costs a whole second trip through it.  A tile's life is the number of such dependent trips, and with a fixed number
+// of resident tiles that sets the rate.
+//
+// So the x values a tile needs are fetched in the SAME trip as its matrix stream.  The plan records per tile up to 32
+// pieces of x, 128 doubles at most each, that cover the columns of its entries (a 2048-entry tile touches 850 - 1100
+// distinct columns in a handful of clusters: rows that are neighbours in the matrix share most of their columns), and
+// per entry a 16-bit index into the concatenation of those pieces.  The piece descriptors are wave-uniform and arrive
+// through the scalar cache (its own path, a few hundred ns); each wave then issues one 16-byte load per lane for each of
+// its eight pieces right behind the (value, index) stream loads, the copy lands in LDS, and the "gathers" are eight LDS
+// reads per lane.  The column array
+// is not read at all: 8 + 2 bytes per entry instead of 12.  Tiles whose columns do not fit 32 pieces / 2048 doubles
+// (restriction operators: a row of P^T reaches far) take the gather path of spmv_tiled_kernel inside the same launch.
+// The staged copy and the products share LDS.
+// Reference counterpart of the whole family: seq_mv/csr_spmv_device.c:35-260 (no LDS, gathers through the cache).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int map_tile(const SpmvArgs &p, int vb, int num_tiles)
-{
-   int tile = vb;
-   if (p.tile_perm) { tile = vb < num_tiles ? p.tile_perm[vb] : -1; }
-   else if (p.xcd_map > 0)
-   {
-      const int g = vb >> 3, c = vb & 7, C = p.xcd_map;
-      tile = (g / C) * (8 * C) + c * C + (g % C);
-   }
-   else if (p.xcd_map < 0) { tile = (vb & 7) * ((num_tiles + 7) >> 3) + (vb >> 3); }
-   return ((unsigned) tile < (unsigned) num_tiles) ? tile : -1;
-}
-
-// Reduction + epilogue of the pipelined kernel's one-lane-per-row path with the epilogue operands of the first three
-// passes (rows tid, tid + 256, tid + 512 of the tile) fetched by the caller BEFORE the next tile's stream was requested:
-// a load issued here would be waited for together with that prefetch.
-template <int OP, bool HASFILL>
-__device__ __forceinline__ void tile_reduce_pipe(const SpmvArgs &p, int r0, int nrows, int k0, int k1, int ka,
-                                                 const double *prod, double *rowsum, const int *rp, int rp_cap,
-                                                 const RowOps &ops0, const RowOps &ops1, const RowOps &ops2)
-{
-   const int tid = threadIdx.x;
-   const int avg = (k1 - k0) / nrows;
-   if (avg > 12) { tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops0); return; }
-   for (int rr = tid, pass = 0; rr < nrows; rr += SPMV_THREADS, pass++)
-   {
-      const int row = r0 + rr;
-      const int s = (rr     <= rp_cap) ? rp[rr]     : p.Ai[row];
-      const int e = (rr + 1 <= rp_cap) ? rp[rr + 1] : p.Ai[row + 1];
-      double sum = 0.0;
-      for (int k = s; k < e; k++)
-      {
-         double t = prod[k - ka];
-         if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-         sum += t;
-      }
-      if (pass == 0)      { row_epilogue<OP>(p, row, sum, ops0); }
-      else if (pass == 1) { row_epilogue<OP>(p, row, sum, ops1); }
-      else if (pass == 2) { row_epilogue<OP>(p, row, sum, ops2); }
-      else { const RowOps o = load_row_ops<OP>(p, row); row_epilogue<OP>(p, row, sum, o); }
-   }
-}
-
-// epilogue operands of row r0 + tid + pass * SPMV_THREADS, clamped into the tile so the loads are unconditional
-template <int OP>
-__device__ __forceinline__ RowOps tile_row_ops_pass(const SpmvArgs &p, int r0, int nrows, int pass)
-{
-   const int rr = min((int) threadIdx.x + pass * SPMV_THREADS, nrows - 1);
-   return load_row_ops<OP>(p, max(r0 + rr, 0));
-}
+constexpr int XS_SEGS  = SPMV_XS_SEGS;      // segments per tile: 4 waves x 8
+constexpr int XS_CAP   = SPMV_TILE;         // doubles a tile may stage (= the product area)
+constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first column of every segment, then (offset << 16 | length)
 
 template <int OP, bool F32, bool HASFILL>
 __global__ __launch_bounds__(SPMV_THREADS)
-void spmv_pipe_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
-                      int num_tiles, int padded_tiles, int prod_elems, int rowsum_elems, int rp_cap)
+void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
+                    const int *__restrict__ xs_cnt, const int *__restrict__ xs_desc,
+                    const unsigned short *__restrict__ lidx,
+                    int num_tiles, int prod_elems, int rowsum_elems, int rp_cap)
 {
    extern __shared__ __align__(16) unsigned char smem_raw[];
-   double *prod   = reinterpret_cast<double *>(smem_raw);
+   double *prod   = reinterpret_cast<double *>(smem_raw);     // staged x first, products after the second barrier
    double *rowsum = prod + prod_elems;
    int    *rp     = reinterpret_cast<int *>(rowsum + rowsum_elems);
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-   const int G = (int) gridDim.x;
-   const unsigned x_last = (unsigned) p.x_last;
-   constexpr int RPJ = (RP_CAP + SPMV_THREADS) / SPMV_THREADS;
 
-   // first tile of this workgroup (padding slots of the placement map hold none)
-   int vb = (int) blockIdx.x, tile = -1;
-   for (; vb < padded_tiles; vb += G) { tile = map_tile(p, vb, num_tiles); if (tile >= 0) { break; } }
-   if (tile < 0) { return; }
-   TileStream S;
-   int r0 = tile_row[tile], r1 = tile_row[tile + 1], k0 = tile_k[tile], k1 = tile_k[tile + 1];
-   stream_issue<F32>(p, tile * SPMV_TILE, 0x7fffffff, S);
-   stream_issue_spill<F32>(p, tile * SPMV_TILE, k1, S);
-
-   while (true)
+   int tile = (int) blockIdx.x;
+   if (p.tile_perm)
    {
-      const int ka = tile * SPMV_TILE;
-      const int nrows = r1 - r0;
-      // The tile after this one and its bounds (wave-uniform scalar loads, needed only when its spill is requested below).
-      // None: the prefetch re-reads this tile, which costs nothing worth a branch — every vector load between the gathers
-      // and the product stores is unconditional, so that the compiler can count (s_waitcnt vmcnt(N)) exactly the loads
-      // this tile waits for and leave the prefetch in flight.
-      int ntile = -1;
-      for (vb += G; vb < padded_tiles; vb += G) { ntile = map_tile(p, vb, num_tiles); if (ntile >= 0) { break; } }
-      const int ptile = ntile >= 0 ? ntile : tile;
-      const int nr0 = tile_row[ptile], nr1 = tile_row[ptile + 1], nk0 = tile_k[ptile], nk1 = tile_k[ptile + 1];
+      if (tile >= num_tiles) { return; }
+      tile = p.tile_perm[tile];
+   }
+   else if (p.xcd_map > 0)
+   {
+      const int g = blockIdx.x >> 3, c = blockIdx.x & 7, C = p.xcd_map;
+      tile = (g / C) * (8 * C) + c * C + (g % C);
+   }
+   else if (p.xcd_map < 0) { tile = (blockIdx.x & 7) * ((num_tiles + 7) >> 3) + (blockIdx.x >> 3); }
+   if ((unsigned) tile >= (unsigned) num_tiles) { return; }
 
-      TileStream N;
-      if (nrows > 0)
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const int ka = tile * SPMV_TILE;
+   // values and local indices of the tile's window, requested before anything about the tile is known
+   TileStream S;
+   const int kA = ka + 4 * tid, kB = kA + 4 * SPMV_THREADS;
+   const int qA = min(kA, p.last_quad), qB = min(kB, p.last_quad);
+   if (F32)
+   {
+      S.fA = stream_load<v4f>(p.Aa32 + qA);
+      S.fB = stream_load<v4f>(p.Aa32 + qB);
+   }
+   else
+   {
+      S.vA01 = stream_load<v2d>(p.Aa + qA); S.vA23 = stream_load<v2d>(p.Aa + qA + 2);
+      S.vB01 = stream_load<v2d>(p.Aa + qB); S.vB23 = stream_load<v2d>(p.Aa + qB + 2);
+   }
+   const v2i lA = stream_load<v2i>(lidx + qA), lB = stream_load<v2i>(lidx + qB);
+
+   // wave-uniform: bounds and this wave's eight segment descriptors (scalar loads)
+   const int r0 = tile_row[tile], r1 = tile_row[tile + 1];
+   if (r1 <= r0) { return; }
+   const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
+   const int nrows = r1 - r0;
+   const int nseg = xs_cnt[tile];
+
+   if (nseg == 0)
+   {
+      // this tile's columns do not fit the staging area: gathers through the cache, as spmv_tiled_kernel
+      S.cA = stream_load<v4i>(p.Aj + qA);
+      S.cB = stream_load<v4i>(p.Aj + qB);
+      stream_issue_spill<F32>(p, ka, k1, S);
+#pragma unroll
+      for (int j = 0; j < (RP_CAP + SPMV_THREADS) / SPMV_THREADS; j++)
       {
-         // row pointers (to LDS further down: nothing needs them before the reduction) and the epilogue operands
-         const int lim = min(nrows, rp_cap);
-         int rpv[RPJ];
-#pragma unroll
-         for (int j = 0; j < RPJ; j++) { rpv[j] = p.Ai[r0 + min(tid + j * SPMV_THREADS, lim)]; }
-         const RowOps ops0 = tile_row_ops_pass<OP>(p, r0, nrows, 0);
-         const RowOps ops1 = tile_row_ops_pass<OP>(p, r0, nrows, 1);
-         const RowOps ops2 = tile_row_ops_pass<OP>(p, r0, nrows, 2);
-
-         // columns through the wave's own LDS slice -> 2 x 4 gathers of 64 consecutive entries each.  Slots outside
-         // [k0, k1) hold entries of neighbouring tiles or, in the matrix's last quad, no entry at all: their columns
-         // are clamped into x (one v_min each, no branch) and their products are never read.
-         double *chunk0 = prod + 256 * wave, *chunk1 = prod + 4 * SPMV_THREADS + 256 * wave;
-         int *ci0 = reinterpret_cast<int *>(chunk0), *ci1 = reinterpret_cast<int *>(chunk1);
-         *reinterpret_cast<v4i *>(ci0 + 4 * lane) = S.cA;
-         *reinterpret_cast<v4i *>(ci1 + 4 * lane) = S.cB;
-         __builtin_amdgcn_wave_barrier();
-         const unsigned a0 = min((unsigned) ci0[lane],       x_last), a1 = min((unsigned) ci0[64 + lane],  x_last);
-         const unsigned a2 = min((unsigned) ci0[128 + lane], x_last), a3 = min((unsigned) ci0[192 + lane], x_last);
-         const unsigned b0 = min((unsigned) ci1[lane],       x_last), b1 = min((unsigned) ci1[64 + lane],  x_last);
-         const unsigned b2 = min((unsigned) ci1[128 + lane], x_last), b3 = min((unsigned) ci1[192 + lane], x_last);
-         const int kC = ka + 8 * SPMV_THREADS + tid;
-         const double xa0 = p.x[a0], xa1 = p.x[a1], xa2 = p.x[a2], xa3 = p.x[a3];
-         const double xb0 = p.x[b0], xb1 = p.x[b1], xb2 = p.x[b2], xb3 = p.x[b3];
-         const double xC = p.x[min((unsigned) S.cC, x_last)];
-
-         // everything this tile still waits for has been requested: now the next tile's stream (the scheduler must not
-         // move a load of this tile behind it: results return in issue order)
-         __builtin_amdgcn_sched_barrier(0);
-         stream_issue<F32>(p, ptile * SPMV_TILE, 0x7fffffff, N);
-         stream_issue_spill<F32>(p, ptile * SPMV_TILE, nk1, N);
-         __builtin_amdgcn_sched_barrier(0);
-
-         {
-            const int lim2 = lim;
-#pragma unroll
-            for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim2)] = rpv[j]; }
-         }
-         __builtin_amdgcn_wave_barrier();
-         chunk0[lane] = xa0; chunk0[64 + lane] = xa1; chunk0[128 + lane] = xa2; chunk0[192 + lane] = xa3;
-         chunk1[lane] = xb0; chunk1[64 + lane] = xb1; chunk1[128 + lane] = xb2; chunk1[192 + lane] = xb3;
-         __builtin_amdgcn_wave_barrier();
-         {
-            const v2d xa = *reinterpret_cast<const v2d *>(chunk0 + 4 * lane);
-            const v2d xb = *reinterpret_cast<const v2d *>(chunk0 + 4 * lane + 2);
-            const v2d ya = *reinterpret_cast<const v2d *>(chunk1 + 4 * lane);
-            const v2d yb = *reinterpret_cast<const v2d *>(chunk1 + 4 * lane + 2);
-            v2d lo0, hi0, lo1, hi1;
-            if (F32)
-            {
-               lo0.x = (double) S.fA.x * xa.x; lo0.y = (double) S.fA.y * xa.y; hi0.x = (double) S.fA.z * xb.x; hi0.y = (double) S.fA.w * xb.y;
-               lo1.x = (double) S.fB.x * ya.x; lo1.y = (double) S.fB.y * ya.y; hi1.x = (double) S.fB.z * yb.x; hi1.y = (double) S.fB.w * yb.y;
-            }
-            else
-            {
-               lo0 = S.vA01 * xa; hi0 = S.vA23 * xb; lo1 = S.vB01 * ya; hi1 = S.vB23 * yb;
-            }
-            *reinterpret_cast<v2d *>(chunk0 + 4 * lane)     = lo0;
-            *reinterpret_cast<v2d *>(chunk0 + 4 * lane + 2) = hi0;
-            *reinterpret_cast<v2d *>(chunk1 + 4 * lane)     = lo1;
-            *reinterpret_cast<v2d *>(chunk1 + 4 * lane + 2) = hi1;
-         }
-         if (kC < k1) { prod[kC - ka] = S.vC * xC; }
-         // tail of a tile whose last row runs past the spill entries as well (rare; waits for the prefetch too)
-         for (int k = ka + 9 * SPMV_THREADS + 4 * tid; k < k1; k += 4 * SPMV_THREADS)
-         {
-            const v4i c = stream_load<v4i>(p.Aj + k);
-            double v0, v1, v2, v3;
-            if (F32) { const v4f f = stream_load<v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
-            else
-            {
-               const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
-               v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
-            }
-            double *dst = prod + (k - ka);
-            if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
-            if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
-            if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
-            if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
-         }
-         __syncthreads();
-         tile_reduce_pipe<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops0, ops1, ops2);
+         const int t = tid + j * SPMV_THREADS;
+         if (t <= nrows && t <= rp_cap) { rp[t] = p.Ai[r0 + t]; }
       }
+      const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
+      stream_consume_gt<F32>(p, k0, k1, ka, S, prod);
+      __syncthreads();
+      tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
+      return;
+   }
+
+   const int *dsc = xs_desc + (size_t) tile * XS_DESC + 8 * wave;
+   int seg_start[8], seg_ol[8];
+#pragma unroll
+   for (int j = 0; j < 8; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
+
+   // x pieces (at most 128 doubles each: one 16-byte load per lane), requested in the same trip through the memory
+   // pipeline as the stream above and written straight into LDS (global_load_lds: no registers, no ds_write pass; the
+   // LDS address is the piece's base + 16 * lane, which is exactly how a piece is laid out)
+#pragma unroll
+   for (int j = 0; j < 8; j++)
+   {
+      const int c = seg_start[j] + 2 * lane, off = seg_ol[j] >> 16, len = seg_ol[j] & 0xffff;
+      if (2 * lane < len)
+      {
+         if (c + 1 <= p.x_last)
+         {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + c),
+                                             (__attribute__((address_space(3))) void *) (prod + off), 16, 0, 0);
+         }
+         else { prod[off + 2 * lane] = p.x[min(c, p.x_last)]; prod[off + 2 * lane + 1] = 0.0; }     // x ends inside this pair
+      }
+   }
+   // spill of the tile's last row past the window (one entry per lane), row pointers, epilogue operands: same trip
+   const int kC = ka + 8 * SPMV_THREADS + tid;
+   const int qC = kC < k1 ? kC : min(ka + 8 * SPMV_THREADS, p.last_quad);
+   const unsigned lC = lidx[qC];
+   S.vC = F32 ? (double) p.Aa32[qC] : p.Aa[qC];
+   constexpr int RPJ = (RP_CAP + SPMV_THREADS) / SPMV_THREADS;
+   const int lim = min(nrows, rp_cap);
+   int rpv[RPJ];
+#pragma unroll
+   for (int j = 0; j < RPJ; j++) { rpv[j] = p.Ai[r0 + min(tid + j * SPMV_THREADS, lim)]; }
+   const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
+   // lanes past the tile's rows repeat its last pointer into the last slot
+#pragma unroll
+   for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
+   __syncthreads();
+
+   // "gathers": eight LDS reads per lane.  Entries of the window that belong to a neighbouring tile carry that tile's
+   // numbering: any index below the staging capacity reads initialised-or-not LDS and the product is never used.
+   const double xa0 = prod[lA.x & 0xffff], xa1 = prod[(unsigned) lA.x >> 16], xa2 = prod[lA.y & 0xffff], xa3 = prod[(unsigned) lA.y >> 16];
+   const double xb0 = prod[lB.x & 0xffff], xb1 = prod[(unsigned) lB.x >> 16], xb2 = prod[lB.y & 0xffff], xb3 = prod[(unsigned) lB.y >> 16];
+   const double xC = prod[lC];
+   v2d lo0, hi0, lo1, hi1;
+   if (F32)
+   {
+      lo0.x = (double) S.fA.x * xa0; lo0.y = (double) S.fA.y * xa1; hi0.x = (double) S.fA.z * xa2; hi0.y = (double) S.fA.w * xa3;
+      lo1.x = (double) S.fB.x * xb0; lo1.y = (double) S.fB.y * xb1; hi1.x = (double) S.fB.z * xb2; hi1.y = (double) S.fB.w * xb3;
+   }
+   else
+   {
+      lo0.x = S.vA01.x * xa0; lo0.y = S.vA01.y * xa1; hi0.x = S.vA23.x * xa2; hi0.y = S.vA23.y * xa3;
+      lo1.x = S.vB01.x * xb0; lo1.y = S.vB01.y * xb1; hi1.x = S.vB23.x * xb2; hi1.y = S.vB23.y * xb3;
+   }
+   const double pC = S.vC * xC;
+   __syncthreads();               // every lane has read its x values: the products may overwrite the staged copy
+   *reinterpret_cast<v2d *>(prod + (kA - ka))     = lo0;
+   *reinterpret_cast<v2d *>(prod + (kA - ka) + 2) = hi0;
+   *reinterpret_cast<v2d *>(prod + (kB - ka))     = lo1;
+   *reinterpret_cast<v2d *>(prod + (kB - ka) + 2) = hi1;
+   if (kC < k1) { prod[kC - ka] = pC; }
+   // entries past the spill (a last row longer than 256 + what is left of the window): their x comes through the cache
+   for (int k = ka + 9 * SPMV_THREADS + 4 * tid; k < k1; k += 4 * SPMV_THREADS)
+   {
+      const v4i c = stream_load<v4i>(p.Aj + k);
+      double v0, v1, v2, v3;
+      if (F32) { const v4f f = stream_load<v4f>(p.Aa32 + k); v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w; }
       else
       {
-         stream_issue<F32>(p, ptile * SPMV_TILE, 0x7fffffff, N);
-         stream_issue_spill<F32>(p, ptile * SPMV_TILE, nk1, N);
+         const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
+         v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
       }
-      if (ntile < 0) { break; }
-      __syncthreads();          // the next tile overwrites rp[], prod[] and rowsum[]
-      S = N;
-      tile = ntile; r0 = nr0; r1 = nr1; k0 = nk0; k1 = nk1;
+      double *dst = prod + (k - ka);
+      if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
+      if (k + 1 < k1) { dst[1] = v1 * p.x[c.y]; }
+      if (k + 2 < k1) { dst[2] = v2 * p.x[c.z]; }
+      if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
+   }
+   __syncthreads();
+   tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
+}
+
+// ---- plan construction: per tile, the segments of x its entries touch and per entry the index of its column in
+// their concatenation.  One workgroup per tile.  Columns are handled in units of two (16 bytes of x): sort the units
+// (bitonic, LDS), keep the distinct ones, cut where the gap to the next unit exceeds a threshold T — the smallest power
+// of two that leaves at most 32 segments — and give up on the tile if the segments hold more than the staging capacity.
+constexpr int XS_SORT  = 4096;              // >= SPMV_TILE + SPMV_MAXROW entries of a tile, power of two
+constexpr int XS_UNITS = XS_CAP / 2;        // distinct 2-column units a staged tile can hold at most
+__global__ __launch_bounds__(SPMV_THREADS)
+void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k, int num_tiles,
+                     int *__restrict__ xs_cnt, int *__restrict__ xs_desc, unsigned short *__restrict__ lidx)
+{
+   __shared__ int key[XS_SORT];
+   __shared__ int uniq[XS_UNITS + 1];       // distinct units, ascending
+   __shared__ int pos[XS_UNITS + 1];        // staged position (in units) of every distinct unit
+   __shared__ int part[SPMV_THREADS];
+   __shared__ int red[2];
+   const int tile = blockIdx.x, tid = threadIdx.x;
+   const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
+   const int m = k1 - k0;
+   int *desc = xs_desc + (size_t) tile * XS_DESC;
+   for (int i = tid; i < XS_DESC; i += SPMV_THREADS) { desc[i] = 0; }
+   if (m <= 0 || m > XS_SORT) { if (tid == 0) { xs_cnt[tile] = 0; } return; }
+   for (int i = tid; i < XS_SORT; i += SPMV_THREADS) { key[i] = i < m ? (Aj[k0 + i] >> 1) : 0x7fffffff; }
+   __syncthreads();
+   for (int k = 2; k <= XS_SORT; k <<= 1)
+   {
+      for (int j = k >> 1; j > 0; j >>= 1)
+      {
+         for (int i = tid; i < XS_SORT; i += SPMV_THREADS)
+         {
+            const int l = i ^ j;
+            if (l > i)
+            {
+               const int a = key[i], b = key[l];
+               const bool up = (i & k) == 0;
+               if ((a > b) == up) { key[i] = b; key[l] = a; }
+            }
+         }
+         __syncthreads();
+      }
+   }
+   // block-wide exclusive scan of one value per lane (part[] in, part[] out inclusive; returns the total)
+   auto scan = [&](int mine) -> int
+   {
+      part[tid] = mine;
+      __syncthreads();
+      for (int off = 1; off < SPMV_THREADS; off <<= 1)
+      {
+         const int v = tid >= off ? part[tid - off] : 0;
+         __syncthreads();
+         part[tid] += v;
+         __syncthreads();
+      }
+      return part[SPMV_THREADS - 1];
+   };
+   // distinct units, in order: every lane scans 16 consecutive slots
+   constexpr int PER = XS_SORT / SPMV_THREADS;
+   int heads = 0;
+   for (int i = tid * PER; i < (tid + 1) * PER; i++)
+   {
+      if (key[i] != 0x7fffffff && (i == 0 || key[i] != key[i - 1])) { heads++; }
+   }
+   const int U = scan(heads);
+   if (U > XS_UNITS) { if (tid == 0) { xs_cnt[tile] = 0; } return; }
+   {
+      int r = part[tid] - heads;
+      for (int i = tid * PER; i < (tid + 1) * PER; i++)
+      {
+         if (key[i] != 0x7fffffff && (i == 0 || key[i] != key[i - 1])) { uniq[r++] = key[i]; }
+      }
+   }
+   __syncthreads();
+   // Cut threshold T in {0, 1, 2, 4, ...}: a gap of more than T units between two distinct units ends a segment; a
+   // segment is staged in pieces of at most XS_PIECE units.  The smallest T whose pieces fit the descriptor table wins
+   // (the covered length grows with T; once it exceeds the staging capacity the tile is given up).
+   constexpr int UPER = (XS_UNITS + SPMV_THREADS - 1) / SPMV_THREADS;
+   constexpr int XS_PIECE = 64;                 // units (2 doubles) per piece: one 16-byte load per lane of a wave
+   int T = 0, npieces = 0;
+   bool fits = false;
+   for (int step = 0; step < 24; step++)
+   {
+      // staged position of unit i = uniq[i] - uniq[0] - (sum of the cut gaps before it); a lane owns UPER consecutive units
+      int cut = 0;
+      for (int i = tid * UPER; i < (tid + 1) * UPER && i < U - 1; i++) { const int g = uniq[i + 1] - uniq[i] - 1; if (g > T) { cut += g; } }
+      const int cut_total = scan(cut);
+      const int covered = uniq[U - 1] - uniq[0] + 1 - cut_total;
+      {
+         int before = part[tid] - cut;           // cut gaps in front of this lane's first unit
+         for (int i = tid * UPER; i < (tid + 1) * UPER && i < U; i++)
+         {
+            pos[i] = uniq[i] - uniq[0] - before;
+            if (i < U - 1) { const int g = uniq[i + 1] - uniq[i] - 1; if (g > T) { before += g; } }
+         }
+      }
+      __syncthreads();
+      if (covered > XS_UNITS) { break; }
+      int np = 0;
+      for (int i = tid * UPER; i < (tid + 1) * UPER && i < U; i++)
+      {
+         if (i == 0 || uniq[i] - uniq[i - 1] - 1 > T)
+         {
+            int e = i + 1;
+            while (e < U && uniq[e] - uniq[e - 1] - 1 <= T) { e++; }
+            np += (pos[e - 1] - pos[i] + XS_PIECE) / XS_PIECE;      // ceil(length / XS_PIECE)
+         }
+      }
+      npieces = scan(np);
+      __syncthreads();
+      if (npieces <= XS_SEGS) { fits = true; break; }
+      T = T == 0 ? 1 : 2 * T;
+   }
+   if (!fits) { if (tid == 0) { xs_cnt[tile] = 0; } return; }
+   // descriptors: part[] still holds the inclusive scan of the pieces per lane
+   {
+      int np = 0;
+      for (int i = tid * UPER; i < (tid + 1) * UPER && i < U; i++)
+      {
+         if (i == 0 || uniq[i] - uniq[i - 1] - 1 > T)
+         {
+            int e = i + 1;
+            while (e < U && uniq[e] - uniq[e - 1] - 1 <= T) { e++; }
+            np += (pos[e - 1] - pos[i] + XS_PIECE) / XS_PIECE;
+         }
+      }
+      int pidx = part[tid] - np;
+      for (int i = tid * UPER; i < (tid + 1) * UPER && i < U; i++)
+      {
+         if (i == 0 || uniq[i] - uniq[i - 1] - 1 > T)
+         {
+            int e = i + 1;
+            while (e < U && uniq[e] - uniq[e - 1] - 1 <= T) { e++; }
+            const int len_units = pos[e - 1] - pos[i] + 1;
+            for (int o = 0; o < len_units; o += XS_PIECE)
+            {
+               const int slot = (pidx & 3) * 8 + (pidx >> 2);        // pieces dealt to the four waves, a wave's eight contiguous
+               desc[slot] = 2 * (uniq[i] + o);
+               desc[XS_SEGS + slot] = ((2 * (pos[i] + o)) << 16) | (2 * min(XS_PIECE, len_units - o));
+               pidx++;
+            }
+         }
+      }
+   }
+   const int nseg = npieces;
+   if (tid == 0) { xs_cnt[tile] = nseg; red[0] = 0; }
+   for (int i = tid; i < m; i += SPMV_THREADS)
+   {
+      const int col = Aj[k0 + i], q = col >> 1;
+      int lo = 0, hi = U - 1;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (uniq[mid] < q) { lo = mid + 1; } else { hi = mid; } }
+      lidx[k0 + i] = (unsigned short) (2 * pos[lo] + (col & 1));
+   }
+}
+
+void launch_build_xs(const HYPRE_Int *Aj, const int *d_tile_k, int num_tiles, int *xs_cnt, int *xs_desc, unsigned short *lidx,
+                     hipStream_t s)
+{
+   if (num_tiles > 0)
+   {
+      hipLaunchKernelGGL(build_xs_kernel, dim3(num_tiles), dim3(SPMV_THREADS), 0, s, Aj, d_tile_k, num_tiles, xs_cnt, xs_desc, lidx);
    }
 }
 
@@ -832,26 +981,26 @@ static void launch_tiled_gt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t
 }
 
 template <int OP, bool F32, bool FILL>
-static void launch_pipe(const SpmvPlan *plan, const SpmvArgs &a, int grid, hipStream_t s)
+static void launch_xs(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
    int rowsum_elems, rp_cap;
    const size_t lds = tiled_lds_bytes(plan, rowsum_elems, rp_cap);
    const int unit = a.tile_perm ? 1 : (a.xcd_map > 0 ? 8 * a.xcd_map : 8);
-   const int padded = ((plan->num_tiles + unit - 1) / unit) * unit;
-   hipLaunchKernelGGL((spmv_pipe_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
-                      plan->d_tile_row, plan->d_tile_k, plan->num_tiles, padded, plan->prod_elems, rowsum_elems, rp_cap);
+   const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
+   hipLaunchKernelGGL((spmv_xs_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
+                      plan->d_tile_row, plan->d_tile_k, plan->d_xs_cnt, plan->d_xs_desc, plan->d_lidx,
+                      plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap);
 }
 
 template <int OP, bool F32, bool FILL>
 static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
-   // persistent pipelined kernel: only when every workgroup gets at least two tiles (otherwise there is nothing to
-   // prefetch); the grid is a multiple of 8 so that a workgroup's tiles all belong to its own XCD's share
-   if (a.variant == 1 && a.gather_t)
+   // x staged through LDS (variant 2, the default) when the plan carries the per-tile segment lists and x can be read in
+   // 16-byte pieces
+   if (a.variant == 2 && a.gather_t && plan->d_lidx && (((uintptr_t) a.x) & 15) == 0)
    {
-      // pipe_wgs > 0: workgroups per CU; < 0: the grid itself, in units of 8 workgroups (tests: small matrices)
-      const int grid = a.pipe_wgs < 0 ? -8 * a.pipe_wgs : (hamd::handle().num_cus * (a.pipe_wgs > 0 ? a.pipe_wgs : 4)) & ~7;
-      if (grid >= 8 && plan->num_tiles >= 2 * grid) { launch_pipe<OP, F32, FILL>(plan, a, grid, s); return; }
+      launch_xs<OP, F32, FILL>(plan, a, s);
+      return;
    }
    if (a.gather_t) { launch_tiled_gt<OP, F32, FILL, true>(plan, a, s); }
    else { launch_tiled_gt<OP, F32, FILL, false>(plan, a, s); }

@@ -341,6 +341,19 @@ HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMatrix *A, hyp
                                                       HYPRE_Real *l1_norms, hypre_ParVector *u,
                                                       hypre_ParVector *Vtemp, hypre_ParVector *Ztemp,
                                                       HYPRE_Int GS_order, HYPRE_Int Symm);
+/* Multicolour Gauss-Seidel, relax types 21 (colours ascending) and 22 (descending) of hypre_BoomerAMGRelax.  No
+ * counterpart in the reference (parcsr_ls/par_relax*.c knows no colouring): it is the hybrid Gauss-Seidel sweep of
+ * par_relax.c:691-945 (Jacobi across ranks, Gauss-Seidel inside a rank) on the colour-permuted local ordering, which
+ * the GPU can run one colour at a time.  `diag`: smoother diagonal (the l1_norms option-5 vector of relax 7 / 11 / 12)
+ * or NULL for the stored diagonal; Vtemp: local work vector (may be NULL on one rank); direction: +1 / -1. */
+HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f,
+                                                          HYPRE_Int *cf_marker, HYPRE_Int relax_points,
+                                                          HYPRE_Real relax_weight, HYPRE_Real *diag,
+                                                          hypre_ParVector *u, hypre_ParVector *Vtemp,
+                                                          HYPRE_Int direction);
+/* number of colours of A's diagonal block (greedy first-fit over the symmetrised pattern, built on demand);
+ * colors_out: host array of one colour per local row, or NULL */
+HYPRE_Int hypre_amd_ParCSRMatrixMultiColoring(hypre_ParCSRMatrix *A, HYPRE_Int *colors_out);
 HYPRE_Int hypre_GaussElimSetup(hypre_ParAMGData *amg_data, HYPRE_Int level, HYPRE_Int relax_type);
 HYPRE_Int hypre_GaussElimSolve(hypre_ParAMGData *amg_data, HYPRE_Int level, HYPRE_Int relax_type);
 HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre_ParVector **U_array);

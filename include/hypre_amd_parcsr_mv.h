@@ -59,7 +59,7 @@ typedef struct _hypre_ParCSRCommPkg
    /* device work space, allocated once per package */
    HYPRE_Complex    *tmp_data;                /* ghost vector (num_cols_offd)   */
    HYPRE_Complex    *buf_data;                /* packed send buffer              */
-   hypre_CSRMatrix  *matrix_E;                /* unused (reference: MatvecT unpack) */
+   hypre_CSRMatrix  *matrix_E;                /* MatvecT unpack operator: y += E * buf (device, built on demand) */
 } hypre_ParCSRCommPkg;
 
 #define hypre_ParCSRCommPkgComm(comm_pkg)               (comm_pkg -> comm)
@@ -191,6 +191,10 @@ HYPRE_Int hypre_ParVectorMigrate(hypre_ParVector *x, HYPRE_MemoryLocation memory
 /* ---- halo exchange ---- */
 HYPRE_Int hypre_MatvecCommPkgCreate(hypre_ParCSRMatrix *A);
 HYPRE_Int hypre_MatvecCommPkgDestroy(hypre_ParCSRCommPkg *comm_pkg);
+/* par_csr_communication.c:1054-1154: switch the package to multivectors of num_components_in columns (one exchange then
+ * carries every column) or back to single vectors */
+HYPRE_Int hypre_ParCSRCommPkgUpdateVecStarts(hypre_ParCSRCommPkg *comm_pkg, HYPRE_Int num_components_in,
+                                             HYPRE_Int vecstride, HYPRE_Int idxstride);
 HYPRE_Int hypre_ParCSRCommPkgCreate_core(MPI_Comm comm, HYPRE_BigInt *col_map_offd,
                                          HYPRE_BigInt first_col_diag, HYPRE_BigInt *col_starts,
                                          HYPRE_Int num_cols_diag, HYPRE_Int num_cols_offd,

@@ -137,10 +137,14 @@ HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A);
  * placement table, force != 0 also drops the minimum slab size so that small (test) matrices
  * take the code path of the benchmark sizes.  A negative argument leaves its field unchanged. */
 HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int min_tiles, HYPRE_Int force);
-/* Kernel variant of the tiled SpMV family (speed only): 0 one workgroup per 2048-entry tile, 1 persistent
- * workgroups (pipe_wgs per CU; pipe_wgs < 0: a grid of 8 * |pipe_wgs| workgroups) that prefetch the next tile's matrix
- * stream.  variant < 0 / pipe_wgs == 0: unchanged. */
+/* Kernel variant of the tiled SpMV family (speed only; results are the same bits): 2 (default) stages the x values a
+ * tile needs through LDS from per-tile chunk lists kept in the plan, 0 gathers x through the cache.  Takes effect for
+ * plans built afterwards (a plan built under 0 has no chunk lists and keeps gathering).  variant < 0: unchanged;
+ * the second argument is unused. */
 HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int pipe_wgs);
+/* x staging of the plan of the device matrix A: returns the number of tiles that take the LDS-staged path of the tiled
+ * kernel; fills the plan's tile count and the mean number of x pieces of a staged tile. */
+HYPRE_Int hypre_amd_CSRMatrixPlanStaging(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Real *mean_pieces);
 /* Returns 1 when the plan of the device matrix A carries a placement table; fills the tile
  * count of the plan and the band distance the table was built for (0: none). */
 HYPRE_Int hypre_amd_CSRMatrixPlanInfo(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Int *band);

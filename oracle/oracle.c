@@ -496,6 +496,55 @@ static void hybrid_gs_core(const ocsr *D, const ocsr *O, const double *f, const 
    }
 }
 
+/* Multicolour Gauss-Seidel (the product's relax 21 / 22; the reference has no colouring).  Statement of parity: the
+ * hybrid Gauss-Seidel sweep of par_relax.c:691-945 — ghost values frozen at the state the call started from, a
+ * sequential Gauss-Seidel sweep over the rank's own rows — with the rows of every rank visited in the order "colour,
+ * then row number" instead of row number (descending for direction < 0).  Because rows of one colour do not couple, that
+ * is the sweep a device runs one colour at a time.  colors: global array, each rank's own colouring of its diagonal
+ * block.  Row update:
+ *    u_i += w (f_i - sum_j a_ij u_j - sum_g o_ig u_g^old) / d_i
+ * with d the smoother diagonal handed in (l1, option 5 = a_ii with 0 -> 1) or the stored a_ii.  For w = 1 and d = a_ii
+ * this is hypre_HybridGaussSeidelNS (u_i = (f_i - sum_{j != i} ...) / a_ii) on the permuted system up to rounding
+ * (tests/test_oracle_basic.py checks exactly that against relax 3 / 4). */
+static const int *g_mc_colors = NULL;
+void oracle_set_multicolor(const int *colors) { g_mc_colors = colors; }
+
+static void multicolor_gs(const opar *A, const double *f, const int *cf_marker, int relax_points, double w,
+                          const double *l1, const int *colors, int direction, double *u, double **vext)
+{
+   for (int r = 0; r < A->nranks; r++)
+   {
+      const long long r0 = A->row_starts[r];
+      const ocsr *D = &A->diag[r], *O = &A->offd[r];
+      const int n = D->nrows;
+      const int *col = colors + r0;
+      int C = 0;
+      for (int i = 0; i < n; i++) { if (col[i] + 1 > C) { C = col[i] + 1; } }
+      /* rows by (colour, row): counting sort */
+      int *start = (int *) calloc((size_t) C + 1, sizeof(int));
+      int *order = (int *) malloc(sizeof(int) * (size_t) (n > 0 ? n : 1));
+      for (int i = 0; i < n; i++) { start[col[i] + 1]++; }
+      for (int c = 0; c < C; c++) { start[c + 1] += start[c]; }
+      for (int i = 0; i < n; i++) { order[start[col[i]]++] = i; }
+      double *ur = u + r0;
+      for (int q = 0; q < n; q++)
+      {
+         const int i = order[direction > 0 ? q : n - 1 - q];
+         if (relax_points != 0 && cf_marker[r0 + i] != relax_points) { continue; }
+         if (D->i[i + 1] == D->i[i]) { continue; }
+         const double d = l1 ? l1[r0 + i] : D->a[D->i[i]];
+         if (d == 0.0) { continue; }
+         /* the device's form of the same update: whole row sum (diagonal term included), then u_i += w (f_i - sum) / d;
+            with d = a_ii that is (1 - w) u_i + w (f_i - sum_{j != i}) / a_ii up to rounding */
+         double sum = 0.0;
+         for (int jj = D->i[i]; jj < D->i[i + 1]; jj++) { sum += D->a[jj] * ur[D->j[jj]]; }
+         if (O->ncols > 0) { for (int jj = O->i[i]; jj < O->i[i + 1]; jj++) { sum += O->a[jj] * vext[r][O->j[jj]]; } }
+         ur[i] += w * (f[r0 + i] - sum) / d;
+      }
+      free(start); free(order);
+   }
+}
+
 /* One call of hypre_BoomerAMGRelax (par_relax.c:24-173) on every virtual rank.
  * u, f, cf_marker, l1 are global arrays; vtemp is global work space.
  * all_zeros: in/out flag of u (par_vector.h all_zeros). Returns 0, or the
@@ -524,6 +573,15 @@ int oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax
    }
    long long ntot = A->row_starts[R];
 
+   if (relax_type == 21 || relax_type == 22)
+   {
+      if (!g_mc_colors) { err = -3; }
+      else { multicolor_gs(A, f, cf_marker, relax_points, w, l1, g_mc_colors, relax_type == 21 ? 1 : -1, u, vext); }
+      for (int r = 0; r < R; r++) { free(vext[r]); }
+      free(vext);
+      *all_zeros = 0;
+      return err;
+   }
    if (relax_type == 7 || (relax_type == 18 && relax_points == 0))
    {
       /* par_relax.c:1178-1254: Vtemp = w f - w A u (or w f when u is known zero); u += Vtemp ./ l1 */
@@ -831,6 +889,7 @@ int oracle_amg_cycle(const oamg *amg, double **F, double **U, int *u0_all_zeros)
       }
       const int *cf = amg->cf_marker ? amg->cf_marker[level] : NULL;
       const double *l1 = amg->l1_norms ? amg->l1_norms[level] : NULL;
+      g_mc_colors = amg->colors ? amg->colors[level] : NULL;
       for (int j = 0; j < num_sweep; j++)
       {
          int relax_points = 0;

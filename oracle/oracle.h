@@ -51,6 +51,9 @@ typedef struct
     * Krylov products).  NULL: A[0] serves both.  With A_outer set, a cycle from a guess that is not known to be zero
     * is applied in correction form: r = f - A_outer u (fp64), e = cycle(r) from zero, u += e. */
    opar     *A_outer;
+   /* multicolour Gauss-Seidel, relax 21 / 22 (the product's; no reference counterpart): per level, the colour of every
+    * row (each rank's colouring of its own diagonal block, concatenated), or NULL */
+   int     **colors;
 } oamg;
 
 /* OpenMP threads of the independent row loops (timed CPU baseline); results are
@@ -72,6 +75,7 @@ int    oracle_l1_norms(const opar *A, int option, const int *cf_marker, double *
 int    oracle_relax(const opar *A, const double *f, const int *cf_marker, int relax_type, int relax_points,
                     double w, double omega, const double *l1, double *u, double *vtemp, int num_threads,
                     int *all_zeros);
+void   oracle_set_multicolor(const int *colors);     /* colours the next oracle_relax(21 / 22) call uses */
 int    oracle_relax_if(const opar *A, const double *f, const int *cf_marker, int relax_type, int relax_order,
                        int cycle_param, double w, double omega, const double *l1, double *u, double *vtemp,
                        int num_threads, int *all_zeros);

@@ -35,7 +35,7 @@ class OAMG(C.Structure):
                 ("relax_order", C.c_int), ("user_relax_type", C.c_int), ("relax_weight", RealP),
                 ("omega", RealP), ("cycle_type", C.c_int), ("fcycle", C.c_int), ("num_threads", C.c_int),
                 ("cheby_order", C.c_int), ("cheby_scale", C.c_int), ("cheby_coefs", C.POINTER(RealP)),
-                ("cheby_ds", C.POINTER(RealP)), ("A_outer", C.POINTER(OPAR))]
+                ("cheby_ds", C.POINTER(RealP)), ("A_outer", C.POINTER(OPAR)), ("colors", C.POINTER(IntP))]
 
 
 def build():
@@ -76,6 +76,8 @@ def load():
     L.oracle_relax.restype = C.c_int
     L.oracle_relax.argtypes = [P(OPAR), RealP, IntP, C.c_int, C.c_int, C.c_double, C.c_double, RealP, RealP,
                                RealP, C.c_int, IntP]
+    L.oracle_set_multicolor.restype = None
+    L.oracle_set_multicolor.argtypes = [IntP]
     L.oracle_relax_if.restype = C.c_int
     L.oracle_relax_if.argtypes = [P(OPAR), RealP, IntP, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                   RealP, RealP, RealP, C.c_int, IntP]
@@ -177,7 +179,7 @@ class Amg:
 
     def __init__(self, A_levels, P_levels, cf_markers, l1_norms, num_grid_sweeps, grid_relax_type,
                  relax_order=0, relax_weight=None, omega=None, cycle_type=1, fcycle=0, num_threads=1,
-                 max_levels=25, user_relax_type=-1, grid_relax_points=None, cheby=None, A_outer=None):
+                 max_levels=25, user_relax_type=-1, grid_relax_points=None, cheby=None, A_outer=None, colors=None):
         """cheby: None or dict(order=, scale=, coefs=[per level array or None], ds=[per level array or None]).
         A_outer: the exact fine-level operator when A_levels hold fp32-rounded values (mixed precision)."""
         L = len(A_levels)
@@ -208,6 +210,12 @@ class Amg:
         if A_outer is not None:
             self._Ao = (OPAR * 1)(A_outer.c)
             self.c.A_outer = self._Ao
+        self.colors = None
+        if colors is not None:
+            # multicolour Gauss-Seidel (relax 21 / 22): colour of every row, per level
+            self.colors = [None if c is None else np.ascontiguousarray(c, dtype=np.int32) for c in colors]
+            self._colors = (IntP * L)(*[_ip(c) if c is not None else None for c in self.colors])
+            self.c.colors = self._colors
         if cheby is not None:
             self.cheby_coefs = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in cheby["coefs"]]
             self.cheby_ds = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in cheby["ds"]]
@@ -281,8 +289,12 @@ def l1_norms(A, option, cf_marker=None):
     return out, bad
 
 
-def relax(A, f, cf_marker, relax_type, relax_points, w, omega, l1, u, num_threads=1, all_zeros=False):
+def relax(A, f, cf_marker, relax_type, relax_points, w, omega, l1, u, num_threads=1, all_zeros=False, colors=None):
+    """colors: colour of every row, for the multicolour sweeps 21 / 22."""
     cf = None if cf_marker is None else np.ascontiguousarray(cf_marker, dtype=np.int32)
+    if colors is not None:
+        colors = np.ascontiguousarray(colors, dtype=np.int32)
+    load().oracle_set_multicolor(_ip(colors) if colors is not None else None)
     vtemp = np.zeros(max(A.nrows, 1))
     az = C.c_int(1 if all_zeros else 0)
     f = np.ascontiguousarray(f, dtype=np.float64)
@@ -397,9 +409,25 @@ def amg_from_solvers(solvers, num_threads=1, mixed_precision=False):
     om = np.array([d.omega[k] for k in range(nl)])
     cheby = _merge_cheby([_export_cheby(s, nl) for s in solvers])
     A_outer = par_from_handles([L.hypre_amd_BoomerAMGGetA(s, 0) for s in solvers]) if mixed_precision else None
+    colors = None
+    if any(t in (21, 22) for t in types):
+        colors = [np.concatenate([level_colors(L.hypre_amd_BoomerAMGGetA(s, l)) for s in solvers]) for l in range(nl)]
     return Amg(A_levels, P_levels, cfs, l1s, sweeps, types, relax_order=d.relax_order, relax_weight=rw, omega=om,
                cycle_type=d.cycle_type, fcycle=d.fcycle, num_threads=num_threads, max_levels=d.max_levels,
-               user_relax_type=d.user_relax_type, cheby=cheby, A_outer=A_outer)
+               user_relax_type=d.user_relax_type, cheby=cheby, A_outer=A_outer, colors=colors)
+
+
+def level_colors(handle):
+    """The product's colouring of one rank's diagonal block (device matrices only)."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    L = B.load_library()
+    h = handle if isinstance(handle, C.POINTER(B.ParCSRMatrix)) else C.cast(handle, C.POINTER(B.ParCSRMatrix))
+    n = h.contents.diag.contents.num_rows
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    L.hypre_amd_ParCSRMatrixMultiColoring(h, _ip(out))
+    B.check()
+    return out[:n]
 
 
 def export_par(h):
@@ -463,6 +491,9 @@ def export_solver(s):
     out["relax_order"], out["cycle_type"], out["fcycle"] = d.relax_order, d.cycle_type, d.fcycle
     out["max_levels"], out["user_relax_type"] = d.max_levels, d.user_relax_type
     out["cheby"] = _export_cheby(s, nl)
+    out["colors"] = None
+    if any(t in (21, 22) for t in out["types"]):
+        out["colors"] = [level_colors(L.hypre_amd_BoomerAMGGetA(s, l)) for l in range(nl)]
     return out
 
 
@@ -483,7 +514,8 @@ def amg_from_exports(parts, num_threads=1, mixed_precision=False):
     return Amg(A_levels, P_levels, cfs, l1s, p0["sweeps"], p0["types"], relax_order=p0["relax_order"],
                relax_weight=p0["rw"], omega=p0["om"], cycle_type=p0["cycle_type"], fcycle=p0["fcycle"],
                num_threads=num_threads, max_levels=p0["max_levels"], user_relax_type=p0["user_relax_type"],
-               cheby=_merge_cheby([p.get("cheby") for p in parts]), A_outer=A_outer)
+               cheby=_merge_cheby([p.get("cheby") for p in parts]), A_outer=A_outer,
+               colors=None if p0.get("colors") is None else [np.concatenate([p["colors"][l] for p in parts]) for l in range(nl)])
 
 
 class AmgDataView(C.Structure):

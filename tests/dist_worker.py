@@ -88,6 +88,38 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
         L.hypre_ParCSRMatrixMatvec(2.0, A, dxt, 0.0, dy)
         L.hypre_ParCSRMatrixMatvecT(1.0, A, dy, -0.5, dz)
         dot = L.hypre_ParVectorInnerProd(dxt, dy)
+        # the transpose product twice: its unpack adds the neighbours' contributions in a fixed order (y += E * buf), so the
+        # bits repeat
+        dz2 = B.parvec_from_numpy(np.ones(len(x)), comm=comm, global_size=nglob, first=first)
+        L.hypre_ParCSRMatrixMatvecT(1.0, A, dy, -0.5, dz2)
+        zt_repeat = bool(np.array_equal(B.parvec_to_numpy(dz), B.parvec_to_numpy(dz2)))
+        # multivectors (3 columns, stored column by column): every column through ONE halo exchange
+        # (hypre_ParCSRCommPkgUpdateVecStarts), compared below with the single-vector products
+        nloc, nv = len(x), 3
+        Xm = np.stack([xt * (k + 1.0) + 0.1 * k for k in range(nv)], axis=1)
+
+        def multivec(M):
+            pv = B.parvec_from_numpy(np.ascontiguousarray(M.T).ravel(), comm=comm, global_size=nglob * nv, first=first * nv)
+            pv.contents.global_size = nglob
+            pv.contents.partitioning[0], pv.contents.partitioning[1] = first, first + nloc
+            pv.contents.first_index, pv.contents.last_index = first, first + nloc - 1
+            pv.contents.actual_local_size = nloc * nv
+            v = pv.contents.local_vector.contents
+            v.size, v.num_vectors, v.vecstride, v.idxstride = nloc, nv, nloc, 1
+            return pv
+
+        def columns(pv):
+            v = pv.contents.local_vector.contents
+            return B.fetch(v.data, nloc * nv, np.float64, v.memory_location).reshape(nv, nloc).T.copy()
+
+        mx, my, mz = multivec(Xm), multivec(np.zeros((nloc, nv))), multivec(np.ones((nloc, nv)))
+        L.hypre_ParCSRMatrixMatvec(2.0, A, mx, 0.0, my)
+        L.hypre_ParCSRMatrixMatvecT(1.0, A, my, -0.5, mz)
+        B.check()
+        mv_y, mv_z = columns(my), columns(mz)
+        # ... and the package is back in single-vector shape
+        L.hypre_ParCSRMatrixMatvec(2.0, A, dxt, 0.0, dy)
+        B.check()
         if opt.solver == 0:
             L.HYPRE_BoomerAMGSolve(s, A, db, dx)
             its, rel = C.c_int(), C.c_double()
@@ -114,7 +146,8 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
         B.check()
         mine.update(replicated_level=int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)))
         mine.update(dev_its=its.value, dev_rel=rel.value, dev_x=B.parvec_to_numpy(dx), xt=xt,
-                    dev_y=B.parvec_to_numpy(dy), dev_z=B.parvec_to_numpy(dz), dev_dot=dot)
+                    dev_y=B.parvec_to_numpy(dy), dev_z=B.parvec_to_numpy(dz), dev_dot=dot, zt_repeat=zt_repeat,
+                    mv_x=Xm, mv_y=mv_y, mv_z=mv_z)
     parts = [None] * world if rank == 0 else None
     dist.gather_object(mine, parts, dst=0)
     if rank == 0:
@@ -150,6 +183,18 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             zd = np.concatenate([p["dev_z"] for p in parts])
             xd = np.concatenate([p["dev_x"] for p in parts])
             out.update(replicated_level=parts[0]["replicated_level"])
+            # multivector products, column by column, against the oracle
+            Xg = np.concatenate([p["mv_x"] for p in parts]); Yg = np.concatenate([p["mv_y"] for p in parts])
+            Zg = np.concatenate([p["mv_z"] for p in parts])
+            mv_err = 0.0
+            for k in range(Xg.shape[1]):
+                yk = np.zeros(n)
+                O.par_matvec(2.0, A0, Xg[:, k].copy(), 0.0, yk, yk)
+                zk = np.ones(n)
+                O.par_matvecT(1.0, A0, yk, -0.5, zk)
+                mv_err = max(mv_err, float(np.max(np.abs(Yg[:, k] - yk)) / np.max(np.abs(yk))),
+                             float(np.max(np.abs(Zg[:, k] - zk)) / np.max(np.abs(zk))))
+            out.update(mv_err=mv_err, matvecT_repeats=all(p["zt_repeat"] for p in parts))
             out.update(dev_iterations=parts[0]["dev_its"], dev_rel_resid=parts[0]["dev_rel"],
                        matvec_err=float(np.max(np.abs(yd - yr)) / np.max(np.abs(yr))),
                        matvecT_err=float(np.max(np.abs(zd - zr)) / np.max(np.abs(zr))),

@@ -15,20 +15,18 @@ from util import rand_vector
 
 pytestmark = pytest.mark.gpu
 
-DEFAULT_VARIANT, DEFAULT_PIPE_WGS = 0, 4      # what the library starts with (seq_mv.cpp: spmv_variant)
+DEFAULT_VARIANT = 2                           # what the library starts with (seq_mv.cpp: spmv_variant): x staged through LDS
 
 
-@pytest.fixture(params=["tile-per-workgroup", "pipelined"])
+@pytest.fixture(params=["x-staged", "x-gathered"])
 def forced_tables(gpu_lib, request):
-    """Placement tables forced on every matrix of at least 8 tiles, under both kernels of the tiled family: one
-    workgroup per tile, and the persistent software-pipelined one (here with a grid of 16 workgroups, so that matrices
-    of 32 tiles and more run through its prefetch loop)."""
+    """Placement tables forced on every matrix of at least 8 tiles, under both kernels of the tiled family: x staged
+    through LDS from the plan's chunk lists (the default) and x gathered through the cache."""
     gpu_lib.hypre_amd_SpmvSetBandPolicy(1, 8, 1)
-    if request.param == "pipelined":
-        gpu_lib.hypre_amd_SpmvSetVariant(1, -2)
+    gpu_lib.hypre_amd_SpmvSetVariant(2 if request.param == "x-staged" else 0, 0)
     yield gpu_lib
     gpu_lib.hypre_amd_SpmvSetBandPolicy(1, 2048, 0)
-    gpu_lib.hypre_amd_SpmvSetVariant(DEFAULT_VARIANT, DEFAULT_PIPE_WGS)
+    gpu_lib.hypre_amd_SpmvSetVariant(DEFAULT_VARIANT, 0)
 
 
 def _setup(lib, **kw):
@@ -180,12 +178,12 @@ def test_benchmark_class_cycle_matches_oracle_default_policy(gpu_lib, oracle, kw
     kw = dict(kw)
     mixed = kw.pop("mixed", False)
     gpu_lib.hypre_amd_SpmvSetBandPolicy(1, 2048, 0)
-    for variant in (0, 1):
-        gpu_lib.hypre_amd_SpmvSetVariant(variant, 4)
+    for variant in (2, 0):
+        gpu_lib.hypre_amd_SpmvSetVariant(variant, 0)
         try:
             assert _one_cycle(gpu_lib, oracle, mixed=mixed, coarsen_type=8, **kw) <= 1e-11, variant
         finally:
-            gpu_lib.hypre_amd_SpmvSetVariant(DEFAULT_VARIANT, DEFAULT_PIPE_WGS)
+            gpu_lib.hypre_amd_SpmvSetVariant(DEFAULT_VARIANT, 0)
 
 
 @pytest.mark.parametrize("kw", [

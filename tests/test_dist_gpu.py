@@ -59,6 +59,7 @@ def test_two_or_three_ranks_on_device(name):
     out = device_batch_result(name)
     exp = case["expect"]
     assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
+    assert out["mv_err"] < 1e-13 and out["matvecT_repeats"]
     assert out["dev_iterations"] == out["iterations"]
     assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
     assert out["x_err"] < 1e-9
@@ -140,6 +141,7 @@ def _baseline_result(name):
 def test_baseline_multi_rank_configs_on_device(name):
     out = _baseline_result(name)
     assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
+    assert out["mv_err"] < 1e-13 and out["matvecT_repeats"]
     assert out["dev_iterations"] == out["iterations"] and out["iterations"] > 3
     assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
     assert out["x_err"] < 1e-9

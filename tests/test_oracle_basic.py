@@ -72,3 +72,43 @@ def test_host_transpose_large_matrix_is_the_stable_counting_sort(lib):
     assert np.array_equal(ti, np.concatenate([[0], np.cumsum(np.bincount(cols.ravel(), minlength=nc))]).astype(np.int32))
     lib.hypre_CSRMatrixDestroy(hA)
     lib.hypre_CSRMatrixDestroy(hT)
+
+
+def test_multicolor_sweep_is_hybrid_gauss_seidel_on_the_colour_permuted_system(oracle):
+    """the reference has no multicolour Gauss-Seidel; the oracle's relax 21 / 22 are pinned to its
+    golden-pinned hybrid Gauss-Seidel sweeps (relax 3 forward, 4 backward): on P A P^T, with P the permutation that sorts
+    the rows by (colour, row), the sequential sweep visits the unknowns in the multicolour order."""
+    import scipy.sparse as sp
+    from util import laplace_3d, rand_vector
+    for stencil, dims in ((7, (7, 6, 5)), (27, (6, 5, 4))):
+        A = laplace_3d(*dims, stencil=stencil)
+        n = A.shape[0]
+        # greedy first-fit colouring in row order
+        colors = -np.ones(n, dtype=np.int32)
+        for i in range(n):
+            taken = {colors[j] for j in A.indices[A.indptr[i]:A.indptr[i + 1]] if j != i and colors[j] >= 0}
+            c = 0
+            while c in taken:
+                c += 1
+            colors[i] = c
+        assert colors.max() + 1 == (2 if stencil == 7 else 8)
+        order = np.lexsort((np.arange(n), colors))            # rows by (colour, row)
+        inv = np.empty(n, dtype=np.int64); inv[order] = np.arange(n)
+        # P A P^T with the diagonal entry first in every row (the relaxation loops rely on it)
+        rows, cols, vals = [], [], []
+        indptr = [0]
+        for pi in range(n):
+            i = order[pi]
+            js = A.indices[A.indptr[i]:A.indptr[i + 1]]; vs = A.data[A.indptr[i]:A.indptr[i + 1]]
+            k = list(js).index(i)
+            cols += [pi] + [inv[j] for q, j in enumerate(js) if q != k]
+            vals += [vs[k]] + [v for q, v in enumerate(vs) if q != k]
+            indptr.append(len(cols))
+        Ap = sp.csr_matrix((np.array(vals), np.array(cols, dtype=np.int32), np.array(indptr, dtype=np.int32)), shape=(n, n))
+        f, u0 = rand_vector(n, 3), rand_vector(n, 4)
+        for rt_mc, rt_gs in ((21, 3), (22, 4)):
+            u = u0.copy()
+            assert oracle.relax(oracle.Par.from_scipy_single(A), f, None, rt_mc, 0, 1.0, 1.0, None, u, colors=colors) == 0
+            up = u0[order].copy()
+            assert oracle.relax(oracle.Par.from_scipy_single(Ap), f[order].copy(), None, rt_gs, 0, 1.0, 1.0, None, up) == 0
+            assert np.max(np.abs(u[order] - up)) <= 1e-13 * np.max(np.abs(up)), (stencil, rt_mc)

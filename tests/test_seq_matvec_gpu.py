@@ -232,3 +232,63 @@ def test_last_row_spills_past_the_streamed_window(gpu_lib, oracle, total):
     A = sp.csr_matrix((vals, cols, indptr), shape=(len(lens), ncols))
     _run(gpu_lib, oracle, A, 1.0, 0.0, seed=total)
     _run(gpu_lib, oracle, A, -0.7, 1.3, seed=total + 1)
+
+
+@pytest.mark.parametrize("shape,lo,hi,empty", [((900, 400), 1, 6, 0.0), ((5000, 700), 0, 4, 0.4), ((300, 3000), 20, 90, 0.0),
+                                               ((64, 64), 1, 3, 0.2), ((40, 5000), 1500, 3000, 0.0)])
+def test_device_transpose_is_the_host_transpose(gpu_lib, shape, lo, hi, empty):
+    """hypre_CSRMatrixTranspose of a device matrix runs on the device (count, scan, scatter, order: kernels.hip) and gives
+    what the host routine gives (seq_mv/csr_matop.c:1043-1270): row c of A^T lists the rows of A holding column c in
+    ascending order, values alongside — array for array."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = random_csr(shape[0], shape[1], lo, hi, seed=shape[0] + hi, empty_frac=empty)
+    dA, hA = B.csr_from_scipy(A), B.csr_from_scipy(A, B.HYPRE_MEMORY_HOST)
+    dT, hT = C.POINTER(B.CSRMatrix)(), C.POINTER(B.CSRMatrix)()
+    lib.hypre_CSRMatrixTranspose(dA, C.byref(dT), 1)
+    lib.hypre_CSRMatrixTranspose(hA, C.byref(hT), 1)
+    B.check()
+    assert dT.contents.memory_location == B.HYPRE_MEMORY_DEVICE and hT.contents.memory_location == B.HYPRE_MEMORY_HOST
+    for a, b in zip(B.csr_to_arrays(dT), B.csr_to_arrays(hT)):
+        assert np.array_equal(a, b)
+    # pattern only
+    dP = C.POINTER(B.CSRMatrix)()
+    lib.hypre_CSRMatrixTranspose(dA, C.byref(dP), 0)
+    B.check()
+    ii, jj, _ = B.csr_to_arrays(dP)
+    ri, rj, _ = B.csr_to_arrays(hT)
+    assert np.array_equal(ii, ri) and np.array_equal(jj, rj)
+    for m in (dA, hA, dT, hT, dP):
+        lib.hypre_CSRMatrixDestroy(m)
+
+
+def test_comm_pkg_update_vec_starts(gpu_lib):
+    """par_csr_communication.c:1054-1154 on a hand-made package: 1 -> 3 components and back."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    pkg = B.CommPkg()
+    starts = np.array([0, 2, 5], dtype=np.int32)
+    elmts = np.array([4, 7, 1, 2, 9], dtype=np.int32)
+    rstarts = np.array([0, 3, 4], dtype=np.int32)
+
+    def host_copy(a):
+        p = lib.hypre_CAlloc(len(a), 4, B.HYPRE_MEMORY_HOST)
+        C.memmove(p, a.ctypes.data, a.nbytes)
+        return C.cast(p, C.POINTER(C.c_int))
+
+    pkg.comm, pkg.num_components, pkg.num_sends, pkg.num_recvs = 0, 1, 2, 2
+    pkg.send_map_starts, pkg.send_map_elmts, pkg.recv_vec_starts = host_copy(starts), host_copy(elmts), host_copy(rstarts)
+    lib.hypre_ParCSRCommPkgUpdateVecStarts(C.byref(pkg), 3, 100, 1)
+    B.check()
+    assert pkg.num_components == 3
+    assert [pkg.send_map_starts[i] for i in range(3)] == [0, 6, 15]
+    assert [pkg.recv_vec_starts[i] for i in range(3)] == [0, 9, 12]
+    assert [pkg.send_map_elmts[i] for i in range(15)] == [e + 100 * j for e in elmts for j in range(3)]
+    lib.hypre_ParCSRCommPkgUpdateVecStarts(C.byref(pkg), 1, 100, 1)
+    B.check()
+    assert pkg.num_components == 1
+    assert [pkg.send_map_starts[i] for i in range(3)] == [0, 2, 5]
+    assert [pkg.recv_vec_starts[i] for i in range(3)] == [0, 3, 4]
+    assert [pkg.send_map_elmts[i] for i in range(5)] == list(elmts)

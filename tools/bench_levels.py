@@ -81,7 +81,17 @@ for l in range(min(nl, args.levels)):
     v = B.parvec_from_numpy(np.zeros(nr))
     l1p = L.hypre_amd_BoomerAMGGetL1Norms(s, l)
     l1 = C.cast(l1p, C.POINTER(B.Vector)).contents.data if l1p else None
-    print("L%d rows=%9d nnz=%10d (%.1f/row)" % (l, nr, nnz, nnz / max(nr, 1)), flush=True)
+    nt, mp = C.c_int(), C.c_double()
+    st = L.hypre_amd_CSRMatrixPlanStaging(Al.contents.diag, C.byref(nt), C.byref(mp))
+    print("L%d rows=%9d nnz=%10d (%.1f/row)  tiles %d, x-staged %d (%.1f pieces each)" % (l, nr, nnz, nnz / max(nr, 1), nt.value, st, mp.value), flush=True)
+    if l < nl - 1:
+        Pq = C.cast(L.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+        stp = L.hypre_amd_CSRMatrixPlanStaging(Pq.contents.diag, C.byref(nt), C.byref(mp))
+        line = "   P: tiles %d, x-staged %d (%.1f pieces)" % (nt.value, stp, mp.value)
+        if Pq.contents.diagT:
+            stt = L.hypre_amd_CSRMatrixPlanStaging(Pq.contents.diagT, C.byref(nt), C.byref(mp))
+            line += " | P^T: tiles %d, x-staged %d (%.1f pieces)" % (nt.value, stt, mp.value)
+        print(line, flush=True)
     for var, wgs in variants:
         L.hypre_amd_SpmvSetVariant(var, wgs)
         ms_a = timed(lambda: L.hypre_ParCSRMatrixMatvec(1.0, Al, x, 0.0, y))
