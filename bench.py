@@ -67,9 +67,10 @@ def proc_grid(n):
 
 
 def main():
-    # pin the OpenMP threads of the CPU baseline (must be in the environment before the OpenMP runtime starts)
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    # Host threads are deliberately NOT pinned: the box's share of its host is a CFS quota over all hardware threads (256
+    # visible, a quota of 16 cores' worth), not a set of cores, so binding to particular cores would only collide with
+    # the other tenants' bindings; and a bound master thread makes every later affinity query (the library's own thread
+    # count for the host setup) see one core.  The CPU baseline instead takes the median of five samples.
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,10 +179,12 @@ def main():
                 dist.all_reduce(torch.zeros(1))      # host-side barrier over gloo
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    warm = max(args.warmup, 2)                           # at least two: the coarse-tail graph is recorded on the second cycle
+    for _ in range(warm):
         step()
     fence()
     B.check()
+    L.hypre_amd_CommCounters(None, None, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -193,6 +196,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     B.check()
+    n_exch, n_allr = C.c_longlong(), C.c_longlong()
+    L.hypre_amd_CommCounters(C.byref(n_exch), C.byref(n_allr), 0)
+    g_level, g_nodes = C.c_int(), C.c_int()
+    L.hypre_amd_BoomerAMGGetGraphInfo(s, C.byref(g_level), C.byref(g_nodes))
     ms_per_step = 1e3 * elapsed / args.steps
     dof_per_s = nglob / (elapsed / args.steps)
 
@@ -246,11 +253,12 @@ def main():
     traffic = None
     traffic_src = None
     try:
-        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_spmv_pmc_summary.json"))
+        # newest per-level counter summary of the kernel in use (tools/pmc_levels.sh + pmc_levels_summary.py), level 0
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r02_levels_xs") and f.endswith("_summary.json"))
         if pmc_files:
             with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as fh:
-                pmc = json.load(fh)
-            if int(pmc.get("algorithmic_bytes_per_launch", -1)) == int(spmv_bytes):
+                pmc = json.load(fh)["levels"]["0"]
+            if int(pmc.get("algorithmic_bytes_per_launch", -1)) == int(spmv_bytes) and "hbm_traffic_bytes_per_launch" in pmc:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
                 traffic_src = "profiles/" + pmc_files[-1]
     except OSError:
@@ -277,8 +285,8 @@ def main():
 
         cores = max(1, min(len(os.sched_getaffinity(0)), args.cpu_threads))
         cpu_1 = cpu_cycles(1, args.cpu_cycles)
-        # threaded: median of 5 samples of 4 cycles each (threads pinned: OMP_PROC_BIND / OMP_PLACES set at start-up);
-        # run to run the mean of one long sample moved by +-25 % on the GPU box's shared host
+        # threaded: median of 5 samples of 4 cycles each (threads float, see main()); run to run the mean of one long
+        # sample moved by +-25 % on the GPU box's shared host
         samples = sorted(cpu_cycles(cores, 2 * args.cpu_cycles) for _ in range(5)) if cores > 1 else [cpu_1]
         cpu_s = samples[len(samples) // 2]
         O.set_num_threads(1)
@@ -289,9 +297,9 @@ def main():
         parity = float(np.max(np.abs(ug - ur)) / np.max(np.abs(ur)))
         cpu = {"value": nglob / cpu_s, "unit": "DOF/s", "cores": cores, "kind": "port",
                "sample": "median of %d samples of %d full V(1,1) cycles of the same %d^3 hierarchy (oracle/oracle.c, "
-                         "OpenMP row loops, %d threads, OMP_PROC_BIND=%s OMP_PLACES=%s)"
+                         "OpenMP row loops, %d threads, not pinned: OMP_PROC_BIND=%s, the host share is a CFS quota)"
                          % (len(samples), 2 * args.cpu_cycles if cores > 1 else args.cpu_cycles, n1, cores,
-                            os.environ.get("OMP_PROC_BIND"), os.environ.get("OMP_PLACES")),
+                            os.environ.get("OMP_PROC_BIND", "unset")),
                "samples_DOF_per_s": [nglob / t for t in samples],
                "single_thread_value": nglob / cpu_1,
                # the reference itself cannot run on the GPU box; what it did in the survey's container (8 cores), and the
@@ -313,7 +321,7 @@ def main():
         arith = "fp32 matrix values / fp64 vectors" if args.mixed else "fp64"
         out = {
             "metric": "BoomerAMG V-cycle DOF/s (%d^3 %s per GPU, %s V(1,1), %s)" % (n1, stencil, smoother, arith),
-            "value": dof_per_s, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": dof_per_s, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": warm,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%dx%d %s, %d rank(s) %dx%dx%d, PMIS + ext+i(4) + %s V(1,1)%s"
@@ -321,9 +329,11 @@ def main():
                                       ", fp32 matrix values in the cycle" if args.mixed else ""),
                        "transport": transport if world > 1 else "none",
                        "replicated_from_level": int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)),
+                       "halo_exchanges_per_cycle": n_exch.value / args.steps, "allreduces_per_cycle": n_allr.value / args.steps,
+                       "coarse_tail_graph_from_level": g_level.value, "coarse_tail_graph_nodes": g_nodes.value,
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s},
-            "roofline": {"bound": "hbm", "kernel": "spmv_tiled_kernel<AXPBY> (fine-level y = A x)",
+            "roofline": {"bound": "hbm", "kernel": "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS)",
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},

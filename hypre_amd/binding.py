@@ -160,6 +160,7 @@ PROTOTYPES = {
     "hypre_MPI_Comm_size": (Int, [Int, IntP]),
     "hypre_amd_CommSelfTest": (Int, [Int, Int]),
     "hypre_MPI_Barrier": (Int, [Int]),
+    "hypre_amd_CommCounters": (Int, [BigIntP, BigIntP, Int]),
     # seq_mv
     "hypre_CSRMatrixCreate": (CSRp, [Int, Int, Int]),
     "hypre_CSRMatrixInitialize_v2": (Int, [CSRp, Int, Int]),

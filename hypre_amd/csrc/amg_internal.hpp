@@ -27,6 +27,23 @@ struct AmgPrivate
    // to a non-zero iterate must work on the error equation, or the iteration converges to the rounded system's solution)
    hypre_ParVector *mp_r = nullptr, *mp_e = nullptr;
 
+   // Coarse tail of a single-rank V-cycle as one HIP graph.  From level graph_level down and back up every kernel is a
+   // few microseconds of work behind a launch that costs as much; the sub-cycle reads F[graph_level], writes U[graph_level]
+   // and touches only buffers the hierarchy owns, so its launches are recorded once (on the second cycle: the first one
+   // creates plans and scratch, which a capture cannot) and replayed as one graph.  A signature of everything the recorded
+   // launches depend on (options, weights, operator and vector addresses) is checked at every cycle; a mismatch drops
+   // the graph and records again.
+   int            graph_rows   = 100000;      // levels with at most this many rows belong to the tail (0: no graph)
+   int            graph_level  = -1;          // first level of the tail (>= 1), fixed when the first cycle runs
+   int            graph_state  = 0;           // 0: nothing yet, 1: warmed up (record next), 2: graph ready
+   unsigned long long graph_sig = 0;
+   hipGraph_t     graph        = nullptr;
+   hipGraphExec_t graph_exec   = nullptr;
+   std::vector<double *> graph_cur;           // where every tail level's iterate lives when the sub-cycle is over
+   double         graph_op_count = 0.0;       // what the sub-cycle adds to cycle_op_count
+   int            graph_launches = 0;         // kernel nodes of the graph (reported by the benchmark)
+   void drop_graph();
+
    // relax 15: one unpreconditioned-CG solver per level, created at the first cycle that needs it
    std::vector<HYPRE_Solver> cg_smoothers;
 

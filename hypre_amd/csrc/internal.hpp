@@ -117,7 +117,9 @@ struct SpmvPlan
    int            *d_xs_cnt = nullptr;
    int            *d_xs_desc = nullptr;
    unsigned short *d_lidx   = nullptr;
-   int             xs_tiles = 0;       // tiles with a chunk list
+   int             xs_tiles = 0;       // tiles with a piece list
+   int             xs_max_units = 0;   // longest staged copy of any tile, in 2-column units
+   int             xs_launch_units = 0;  // what a launch stages at most (tiles above it gather): sizes the launch's LDS
 };
 SpmvPlan *get_plan(hypre_CSRMatrix *A);
 hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A);   // device CSR of {a_ij : j < i}, cached in A's plan
@@ -152,6 +154,7 @@ struct SpmvArgs
    int                  row_offset;
    int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
    int                  x_last;      // num_cols - 1: largest valid index into x
+   int                  w8_max;      // tiles whose mean row length is at most this reduce with 8 lanes per row, longer ones with 32
    int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
    const int           *tile_perm;   // workgroup -> tile table (overrides xcd_map), or null
@@ -169,7 +172,8 @@ void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tile
                         int *d_tile_k, hipStream_t s);
 void launch_build_xs(const HYPRE_Int *Aj, const int *d_tile_k, int num_tiles, int *xs_cnt, int *xs_desc, unsigned short *lidx,
                      hipStream_t s);
-constexpr int SPMV_XS_SEGS = 32;     // column segments a staged tile may have
+constexpr int SPMV_XS_SEGS = 48;     // pieces of x (<= 128 doubles each) a staged tile may have
+constexpr int SPMV_XS_CAP  = 4096;   // doubles a tile may stage at most
 int  device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s);
 // largest |col - row| of `nsamples` evenly spaced rows, copied to the host (structure probe of the plan builder)
 void sample_row_bands(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int num_rows, int nsamples, int *host_out, hipStream_t s);
@@ -192,6 +196,10 @@ void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, h
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
 void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows, int ncols, int nnz, int *Ti, int *tj, double *ta,
                       hipStream_t s);     // device CSR transpose, rows of the result in ascending source-row order
+// Galerkin product R A P on the device, bit-identical to the host setup's (rap_kernels.hip); false: does not fit, use the host
+bool device_rap(int nc, int ncP, int maxP, const int *Ri, const int *Rj, const double *Ra, const int *Ai, const int *Aj,
+                const double *Aa, const int *Pi, const int *Pj, const double *Pa, int **Ci_out, int **Cj_out, double **Ca_out,
+                int *nnz_out, hipStream_t s);
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s);   // [entry][component] -> column by column
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s);
 void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s);

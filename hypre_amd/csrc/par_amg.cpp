@@ -337,6 +337,26 @@ HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver s, HYPRE_MemoryLocat
 { AMG_DATA(s, d); d->memory_location = loc; return hypre_error_flag; }
 HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver s, HYPRE_Int n)
 { AMG_DATA(s, d); ((AmgPrivate *) d->amd_private)->emulated_threads = n < 1 ? 1 : n; return hypre_error_flag; }
+// Coarse tail of the single-rank V-cycle as one HIP graph: levels with at most `rows` rows (0 switches the graph off;
+// default 100000).  Speed only.
+HYPRE_Int hypre_amd_BoomerAMGSetGraphThreshold(HYPRE_Solver s, HYPRE_Int rows)
+{
+   AMG_DATA(s, d);
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   pv->drop_graph();
+   pv->graph_level = -1;
+   pv->graph_rows = rows > 0 ? rows : 0;
+   return hypre_error_flag;
+}
+// first level of the graph (-1: none recorded) and the number of nodes it holds
+HYPRE_Int hypre_amd_BoomerAMGGetGraphInfo(HYPRE_Solver s, HYPRE_Int *level, HYPRE_Int *nodes)
+{
+   AMG_DATA(s, d);
+   AmgPrivate *pv = (AmgPrivate *) d->amd_private;
+   if (level) { *level = pv->graph_state == 2 ? pv->graph_level : -1; }
+   if (nodes) { *nodes = pv->graph_state == 2 ? pv->graph_launches : 0; }
+   return hypre_error_flag;
+}
 HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver s, HYPRE_Int on)
 { AMG_DATA(s, d); ((AmgPrivate *) d->amd_private)->mixed_precision = on != 0; return hypre_error_flag; }
 

@@ -1073,6 +1073,72 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
 }
 
 // ===========================================================================
+// Galerkin product on the device (rap_kernels.hip), for host operands of a single rank when a GPU is there: the
+// operands are uploaded, P is transposed on the device, the product is formed by one wave per coarse row in the host
+// loop's order — same columns, same order, same bits — and comes back to the host, where the next level's coarsening
+// still runs.  HYPRE_AMD_SETUP_DEVICE_RAP=0 keeps the host loop (tests compare the two).  Returns false when the
+// product was not formed here.
+// ===========================================================================
+// set by hypre_BoomerAMGSetup while it builds a hierarchy whose home is device memory
+static bool g_setup_targets_device = false;
+static int  g_device_rap_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_RAP"); return e ? atoi(e) : 1; }();
+static int  g_device_rap_min_rows = 20000;
+static int  g_device_rap_count = 0;          // products formed on the device since the last query
+
+// Galerkin products of single-rank setups whose hierarchy lives in device memory are formed on the device (same bits as
+// the host loop): on = 0 keeps the host loop, min_rows = smallest fine level worth the transfers (negative: unchanged).
+// Returns the number of products formed on the device since the previous call.
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows)
+{
+   if (on >= 0) { g_device_rap_on = on; }
+   if (min_rows >= 0) { g_device_rap_min_rows = min_rows; }
+   const int c = g_device_rap_count;
+   g_device_rap_count = 0;
+   return c;
+}
+static bool device_rap_allowed() { return g_setup_targets_device; }
+
+static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
+                                    HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr)
+{
+   if (!g_device_rap_on || !device_rap_allowed() || RT != P) { return false; }
+   if (A->diag->memory_location != HYPRE_MEMORY_HOST || P->diag->memory_location != HYPRE_MEMORY_HOST) { return false; }
+   const HYPRE_Int nf = A->diag->num_rows, nc = P->diag->num_cols;
+   if (nf < g_device_rap_min_rows || A->diag->num_nonzeros <= 0 || P->diag->num_nonzeros <= 0) { return false; }   // small levels: the host loop is quicker than the transfers
+   if (!ensure_device()) { return false; }
+   hipStream_t s = stream();
+   hypre_CSRMatrix *dA = hypre_CSRMatrixClone_v2(A->diag, 1, HYPRE_MEMORY_DEVICE);
+   hypre_CSRMatrix *dP = hypre_CSRMatrixClone_v2(P->diag, 1, HYPRE_MEMORY_DEVICE);
+   hypre_CSRMatrix *dR = nullptr;
+   hypre_CSRMatrixTranspose(dP, &dR, 1);            // device transpose: rows of R list the fine rows in ascending order, as the host's
+   int maxP = 0;
+   for (HYPRE_Int i = 0; i < nf; i++) { maxP = std::max(maxP, (int) (P->diag->i[i + 1] - P->diag->i[i])); }
+   int *Ci = nullptr, *Cj = nullptr, nnz = 0;
+   double *Ca = nullptr;
+   const bool ok = device_rap(nc, nc, maxP, dR->i, dR->j, dR->data, dA->i, dA->j, dA->data, dP->i, dP->j, dP->data, &Ci, &Cj, &Ca, &nnz, s);
+   hypre_CSRMatrixDestroy(dA);
+   hypre_CSRMatrixDestroy(dP);
+   if (!ok) { hypre_CSRMatrixDestroy(dR); return false; }
+   hypre_ParCSRMatrix *C = hypre_ParCSRMatrixCreate(A->comm, RT->global_num_cols, P->global_num_cols, RT->col_starts,
+                                                    P->col_starts, 0, nnz, 0);
+   hypre_ParCSRMatrixInitialize_v2(C, HYPRE_MEMORY_HOST);
+   hypre_TMemcpy(C->diag->i, Ci, HYPRE_Int, (size_t) nc + 1, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+   if (nnz > 0)
+   {
+      hypre_TMemcpy(C->diag->j, Cj, HYPRE_Int, (size_t) nnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      hypre_TMemcpy(C->diag->data, Ca, HYPRE_Real, (size_t) nnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+   }
+   HIP_CHECK(hipFree(Ci)); HIP_CHECK(hipFree(Cj)); HIP_CHECK(hipFree(Ca));
+   if (keepTranspose) { hypre_CSRMatrixMigrate(dR, HYPRE_MEMORY_HOST); RT->diagT = dR; } else { hypre_CSRMatrixDestroy(dR); }
+   hypre_CSRMatrixSetRownnz(C->offd);
+   hypre_ParCSRMatrixSetNumNonzeros(C);
+   hypre_ParCSRMatrixSetDNumNonzeros(C);
+   *RAP_ptr = C;
+   g_device_rap_count++;
+   return true;
+}
+
+// ===========================================================================
 // Galerkin product A_c = P^T A P (par_rap.c:30-2000), single-rank form.
 // Row ic: diagonal slot first, then RA = sum_{i1 in R(ic,:)} r * A(i1,:)
 // accumulated in first-touch order, then RA * P in first-touch order.
@@ -1083,6 +1149,7 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
 {
    MPI_Comm comm = A->comm;
    if (comm_size(comm) > 1) { return dist_build_coarse_operator(RT, A, P, keepTranspose, RAP_ptr); }
+   if (device_galerkin_product(RT, A, P, keepTranspose, RAP_ptr)) { return hypre_error_flag; }
    hypre_CSRMatrix *R = nullptr;
    hypre_CSRMatrixTranspose(RT->diag, &R, 1);
    const HYPRE_Int nc = R->num_rows, nf = A->diag->num_rows;
@@ -1453,6 +1520,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: hierarchy requested in device memory but no HIP device is available");
       return hypre_error_flag;
    }
+   g_setup_targets_device = (target == HYPRE_MEMORY_DEVICE);
    const int max_levels = d->max_levels;
    d->A = A;
    d->A_array = (hypre_ParCSRMatrix **) calloc((size_t) max_levels, sizeof(void *));

@@ -27,8 +27,18 @@ using namespace hamd;
 
 namespace hamd {
 
+void AmgPrivate::drop_graph()
+{
+   if (graph_exec) { (void) hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+   if (graph) { (void) hipGraphDestroy(graph); graph = nullptr; }
+   graph_state = 0; graph_sig = 0; graph_launches = 0;
+   graph_cur.clear();
+}
+
 void AmgPrivate::release_device()
 {
+   drop_graph();
+   graph_level = -1;
    for (double *p : u_alt) { if (p) { hypre_Free(p, HYPRE_MEMORY_DEVICE); } }
    u_alt.clear(); u_alt_len.clear();
    if (d_coarse_lu) { hypre_Free(d_coarse_lu, HYPRE_MEMORY_DEVICE); d_coarse_lu = nullptr; }
@@ -428,6 +438,38 @@ int run_replicated_tail(hypre_ParAMGData *d, AmgPrivate *pv, const double *f_loc
    return err;
 }
 
+// everything the launches of the sub-cycle below level gl depend on
+unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, hypre_ParVector **F, hypre_ParVector **U)
+{
+   unsigned long long h = 1469598103934665603ull;
+   auto mix = [&](unsigned long long v) { h ^= v; h *= 1099511628211ull; };
+   auto mixd = [&](double v) { unsigned long long b; memcpy(&b, &v, sizeof b); mix(b); };
+   mix((unsigned long long) d->num_levels); mix((unsigned long long) gl);
+   for (int k = 0; k < 4; k++) { mix((unsigned long long) d->grid_relax_type[k]); mix((unsigned long long) d->num_grid_sweeps[k]); }
+   mix((unsigned long long) d->relax_order); mix((unsigned long long) d->cycle_type); mix((unsigned long long) d->fcycle);
+   mix((unsigned long long) d->user_relax_type); mix((unsigned long long) (d->grid_relax_points != nullptr));
+   mix((unsigned long long) pv->mixed_precision); mix((unsigned long long) pv->emulated_threads);
+   mix((unsigned long long) (uintptr_t) d->Vtemp->local_vector->data);
+   for (int l = gl; l < d->num_levels; l++)
+   {
+      mixd(d->relax_weight[l]); mixd(d->omega[l]);
+      mix((unsigned long long) (uintptr_t) d->A_array[l]->diag->data); mix((unsigned long long) (uintptr_t) d->A_array[l]->diag->j);
+      mix((unsigned long long) d->A_array[l]->diag->num_nonzeros);
+      if (l < d->num_levels - 1 && d->P_array[l])
+      {
+         mix((unsigned long long) (uintptr_t) d->P_array[l]->diag->data);
+         mix((unsigned long long) (uintptr_t) (d->P_array[l]->diagT ? d->P_array[l]->diagT->data : nullptr));
+      }
+      mix((unsigned long long) (uintptr_t) F[l]->local_vector->data); mix((unsigned long long) (uintptr_t) U[l]->local_vector->data);
+      mix((unsigned long long) (uintptr_t) (d->l1_norms[l] ? d->l1_norms[l]->data : nullptr));
+      mix((unsigned long long) (uintptr_t) (l < (int) pv->u_alt.size() ? pv->u_alt[(size_t) l] : nullptr));
+   }
+   SpmvArgs a{};
+   spmv_default_flags(a);
+   mix((unsigned long long) a.variant); mix((unsigned long long) a.gather_t); mix((unsigned long long) a.xcd_map);
+   return h;
+}
+
 bool is_jacobi_type(int t) { return t == 0 || t == 7 || t == 18; }
 bool is_ge_type(int t) { return t == 9 || t == 19 || t == 98 || t == 99 || t == 198 || t == 199; }
 
@@ -477,9 +519,57 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    const bool old_version = d->grid_relax_points != nullptr;
    double cycle_op_count = d->cycle_op_count;
 
+   // ---- coarse tail as a HIP graph (single rank, plain V-cycle, smoothers whose launches do not depend on host state
+   // that changes from cycle to cycle) ----
+   HYPRE_Int cycle_nprocs = 1;
+   hypre_MPI_Comm_size(A[0]->comm, &cycle_nprocs);
+   int gl = -1;
+   {
+      auto graphable = [&](int t) { return is_jacobi_type(t) || is_ge_type(t) || t == 11 || t == 12 || t == 16 || t == 21 || t == 22; };
+      static const int graph_env = [] { const char *e = getenv("HYPRE_AMD_CYCLE_GRAPH"); return e ? atoi(e) : 1; }();
+      const bool ok = graph_env && pv->graph_rows > 0 && cycle_nprocs == 1 && d->cycle_type == 1 && !d->fcycle && !old_version &&
+                      L >= 3 && graphable(d->grid_relax_type[1]) && graphable(d->grid_relax_type[2]) && graphable(d->grid_relax_type[3]);
+      if (ok)
+      {
+         if (pv->graph_level < 0)
+         {
+            for (int l = 1; l < L - 1; l++) { if (A[l]->global_num_rows <= (HYPRE_BigInt) pv->graph_rows) { pv->graph_level = l; break; } }
+         }
+         gl = pv->graph_level;
+         if (gl >= L - 1) { gl = -1; }
+      }
+      if (gl < 0 && pv->graph_state) { pv->drop_graph(); }
+      if (gl >= 0)
+      {
+         const unsigned long long sig = tail_signature(d, pv, gl, F_array, U_array);
+         if (pv->graph_state && sig != pv->graph_sig) { pv->drop_graph(); }
+         pv->graph_sig = sig;
+      }
+   }
+   bool arrived_down = false, capturing = false;
+   double op_count_at_capture = 0.0;
+
    while (not_finished)
    {
       const int n = A[level]->diag->num_rows;
+      // the tail: replay, or record on the second visit
+      bool replayed = false;
+      if (gl >= 0 && level == gl && arrived_down)
+      {
+         if (pv->graph_state == 2)
+         {
+            HIP_CHECK(hipGraphLaunch(pv->graph_exec, s));
+            for (int l = gl; l < L; l++) { lv[(size_t) l].cur = pv->graph_cur[(size_t) (l - gl)]; zeros[(size_t) l] = 0; lev_counter[(size_t) l] = -1; }
+            cycle_op_count += pv->graph_op_count;
+            replayed = true;
+         }
+         else if (pv->graph_state == 1)
+         {
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; op_count_at_capture = cycle_op_count; }
+            else { (void) hipGetLastError(); pv->graph_state = 0; gl = -1; }
+         }
+      }
+      arrived_down = false;
       int num_sweep, relax_type;
       if (L > 1) { num_sweep = d->num_grid_sweeps[cycle_param]; relax_type = d->grid_relax_type[cycle_param]; }
       else
@@ -504,7 +594,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
          zeros[(size_t) level] = 0;
          if (err) { break; }
       }
-      for (int j = 0; j < (tail_here ? 0 : num_sweep); j++)
+      for (int j = 0; j < ((tail_here || replayed) ? 0 : num_sweep); j++)
       {
          int relax_points = 0, relax_local = d->relax_order;
          if (L == 1 && d->max_levels > 1) { relax_points = 0; relax_local = 0; }
@@ -636,9 +726,10 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       }
       if (err) { break; }
 
-      --lev_counter[(size_t) level];
-      if (lev_counter[(size_t) level] >= 0 && level != L - 1 && !tail_here)
+      if (!replayed) { --lev_counter[(size_t) level]; }
+      if (!replayed && lev_counter[(size_t) level] >= 0 && level != L - 1 && !tail_here)
       {
+         arrived_down = true;
          // descend: u_c = 0 ; r = f - A u ; f_c = P^T r
          const int fine = level, coarse = level + 1;
          LevelVec &uc = lv[(size_t) coarse];
@@ -661,6 +752,29 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       }
       else if (level != 0)
       {
+         if (capturing && level == gl)
+         {
+            // the sub-cycle is over: everything enqueued since the tail was entered becomes the graph
+            capturing = false;
+            hipGraph_t g = nullptr;
+            if (hipStreamEndCapture(s, &g) == hipSuccess && g)
+            {
+               hipGraphExec_t ex = nullptr;
+               if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess)
+               {
+                  pv->graph = g; pv->graph_exec = ex; pv->graph_state = 2;
+                  pv->graph_cur.assign((size_t) (L - gl), nullptr);
+                  for (int l = gl; l < L; l++) { pv->graph_cur[(size_t) (l - gl)] = lv[(size_t) l].cur; }
+                  pv->graph_op_count = cycle_op_count - op_count_at_capture;
+                  size_t nn = 0;
+                  if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) { pv->graph_launches = (int) nn; }
+                  HIP_CHECK(hipGraphLaunch(ex, s));       // the capture recorded the work, it did not run it
+               }
+               else { (void) hipGetLastError(); (void) hipGraphDestroy(g); pv->graph_state = 0; err = 1; hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCycle: the coarse-tail graph could not be instantiated"); }
+            }
+            else { (void) hipGetLastError(); pv->graph_state = 0; err = 1; hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCycle: capturing the coarse tail failed"); }
+            if (err) { break; }
+         }
          // ascend: u_f += P u_c, written to whichever buffer lets the
          // post-smoothing sweeps end in the level's home vector
          const int fine = level - 1;
@@ -691,6 +805,16 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
          not_finished = false;
       }
    }
+   if (capturing)
+   {
+      // left the loop (an error) while recording: close the capture so that the stream is usable again
+      hipGraph_t g = nullptr;
+      (void) hipStreamEndCapture(s, &g);
+      if (g) { (void) hipGraphDestroy(g); }
+      (void) hipGetLastError();
+      pv->graph_state = 0;
+   }
+   else if (gl >= 0 && pv->graph_state == 0 && !err) { pv->graph_state = 1; }      // warmed up: record at the next cycle
    // the caller's vector must hold the result
    if (lv[0].cur != lv[0].home)
    {

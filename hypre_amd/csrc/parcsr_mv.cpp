@@ -21,10 +21,21 @@
 using namespace hamd;
 
 namespace hamd {
+// traffic counters of this process (reported by the benchmark): neighbour exchanges and all-reduces started
+static long long g_exchanges = 0, g_allreduces = 0;
+}
+extern "C" HYPRE_Int hypre_amd_CommCounters(HYPRE_BigInt *exchanges, HYPRE_BigInt *allreduces, HYPRE_Int reset)
+{
+   if (exchanges) { *exchanges = hamd::g_exchanges; }
+   if (allreduces) { *allreduces = hamd::g_allreduces; }
+   if (reset) { hamd::g_exchanges = 0; hamd::g_allreduces = 0; }
+   return hypre_error_flag;
+}
+namespace hamd {
 double global_sum(MPI_Comm comm, double v)
 {
    const hypre_amd_CommOps *o = comm_ops(comm);
-   if (o && o->size > 1 && o->allreduce_sum) { o->allreduce_sum(o->ctx, &v, 1, 0, nullptr); }
+   if (o && o->size > 1 && o->allreduce_sum) { g_allreduces++; o->allreduce_sum(o->ctx, &v, 1, 0, nullptr); }
    return v;
 }
 }  // namespace hamd
@@ -62,6 +73,7 @@ void dev_allreduce_sum(MPI_Comm comm, double *d_buf, int n)
 {
    const hypre_amd_CommOps *o = comm_ops(comm);
    if (!o || o->size <= 1 || n <= 0) { return; }
+   g_allreduces++;
    Handle &hd = handle();
    if (o->device_buffers)
    {
@@ -549,6 +561,7 @@ hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate_v2(HYPRE_Int job, hypre_Par
    h->recv_data = recv_data;
    const hypre_amd_CommOps *o = comm_ops(pkg->comm);
    if (!o || o->size <= 1) { return h; }
+   hamd::g_exchanges++;
 
    // jobs 1/2: HYPRE_Complex, 11/12: HYPRE_Int, 21/22: HYPRE_BigInt (par_csr_communication.c:483-614)
    const size_t esz = (job == 11 || job == 12) ? sizeof(HYPRE_Int) : sizeof(HYPRE_Complex);

@@ -1,0 +1,268 @@
+// hypre_amd — Galerkin product A_c = R A P on the device (single rank), bit-identical to the host setup.
+//
+// Reference: parcsr_ls/par_rap.c:30-2000 (hypre_BoomerAMGBuildCoarseOperatorKT) — row ic of A_c is formed as
+//    RA  = sum_{i1 in R(ic,:)} r * A(i1,:)        columns kept in first-touch order,
+//    row = RA * P                                  columns in first-touch order behind the diagonal slot,
+// every value accumulated in exactly that nesting order.  The host setup of this library (par_amg_setup.cpp) keeps that
+// order because the C/F splittings of the coarser levels — and with them the iteration counts and complexities the
+// reference's regression files pin — depend on the bits of A_c.  So does this kernel: one WAVE owns a coarse row and
+// walks R(ic,:) and RA in order; the lanes share the work INSIDE a step (the entries of one row of A, or of one row of
+// P, have distinct columns: they can be looked up, appended — in entry order, by ballot and prefix count — and
+// accumulated side by side without changing any sum).  The two column -> position maps of a row live in LDS as
+// open-addressing tables whose slots carry the row's number, so nothing is cleared between rows.  Two passes over the
+// rows: lengths, then (after a scan) columns and values.
+//
+// The reference's own device product (parcsr_mv/par_csr_triplemat_device.c, hypre's spgemm hash kernels) is a general
+// row-wise SpGEMM whose summation order is whatever the hash probing yields; it is what this has to beat in time, not
+// in form.
+#include "internal.hpp"
+#include <algorithm>
+
+// r * a and the accumulation are separate roundings on the host (no fused multiply-add in the host build): keep them so
+#pragma clang fp contract(off)
+
+namespace hamd {
+
+namespace {
+
+// (row tag << 32 | key) in one 64-bit LDS word; a slot whose tag is not the current row's is free
+__device__ __forceinline__ int table_find(const unsigned long long *tab, const int *pos, int mask, unsigned tag, int key)
+{
+   unsigned h = ((unsigned) key * 2654435761u) >> 7;
+   while (true)
+   {
+      const unsigned long long e = tab[h & mask];
+      if ((unsigned) (e >> 32) != tag) { return -1; }
+      if ((int) (unsigned) e == key) { return pos[h & mask]; }
+      h++;
+   }
+}
+
+// insert a key known to be absent (lanes insert distinct keys side by side)
+__device__ __forceinline__ void table_insert(unsigned long long *tab, int *pos, int mask, unsigned tag, int key, int p)
+{
+   unsigned h = ((unsigned) key * 2654435761u) >> 7;
+   const unsigned long long mine = ((unsigned long long) tag << 32) | (unsigned) key;
+   while (true)
+   {
+      const unsigned long long e = tab[h & mask];
+      if ((unsigned) (e >> 32) != tag)
+      {
+         if (atomicCAS(&tab[h & mask], e, mine) == e) { pos[h & mask] = p; return; }
+         continue;          // somebody took the slot: look at it again
+      }
+      h++;
+   }
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long ballot, int lane)
+{
+   return __popcll(ballot & ((1ull << lane) - 1ull));
+}
+
+}  // namespace
+
+// FILL = false: row lengths only.  One wave per workgroup; workgroups walk the rows with stride gridDim.
+template <bool FILL>
+__global__ __launch_bounds__(64)
+void rap_rows_kernel(int nc, int square,
+                     const int *__restrict__ Ri, const int *__restrict__ Rj, const double *__restrict__ Ra,
+                     const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa,
+                     const int *__restrict__ Pi, const int *__restrict__ Pj, const double *__restrict__ Pa,
+                     int capA, int capRA, int capP, int capO,
+                     int *__restrict__ rowlen, const int *__restrict__ Ci, int *__restrict__ Cj, double *__restrict__ Ca,
+                     int *__restrict__ overflow)
+{
+   extern __shared__ __align__(16) unsigned char smem[];
+   unsigned long long *Akey = reinterpret_cast<unsigned long long *>(smem);
+   unsigned long long *Pkey = Akey + capA;
+   double *raa = reinterpret_cast<double *>(Pkey + capP);
+   double *oa  = raa + capRA;
+   int *Apos = reinterpret_cast<int *>(oa + capO);
+   int *Ppos = Apos + capA;
+   int *raj  = Ppos + capP;
+   int *oj   = raj + capRA;
+   const int lane = threadIdx.x;
+   for (int i = lane; i < capA; i += 64) { Akey[i] = 0; }
+   for (int i = lane; i < capP; i += 64) { Pkey[i] = 0; }
+   __syncthreads();
+
+   unsigned tag = 0;
+   for (int ic = blockIdx.x; ic < nc; ic += gridDim.x)
+   {
+      tag++;                                   // tag 0 = the cleared table
+      // ---- RA = sum r * A(i1,:), first-touch order
+      int nRA = 0;
+      bool bad = false;
+      for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; j1++)
+      {
+         const int i1 = Rj[j1];
+         const double r = FILL ? Ra[j1] : 0.0;
+         const int a0 = Ai[i1], a1 = Ai[i1 + 1];
+         for (int base = a0; base < a1; base += 64)
+         {
+            const int j2 = base + lane;
+            const bool have = j2 < a1;
+            const int i2 = have ? Aj[j2] : -1;
+            const double v = (FILL && have) ? r * Aa[j2] : 0.0;
+            const int m = have ? table_find(Akey, Apos, capA - 1, tag, i2) : 0;
+            const bool fresh = have && m < 0;
+            const unsigned long long ball = __ballot(fresh);
+            const int p = nRA + lanes_below(ball, lane);
+            if (nRA + __popcll(ball) > capRA) { bad = true; break; }
+            if (fresh)
+            {
+               table_insert(Akey, Apos, capA - 1, tag, i2, p);
+               raj[p] = i2;
+               if (FILL) { raa[p] = v; }
+            }
+            else if (FILL && have) { raa[m] += v; }
+            nRA += __popcll(ball);
+            __syncthreads();
+         }
+         if (bad) { break; }
+      }
+      // ---- row = RA * P, first-touch order behind the diagonal slot
+      int nO = 0;
+      if (!bad)
+      {
+         if (square)
+         {
+            if (lane == 0) { table_insert(Pkey, Ppos, capP - 1, tag, ic, 0); oj[0] = ic; if (FILL) { oa[0] = 0.0; } }
+            nO = 1;
+            __syncthreads();
+         }
+         for (int q = 0; q < nRA && !bad; q++)
+         {
+            const int i1 = raj[q];
+            const double rap = FILL ? raa[q] : 0.0;
+            const int p0 = Pi[i1], p1 = Pi[i1 + 1];
+            for (int base = p0; base < p1; base += 64)
+            {
+               const int j2 = base + lane;
+               const bool have = j2 < p1;
+               const int i2 = have ? Pj[j2] : -1;
+               const int m = have ? table_find(Pkey, Ppos, capP - 1, tag, i2) : 0;
+               const bool fresh = have && m < 0;
+               const unsigned long long ball = __ballot(fresh);
+               const int p = nO + lanes_below(ball, lane);
+               if (nO + __popcll(ball) > capO) { bad = true; break; }
+               if (fresh)
+               {
+                  table_insert(Pkey, Ppos, capP - 1, tag, i2, p);
+                  oj[p] = i2;
+                  if (FILL) { oa[p] = rap * Pa[j2]; }
+               }
+               else if (FILL && have) { oa[m] += rap * Pa[j2]; }
+               nO += __popcll(ball);
+               __syncthreads();
+            }
+         }
+      }
+      if (bad) { if (lane == 0) { atomicExch(overflow, 1); } nO = 0; }
+      if (!FILL) { if (lane == 0) { rowlen[ic] = nO; } }
+      else
+      {
+         const int c0 = Ci[ic];
+         for (int k = lane; k < nO; k += 64) { Cj[c0 + k] = oj[k]; Ca[c0 + k] = oa[k]; }
+      }
+      __syncthreads();
+   }
+}
+
+// per coarse row: sum of the lengths of the rows of A it touches (bounds the length of RA), maximum over all rows
+__global__ void rap_bound_kernel(int nc, const int *__restrict__ Ri, const int *__restrict__ Rj, const int *__restrict__ Ai,
+                                 int *__restrict__ max_out)
+{
+   int m = 0;
+   for (int ic = blockIdx.x * blockDim.x + threadIdx.x; ic < nc; ic += gridDim.x * blockDim.x)
+   {
+      int ub = 0;
+      for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; j1++) { const int i1 = Rj[j1]; ub += Ai[i1 + 1] - Ai[i1]; }
+      m = max(m, ub);
+   }
+   for (int off = 32; off > 0; off >>= 1) { m = max(m, __shfl_xor(m, off, 64)); }
+   if ((threadIdx.x & 63) == 0) { atomicMax(max_out, m); }
+}
+
+static int pow2_at_least(int v) { int p = 8; while (p < v) { p <<= 1; } return p; }
+
+// R (nc x nf), A (nf x nf), P (nf x ncP) as device CSR.  Allocates *Ci / *Cj / *Ca (device) for the product.  Returns false
+// when a row does not fit the LDS budget of a workgroup (the caller then forms this product on the host).
+bool device_rap(int nc, int ncP, int maxP,
+                const int *Ri, const int *Rj, const double *Ra, const int *Ai, const int *Aj, const double *Aa,
+                const int *Pi, const int *Pj, const double *Pa, int **Ci_out, int **Cj_out, double **Ca_out, int *nnz_out,
+                hipStream_t s)
+{
+   const bool square = (nc == ncP);
+   int *d_scr = nullptr;
+   HIP_CHECK(hipMalloc((void **) &d_scr, sizeof(int) * 2));
+   HIP_CHECK(hipMemsetAsync(d_scr, 0, sizeof(int) * 2, s));
+   int grid = (nc + 255) / 256;
+   if (grid > 4096) { grid = 4096; }
+   hipLaunchKernelGGL(rap_bound_kernel, dim3(grid), dim3(256), 0, s, nc, Ri, Rj, Ai, d_scr);
+   int h_scr[2] = {0, 0};
+   HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   const int ubA = std::max(h_scr[0], 1);
+   auto lds_bytes = [](int capA, int capRA, int capP, int capO)
+   { return (size_t) 8 * capA + 8 * capP + 8 * capRA + 8 * capO + 4 * capA + 4 * capP + 4 * capRA + 4 * capO + 64; };
+   // Pass 1 (lengths).  The tables are sized by what rows of such products usually need, not by the worst case the
+   // bounds allow (RA <= sum of the touched rows of A; the row <= RA x longest row of P): a first attempt with small
+   // tables (six workgroups per CU), a second one with four times the room if any row overflowed, the host after that.
+   const long long ubO = std::min<long long>((long long) ubA * std::max(maxP, 1) + 1, (long long) ncP);
+   const size_t budget = 150 * 1024;
+   (void) hipFuncSetAttribute((const void *) rap_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
+   (void) hipFuncSetAttribute((const void *) rap_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
+   int *rowlen = nullptr;
+   HIP_CHECK(hipMalloc((void **) &rowlen, sizeof(int) * ((size_t) nc + 1)));
+   const int waves = std::min(nc, handle().num_cus * 32);
+   int capRA = 0, capA = 0, capO = 0, capP = 0;
+   bool done = false;
+   for (int attempt = 0; attempt < 2 && !done; attempt++)
+   {
+      capRA = (std::min(ubA, attempt == 0 ? 384 : 1536) + 1) & ~1;
+      capA = pow2_at_least(2 * capRA);
+      capO = (int) ((std::min<long long>(ubO, attempt == 0 ? 192 : 768) + 1) & ~1LL);
+      capP = pow2_at_least(2 * capO);
+      if (lds_bytes(capA, capRA, capP, capO) > budget) { break; }
+      HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
+      hipLaunchKernelGGL((rap_rows_kernel<false>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
+                         Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, (int *) nullptr,
+                         (double *) nullptr, d_scr + 1);
+      HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      done = h_scr[1] == 0;
+      if (capRA >= ubA && capO >= ubO) { break; }        // the bounds themselves fitted: nothing larger to try
+   }
+   if (!done) { HIP_CHECK(hipFree(rowlen)); HIP_CHECK(hipFree(d_scr)); return false; }
+   // row pointers: exclusive scan on the host (one pass over nc integers)
+   std::vector<int> hl((size_t) nc + 1, 0);
+   HIP_CHECK(hipMemcpyAsync(hl.data(), rowlen, sizeof(int) * (size_t) nc, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   int maxlen = 0;
+   long long run = 0;
+   for (int i = 0; i < nc; i++) { const int l = hl[(size_t) i]; maxlen = std::max(maxlen, l); hl[(size_t) i] = (int) run; run += l; }
+   hl[(size_t) nc] = (int) run;
+   if (run > 0x7fffffffLL) { HIP_CHECK(hipFree(rowlen)); HIP_CHECK(hipFree(d_scr)); return false; }
+   const int nnz = (int) run;
+   int *Ci = rowlen, *Cj = nullptr;
+   double *Ca = nullptr;
+   HIP_CHECK(hipMemcpyAsync(Ci, hl.data(), sizeof(int) * ((size_t) nc + 1), hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipMalloc((void **) &Cj, sizeof(int) * (size_t) std::max(nnz, 1)));
+   HIP_CHECK(hipMalloc((void **) &Ca, sizeof(double) * (size_t) std::max(nnz, 1)));
+   // pass 2 (columns and values): the output tables need only hold the longest row found
+   capO = (std::max(maxlen, 1) + 1) & ~1;
+   capP = pow2_at_least(2 * capO);
+   HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
+   hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
+                      Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, (int *) nullptr, Ci, Cj, Ca, d_scr + 1);
+   HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(d_scr));
+   if (h_scr[1]) { HIP_CHECK(hipFree(Ci)); HIP_CHECK(hipFree(Cj)); HIP_CHECK(hipFree(Ca)); return false; }
+   *Ci_out = Ci; *Cj_out = Cj; *Ca_out = Ca; *nnz_out = nnz;
+   return true;
+}
+
+}  // namespace hamd

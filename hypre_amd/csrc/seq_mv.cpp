@@ -54,6 +54,11 @@ void spmv_default_flags(SpmvArgs &a)
    }
    a.gather_t = gt; a.xcd_map = xcd;
    a.variant = spmv_variant().variant; a.pipe_wgs = spmv_variant().pipe_wgs;
+   // Row-sum width of the multi-lane reduction: 8 lanes per row up to a mean row length of 128 (32 rows per pass), 32 lanes
+   // beyond.  Measured on level 2 of the 256^3 hierarchy (70 entries per row, 29 rows per tile): 32 lanes per row (the
+   // round-1 choice above 48) 0.123 ms, 8 lanes 0.104 ms — with the x gathers out of the way the kernel is bound by
+   // instruction issue, and four passes of 8 rows cost more instructions than one pass of 32.
+   { static int w8 = -1; if (w8 < 0) { const char *e = getenv("HYPRE_AMD_SPMV_W8MAX"); w8 = e ? atoi(e) : 128; } a.w8_max = w8; }
 }
 
 // Band-aware XCD placement.  Workgroup g runs on XCD g % 8 and every XCD has its own L2.  A matrix from a
@@ -123,6 +128,8 @@ static void build_band_placement(SpmvPlan *p, const hypre_CSRMatrix *A, hipStrea
    HIP_CHECK(hipStreamSynchronize(s));
    p->band = B;
 }
+
+constexpr int RP_CAP_HOST = 640;     // = RP_CAP of spmv_kernels.hip
 
 static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> &plan_table()
 {
@@ -203,6 +210,29 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
             HIP_CHECK(hipMalloc((void **) &p->d_lidx, sizeof(unsigned short) * nl));
             HIP_CHECK(hipMemsetAsync(p->d_lidx, 0, sizeof(unsigned short) * nl, s));
             launch_build_xs(A->j, p->d_tile_k, p->num_tiles, p->d_xs_cnt, p->d_xs_desc, p->d_lidx, s);
+            // the product area doubles as the staging area: size it by the longest staged copy of this matrix
+            std::vector<int> cnt((size_t) p->num_tiles);
+            HIP_CHECK(hipMemcpyAsync(cnt.data(), p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            std::vector<int> cov;
+            cov.reserve(cnt.size());
+            for (int c : cnt) { if (c & 0xff) { p->xs_tiles++; p->xs_max_units = std::max(p->xs_max_units, c >> 8); cov.push_back(c >> 8); } }
+            // LDS per workgroup decides how many tiles a CU holds (160 KB): stage what 99 % of the tiles need, rounded up
+            // to the next occupancy step; the few tiles above that gather through the cache
+            if (!cov.empty())
+            {
+               std::sort(cov.begin(), cov.end());
+               const int need = cov[(size_t) ((cov.size() - 1) * 99 / 100)];
+               const int other = 8 * 264 + 4 * (RP_CAP_HOST + 4) + 64;          // row sums + row pointers beside the products
+               int units = p->xs_max_units;
+               for (int wgs = 8; wgs >= 3; wgs--)
+               {
+                  const int fit = ((160 * 1024) / wgs - other) / 16;             // units (16 bytes) that leave room for wgs workgroups
+                  if (fit >= need) { units = std::min(fit, p->xs_max_units); break; }
+               }
+               p->xs_launch_units = std::max(units, need);
+            }
+            p->prod_elems = std::max(p->prod_elems, 2 * p->xs_launch_units + 8);
          }
       }
    }
@@ -303,7 +333,7 @@ extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanStaging(hypre_CSRMatrix *A, HYPRE_In
    HIP_CHECK(hipStreamSynchronize(hamd::stream()));
    HIP_CHECK(hipMemcpy(cnt.data(), p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles, hipMemcpyDeviceToHost));
    long long staged = 0, pieces = 0;
-   for (int c : cnt) { if (c > 0) { staged++; pieces += c; } }
+   for (int c : cnt) { if (c & 0xff) { staged++; pieces += c & 0xff; } }
    if (num_tiles) { *num_tiles = p->num_tiles; }
    if (mean_pieces && staged) { *mean_pieces = (double) pieces / (double) staged; }
    return (HYPRE_Int) staged;

@@ -149,7 +149,7 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
    else
    {
       // avg > 12  =>  nrows <= (TILE + MAXROW)/13 < SPMV_THREADS: row sums fit rowsum[]
-      if (avg <= 48)
+      if (avg <= p.w8_max)
       {
          constexpr int W = 8, G = SPMV_THREADS / W;
          const int sub = tid & (W - 1);
@@ -486,28 +486,29 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
 // costs a whole second trip through it.  A tile's life is the number of such dependent trips, and with a fixed number
 // of resident tiles that sets the rate.
 //
-// So the x values a tile needs are fetched in the SAME trip as its matrix stream.  The plan records per tile up to 32
+// So the x values a tile needs are fetched in the SAME trip as its matrix stream.  The plan records per tile up to 48
 // pieces of x, 128 doubles at most each, that cover the columns of its entries (a 2048-entry tile touches 850 - 1100
 // distinct columns in a handful of clusters: rows that are neighbours in the matrix share most of their columns), and
 // per entry a 16-bit index into the concatenation of those pieces.  The piece descriptors are wave-uniform and arrive
 // through the scalar cache (its own path, a few hundred ns); each wave then issues one 16-byte load per lane for each of
-// its eight pieces right behind the (value, index) stream loads, the copy lands in LDS, and the "gathers" are eight LDS
+// its twelve pieces right behind the (value, index) stream loads, the copy lands in LDS, and the "gathers" are eight LDS
 // reads per lane.  The column array
-// is not read at all: 8 + 2 bytes per entry instead of 12.  Tiles whose columns do not fit 32 pieces / 2048 doubles
+// is not read at all: 8 + 2 bytes per entry instead of 12.  Tiles whose columns do not fit 48 pieces / 3072 doubles
 // (restriction operators: a row of P^T reaches far) take the gather path of spmv_tiled_kernel inside the same launch.
 // The staged copy and the products share LDS.
 // Reference counterpart of the whole family: seq_mv/csr_spmv_device.c:35-260 (no LDS, gathers through the cache).
 // ---------------------------------------------------------------------------
-constexpr int XS_SEGS  = SPMV_XS_SEGS;      // segments per tile: 4 waves x 8
-constexpr int XS_CAP   = SPMV_TILE;         // doubles a tile may stage (= the product area)
-constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first column of every segment, then (offset << 16 | length)
+constexpr int XS_SEGS  = SPMV_XS_SEGS;      // pieces per tile: 4 waves x XS_WSEG
+constexpr int XS_WSEG  = XS_SEGS / 4;       // pieces a wave fetches
+constexpr int XS_CAP   = SPMV_XS_CAP;       // doubles a tile may stage at most (the launch sizes LDS by what the matrix needs)
+constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first column of every piece, then (offset << 16 | length)
 
 template <int OP, bool F32, bool HASFILL>
 __global__ __launch_bounds__(SPMV_THREADS)
 void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
                     const int *__restrict__ xs_cnt, const int *__restrict__ xs_desc,
                     const unsigned short *__restrict__ lidx,
-                    int num_tiles, int prod_elems, int rowsum_elems, int rp_cap)
+                    int num_tiles, int prod_elems, int rowsum_elems, int rp_cap, int xs_units)
 {
    extern __shared__ __align__(16) unsigned char smem_raw[];
    double *prod   = reinterpret_cast<double *>(smem_raw);     // staged x first, products after the second barrier
@@ -552,7 +553,8 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    if (r1 <= r0) { return; }
    const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
    const int nrows = r1 - r0;
-   const int nseg = xs_cnt[tile];
+   const int xc = xs_cnt[tile];                // (covered units << 8) | pieces
+   const int nseg = (xc >> 8) <= xs_units ? (xc & 0xff) : 0;     // the launch may stage less than the plan allows (occupancy)
 
    if (nseg == 0)
    {
@@ -573,26 +575,24 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       return;
    }
 
-   const int *dsc = xs_desc + (size_t) tile * XS_DESC + 8 * wave;
-   int seg_start[8], seg_ol[8];
+   const int *dsc = xs_desc + (size_t) tile * XS_DESC + XS_WSEG * wave;
+   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
 #pragma unroll
-   for (int j = 0; j < 8; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
+   for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
 
    // x pieces (at most 128 doubles each: one 16-byte load per lane), requested in the same trip through the memory
    // pipeline as the stream above and written straight into LDS (global_load_lds: no registers, no ds_write pass; the
-   // LDS address is the piece's base + 16 * lane, which is exactly how a piece is laid out)
+   // LDS address is the piece's base + 16 * lane, which is exactly how a piece is laid out).  A piece starts at an even
+   // column and x is 16-byte aligned, so a lane's 16 bytes never straddle a page: when x has an odd length the upper
+   // half of its last pair is read (not used) but cannot fault.
 #pragma unroll
-   for (int j = 0; j < 8; j++)
+   for (int j = 0; j < XS_WSEG; j++)
    {
-      const int c = seg_start[j] + 2 * lane, off = seg_ol[j] >> 16, len = seg_ol[j] & 0xffff;
+      const int off = seg_ol[j] >> 16, len = seg_ol[j] & 0xffff;
       if (2 * lane < len)
       {
-         if (c + 1 <= p.x_last)
-         {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + c),
-                                             (__attribute__((address_space(3))) void *) (prod + off), 16, 0, 0);
-         }
-         else { prod[off + 2 * lane] = p.x[min(c, p.x_last)]; prod[off + 2 * lane + 1] = 0.0; }     // x ends inside this pair
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + seg_start[j] + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (prod + off), 16, 0, 0);
       }
    }
    // spill of the tile's last row past the window (one entry per lane), row pointers, epilogue operands: same trip
@@ -669,7 +669,6 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
    __shared__ int uniq[XS_UNITS + 1];       // distinct units, ascending
    __shared__ int pos[XS_UNITS + 1];        // staged position (in units) of every distinct unit
    __shared__ int part[SPMV_THREADS];
-   __shared__ int red[2];
    const int tile = blockIdx.x, tid = threadIdx.x;
    const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
    const int m = k1 - k0;
@@ -731,7 +730,7 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
    // (the covered length grows with T; once it exceeds the staging capacity the tile is given up).
    constexpr int UPER = (XS_UNITS + SPMV_THREADS - 1) / SPMV_THREADS;
    constexpr int XS_PIECE = 64;                 // units (2 doubles) per piece: one 16-byte load per lane of a wave
-   int T = 0, npieces = 0;
+   int T = 0, npieces = 0, covered_units = 0;
    bool fits = false;
    for (int step = 0; step < 24; step++)
    {
@@ -750,6 +749,7 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
       }
       __syncthreads();
       if (covered > XS_UNITS) { break; }
+      covered_units = covered;
       int np = 0;
       for (int i = tid * UPER; i < (tid + 1) * UPER && i < U; i++)
       {
@@ -788,7 +788,7 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
             const int len_units = pos[e - 1] - pos[i] + 1;
             for (int o = 0; o < len_units; o += XS_PIECE)
             {
-               const int slot = (pidx & 3) * 8 + (pidx >> 2);        // pieces dealt to the four waves, a wave's eight contiguous
+               const int slot = (pidx & 3) * XS_WSEG + (pidx >> 2);  // pieces dealt to the four waves, a wave's own contiguous
                desc[slot] = 2 * (uniq[i] + o);
                desc[XS_SEGS + slot] = ((2 * (pos[i] + o)) << 16) | (2 * min(XS_PIECE, len_units - o));
                pidx++;
@@ -797,7 +797,7 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
       }
    }
    const int nseg = npieces;
-   if (tid == 0) { xs_cnt[tile] = nseg; red[0] = 0; }
+   if (tid == 0) { xs_cnt[tile] = (covered_units << 8) | nseg; }
    for (int i = tid; i < m; i += SPMV_THREADS)
    {
       const int col = Aj[k0 + i], q = col >> 1;
@@ -989,7 +989,7 @@ static void launch_xs(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
    const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
    hipLaunchKernelGGL((spmv_xs_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
                       plan->d_tile_row, plan->d_tile_k, plan->d_xs_cnt, plan->d_xs_desc, plan->d_lidx,
-                      plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap);
+                      plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap, plan->xs_launch_units);
 }
 
 template <int OP, bool F32, bool FILL>

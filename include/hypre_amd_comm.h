@@ -80,6 +80,9 @@ MPI_Comm  hypre_amd_CommCreateStreamStaged(MPI_Comm inner);
  * all-gather, each verified.  Returns the number of failed checks. */
 HYPRE_Int hypre_amd_CommSelfTest(MPI_Comm comm, HYPRE_Int nbytes);
 
+/* neighbour exchanges and all-reduces this process has started since the last reset (benchmark reporting) */
+HYPRE_Int hypre_amd_CommCounters(HYPRE_BigInt *exchanges, HYPRE_BigInt *allreduces, HYPRE_Int reset);
+
 HYPRE_Int hypre_MPI_Comm_rank(MPI_Comm comm, HYPRE_Int *rank);
 HYPRE_Int hypre_MPI_Comm_size(MPI_Comm comm, HYPRE_Int *size);
 HYPRE_Int hypre_MPI_Barrier(MPI_Comm comm);

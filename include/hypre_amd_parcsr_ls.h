@@ -247,6 +247,18 @@ HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver solver, HYPRE_Memory
 HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_threads);
 /* store matrix values of every level in fp32 for the SpMV / smoother kernels;
  * residuals on level 0 stay fp64 (mixed-precision configuration) */
+/* Where the Galerkin products of HYPRE_BoomerAMGSetup are formed when the hierarchy's home is device memory and there is
+ * one rank: on the device by default (rap_kernels.hip; same columns, order and bits as the host loop), on = 0 keeps the
+ * host loop; min_rows: smallest fine level sent to the device (default 20000).  Negative arguments leave a setting
+ * unchanged.  Returns the number of products formed on the device since the previous call.  The reference's device setup:
+ * parcsr_mv/par_csr_triplemat.c:938-960. */
+HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows);
+/* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows, default 100000; 0: off) is recorded once as a
+ * HIP graph and replayed: its kernels are a few microseconds each behind launches that cost as much.  No reference
+ * counterpart (the reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded
+ * graph (-1: none) and its node count. */
+HYPRE_Int hypre_amd_BoomerAMGSetGraphThreshold(HYPRE_Solver solver, HYPRE_Int rows);
+HYPRE_Int hypre_amd_BoomerAMGGetGraphInfo(HYPRE_Solver solver, HYPRE_Int *level, HYPRE_Int *nodes);
 HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on);
 /* grid / operator complexity of the last setup */
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);

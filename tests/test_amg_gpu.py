@@ -421,3 +421,90 @@ def test_solver_life_cycle_leaves_no_error(gpu_lib, oracle):
     for v in (b1, x1, b2, x2):
         lib.hypre_ParVectorDestroy(v)
     B.check()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(relax_type=18), dict(relax_type=18, relax_order=1), dict(relax_type=11), dict(relax_type=12, problem="27pt"),
+    dict(relax_down=21, relax_up=22), dict(relax_type=16), dict(relax_type=7, relax_wt=0.8), dict(relax_type=18, mixed=True),
+])
+def test_coarse_tail_graph_replays_the_same_cycle(gpu_lib, oracle, kw):
+    """The coarse tail of the V-cycle is recorded as a HIP graph on the second cycle and replayed afterwards: cycles 1
+    (eager), 2 (recorded and launched) and 3, 4 (replayed) give the same result — the oracle's — from a zero and from a
+    non-zero guess; changing a smoother weight invalidates the recording and the new cycles follow the new weight."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    kw = dict(kw)
+    mixed = kw.pop("mixed", False)
+    opt, A, s = _setup(lib, n=(30, 29, 28), coarsen_type=8, **kw)
+    if mixed:
+        lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    n = 30 * 29 * 28
+    f = rand_vector(n, 5)
+    lev, nodes = C.c_int(), C.c_int()
+
+    def check(rounds):
+        amg = oracle.amg_from_solvers([s], mixed_precision=mixed)
+        for k in range(rounds):
+            zero = k % 2 == 0
+            u0 = np.zeros(n) if zero else rand_vector(n, 6 + k)
+            du, df = B.parvec_from_numpy(u0), B.parvec_from_numpy(f)
+            if zero:
+                lib.hypre_ParVectorSetZeros(du)
+            lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+            B.check()
+            ur = u0.copy()
+            amg.solve(f, ur, tol=0.0, max_iter=1, u_all_zeros=zero)
+            assert np.max(np.abs(B.parvec_to_numpy(du) - ur)) <= 1e-11 * np.max(np.abs(ur)), (kw, k)
+
+    check(4)
+    lib.hypre_amd_BoomerAMGGetGraphInfo(s, C.byref(lev), C.byref(nodes))
+    assert lev.value >= 1 and nodes.value > 5
+    # a different weight on every level: the recording must not survive it
+    view = C.cast(s, C.POINTER(oracle.AmgDataView)).contents
+    for l in range(lib.hypre_amd_BoomerAMGGetNumLevels(s)):
+        view.relax_weight[l] = 0.9
+    check(4)
+    # and switched off
+    lib.hypre_amd_BoomerAMGSetGraphThreshold(s, 0)
+    check(2)
+    lib.hypre_amd_BoomerAMGGetGraphInfo(s, C.byref(lev), C.byref(nodes))
+    assert lev.value == -1
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
+@pytest.mark.parametrize("kw", [dict(n=(40, 39, 38)), dict(n=(30, 30, 30), problem="27pt"),
+                                dict(n=(36, 35, 34), problem="difconv", c=(1.0, 1.0, 0.001), a=(0.0, 0.0, 0.0)),
+                                dict(n=(40, 40, 40), coarsen_type=10, P_max_elmts=0)])
+def test_device_galerkin_product_is_the_host_product(gpu_lib, kw):
+    """Setup with the Galerkin products formed on the device (one wave per coarse row, the host loop's order) and on the
+    host: every level's operator identical array for array — row pointers, column order, values bit for bit — and so
+    are the stored transposes of the interpolation operators (device transpose vs host counting sort)."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    hier = []
+    for on in (0, 1):
+        lib.hypre_amd_SetSetupDeviceRAP(on, 50)
+        opt = ij.IJOptions(relax_type=18, **dict(dict(coarsen_type=8), **kw))
+        A = ij.build_matrix(opt)
+        s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+        lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+        B.check()
+        formed = lib.hypre_amd_SetSetupDeviceRAP(-1, -1)
+        nl = lib.hypre_amd_BoomerAMGGetNumLevels(s)
+        assert (formed >= 2) if on else (formed == 0), (on, formed, nl)
+        lv = []
+        for l in range(nl):
+            Al = C.cast(lib.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
+            lv.append(B.csr_to_arrays(Al.contents.diag))
+            if l < nl - 1:
+                Pl = C.cast(lib.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+                lv.append(B.csr_to_arrays(Pl.contents.diagT))
+        hier.append(lv)
+        lib.HYPRE_BoomerAMGDestroy(s)
+    lib.hypre_amd_SetSetupDeviceRAP(1, 20000)
+    assert len(hier[0]) == len(hier[1])
+    for m0, m1 in zip(hier[0], hier[1]):
+        for a, b in zip(m0, m1):
+            assert np.array_equal(a, b)

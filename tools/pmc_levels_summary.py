@@ -37,7 +37,7 @@ def level_of(grid_size, wg=256):
 kernel_rows = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_pipe_kernel" in r["Kernel_Name"]:
+        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"]:
             lv = level_of(int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]))
             if lv is not None:
                 kernel_rows[lv].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
@@ -51,7 +51,7 @@ for lv, v in kernel_rows.items():
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_pipe_kernel" in r["Kernel_Name"]:
+        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"]:
             lv = level_of(int(r["Grid_Size"]))
             if lv is not None:
                 agg[lv][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -77,7 +77,11 @@ for lv, d in levels.items():
         d["wave_time_issuing_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
 out = {"tag": tag, "command": "bash tools/pmc_levels.sh %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set, "
                               "each over python3 tools/bench_levels_spmv.py 256 3 10)" % tag,
-       "matrix": "levels 0-2 of the 256^3 7-pt hierarchy (PMIS, ext+i(4))", "levels": {str(k): levels[k] for k in sorted(levels)}}
+       "matrix": "levels 0-2 of the 256^3 7-pt hierarchy (PMIS, ext+i(4))",
+       "note": "SQ_* cycle counters are in units of 4 cycles and sampled; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled "
+               "(gfx950 reports half of wide streaming reads, MI355X_MICROARCH.md); the x-staged kernel reads 8 + 2 bytes "
+               "per entry instead of CSR's 12, so its traffic may be below the algorithmic (CSR) byte count",
+       "levels": {str(k): levels[k] for k in sorted(levels)}}
 os.makedirs("profiles", exist_ok=True)
 json.dump(out, open(os.path.join("profiles", "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(out, indent=1))
