@@ -1,0 +1,379 @@
+// hypre_amd — extended+i interpolation on the device (single rank, scalar problems), bit-identical to the host setup.
+//
+// Reference: parcsr_ls/par_lr_interp.c:1024-1700 (hypre_BoomerAMGBuildExtPIInterpHost) and the truncation of
+// parcsr_mv/par_csr_matrix.c:2874-3400; restated for the host in par_amg_setup.cpp (hypre_BoomerAMGBuildExtPIInterp,
+// hypre_BoomerAMGInterpTruncation), whose loop order — the order in which a row's interpolatory set is discovered, the
+// order of every sum, the quicksort that picks the entries a truncated row keeps, ties included — this kernel follows
+// statement for statement, because the hierarchies the reference's regression files pin depend on those bits.
+// The reference's own device routine: parcsr_ls/par_lr_interp_device.c:1001 (a different formulation of the same weights).
+//
+// One wave owns a row.  What is sequential in the host loop stays sequential (the walk over the row's strong neighbours,
+// over the row's entries, every running sum); what the host does for the entries of ONE neighbour's row — look its
+// columns up in the row's column -> position map, append the new ones, add the distributed shares — the 64 lanes do side
+// by side, since those columns are distinct: appended in entry order (ballot + prefix count), sums over a neighbour's
+// row folded in entry order (one lane, values read lane by lane).  The map is an open-addressing table in LDS whose slots
+// carry the row's tag.
+#include "internal.hpp"
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace hamd {
+
+namespace {
+
+constexpr int ABSENT = -1, STRONG_F = -2;
+
+__device__ __forceinline__ int map_get(const unsigned long long *tab, const int *val, int mask, unsigned tag, int key)
+{
+   unsigned h = ((unsigned) key * 2654435761u) >> 7;
+   while (true)
+   {
+      const unsigned long long e = tab[h & mask];
+      if ((unsigned) (e >> 32) != tag) { return ABSENT; }
+      if ((int) (unsigned) e == key) { return val[h & mask]; }
+      h++;
+   }
+}
+
+// insert a key known to be absent, or overwrite the value of a present one (lanes work on distinct keys)
+__device__ __forceinline__ void map_set(unsigned long long *tab, int *val, int mask, unsigned tag, int key, int v)
+{
+   unsigned h = ((unsigned) key * 2654435761u) >> 7;
+   const unsigned long long mine = ((unsigned long long) tag << 32) | (unsigned) key;
+   while (true)
+   {
+      const unsigned long long e = tab[h & mask];
+      if ((unsigned) (e >> 32) != tag)
+      {
+         if (atomicCAS(&tab[h & mask], e, mine) == e) { val[h & mask] = v; return; }
+         continue;
+      }
+      if ((int) (unsigned) e == key) { val[h & mask] = v; return; }
+      h++;
+   }
+}
+
+__device__ __forceinline__ int below(unsigned long long ballot, int lane) { return __popcll(ballot & ((1ull << lane) - 1ull)); }
+
+// utilities/qsort.c:395-417 (decreasing |w|; the tie order is part of the contract), recursion unrolled on a stack:
+// the left part of a split is sorted before the right one, as the recursive routine does
+__device__ void qsort2_abs_dev(int *v, double *w, int n, int *stack)
+{
+   int top = 0;
+   stack[top++] = 0; stack[top++] = n - 1;
+   while (top > 0)
+   {
+      const int right = stack[--top], left = stack[--top];
+      if (left >= right) { continue; }
+      const int mid = (left + right) / 2;
+      { const int tv = v[left]; v[left] = v[mid]; v[mid] = tv; const double tw = w[left]; w[left] = w[mid]; w[mid] = tw; }
+      int last = left;
+      for (int i = left + 1; i <= right; i++)
+      {
+         if (fabs(w[i]) > fabs(w[left]))
+         {
+            ++last;
+            const int tv = v[last]; v[last] = v[i]; v[i] = tv; const double tw = w[last]; w[last] = w[i]; w[i] = tw;
+         }
+      }
+      { const int tv = v[left]; v[left] = v[last]; v[last] = tv; const double tw = w[left]; w[left] = w[last]; w[last] = tw; }
+      // push the right part first so that the left one is popped (sorted) first
+      stack[top++] = last + 1; stack[top++] = right;
+      stack[top++] = left;     stack[top++] = last - 1;
+   }
+}
+
+}  // namespace
+
+// MODE 0: row lengths only (no truncation by count is possible then: max_elmts == 0, tol == 0 handled by the caller);
+// MODE 1: write rows at out_off[i] (exact offsets) ; MODE 2: write rows at i * stride and their lengths to rowlen.
+template <int MODE>
+__global__ __launch_bounds__(64)
+void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa,
+                       const int *__restrict__ Si, const int *__restrict__ Sj, const int *__restrict__ CF,
+                       const int *__restrict__ f2c, double trunc_tol, int max_elmts, int capM, int capR,
+                       const int *__restrict__ out_off, int stride, int *__restrict__ rowlen,
+                       int *__restrict__ Pj, double *__restrict__ Pa, int *__restrict__ overflow)
+{
+   extern __shared__ __align__(16) unsigned char smem[];
+   unsigned long long *Mkey = reinterpret_cast<unsigned long long *>(smem);
+   double *pa = reinterpret_cast<double *>(Mkey + capM);
+   int *Mval = reinterpret_cast<int *>(pa + capR);
+   int *pj = Mval + capM;
+   int *stack = pj + capR;               // 4 * capR + 8 ints
+   const int lane = threadIdx.x;
+   for (int i = lane; i < capM; i += 64) { Mkey[i] = 0; }
+   __syncthreads();
+   const int mask = capM - 1;
+   unsigned tag = 0;
+
+   for (int i = blockIdx.x; i < n; i += gridDim.x)
+   {
+      tag++;
+      int len = 0;
+      bool bad = false;
+      const int cf_i = CF[i];
+      if (cf_i >= 0)
+      {
+         if (lane == 0) { pj[0] = f2c[i]; pa[0] = 1.0; }
+         len = 1;
+         __syncthreads();
+      }
+      else if (cf_i != -3)
+      {
+         // ---- the interpolatory set, in first-touch order
+         for (int jj = Si[i]; jj < Si[i + 1] && !bad; jj++)
+         {
+            const int i1 = Sj[jj];
+            const int cf1 = CF[i1];
+            if (cf1 >= 0)
+            {
+               const int m = map_get(Mkey, Mval, mask, tag, i1);
+               if (m < 0)
+               {
+                  if (len + 1 > capR) { bad = true; break; }
+                  if (lane == 0) { map_set(Mkey, Mval, mask, tag, i1, len); pj[len] = f2c[i1]; pa[len] = 0.0; }
+                  len++;
+               }
+               __syncthreads();
+            }
+            else if (cf1 != -3)
+            {
+               if (lane == 0) { map_set(Mkey, Mval, mask, tag, i1, STRONG_F); }
+               __syncthreads();
+               const int s0 = Si[i1], s1 = Si[i1 + 1];
+               for (int base = s0; base < s1; base += 64)
+               {
+                  const int kk = base + lane;
+                  const bool have = kk < s1;
+                  const int k1 = have ? Sj[kk] : 0;
+                  const bool isc = have && CF[k1] >= 0;
+                  const bool fresh = isc && map_get(Mkey, Mval, mask, tag, k1) < 0;
+                  const unsigned long long ball = __ballot(fresh);
+                  if (len + __popcll(ball) > capR) { bad = true; break; }
+                  if (fresh)
+                  {
+                     const int p = len + below(ball, lane);
+                     map_set(Mkey, Mval, mask, tag, k1, p);
+                     pj[p] = f2c[k1]; pa[p] = 0.0;
+                  }
+                  len += __popcll(ball);
+                  __syncthreads();
+               }
+            }
+         }
+         // ---- the weights
+         if (!bad && MODE != 0)
+         {
+            double diagonal = Aa[Ai[i]];
+            for (int jj = Ai[i] + 1; jj < Ai[i + 1]; jj++)
+            {
+               const int i1 = Aj[jj];
+               const double a = Aa[jj];
+               const int m = map_get(Mkey, Mval, mask, tag, i1);
+               if (m >= 0)
+               {
+                  if (lane == 0) { pa[m] += a; }
+                  __syncthreads();
+               }
+               else if (m == STRONG_F)
+               {
+                  const int b0 = Ai[i1] + 1, b1 = Ai[i1 + 1];
+                  const int sgn = Aa[Ai[i1]] < 0 ? -1 : 1;
+                  // sum of the couplings of i1 to the set (and to i itself) that have the sign opposite to its diagonal,
+                  // added in entry order
+                  double sum = 0.0;
+                  for (int base = b0; base < b1; base += 64)
+                  {
+                     const int j1 = base + lane;
+                     const bool have = j1 < b1;
+                     const int i2 = have ? Aj[j1] : 0;
+                     const double v = have ? Aa[j1] : 0.0;
+                     const bool take = have && (sgn * v) < 0 && (i2 == i || map_get(Mkey, Mval, mask, tag, i2) >= 0);
+                     unsigned long long ball = __ballot(take);
+                     while (ball)
+                     {
+                        const int b = __ffsll((long long) ball) - 1;
+                        sum += __shfl(v, b, 64);
+                        ball &= ball - 1;
+                     }
+                  }
+                  if (sum != 0)
+                  {
+                     const double distribute = a / sum;
+                     for (int base = b0; base < b1; base += 64)
+                     {
+                        const int j1 = base + lane;
+                        const bool have = j1 < b1;
+                        const int i2 = have ? Aj[j1] : 0;
+                        const double v = have ? Aa[j1] : 0.0;
+                        const bool neg = have && (sgn * v) < 0;
+                        const int m2 = neg ? map_get(Mkey, Mval, mask, tag, i2) : ABSENT;
+                        if (m2 >= 0) { pa[m2] += distribute * v; }
+                        // at most one entry of the row is i itself
+                        const unsigned long long self = __ballot(neg && i2 == i);
+                        if (self) { diagonal += distribute * __shfl(v, __ffsll((long long) self) - 1, 64); }
+                     }
+                     __syncthreads();
+                  }
+                  else { diagonal += a; }
+               }
+               else if (CF[i1] != -3) { diagonal += a; }       // weak neighbour: lumped into the diagonal
+            }
+            if (diagonal != 0.0) { for (int k = lane; k < len; k += 64) { pa[k] /= -diagonal; } }
+            __syncthreads();
+         }
+      }
+      if (bad) { if (lane == 0) { atomicExch(overflow, 1); } len = 0; }
+
+      // ---- truncation (par_csr_matrix.c:2874-3400 with rescale, inf-norm): relative threshold, then the max_elmts
+      // largest; one lane, the host's statement order
+      if (MODE != 0 && !bad && cf_i < 0 && cf_i != -3 && (trunc_tol > 0.0 || (max_elmts > 0 && max_elmts < len)))
+      {
+         if (lane == 0)
+         {
+            int d1 = len;
+            if (trunc_tol > 0.0)
+            {
+               double row_nrm = 0.0;
+               for (int k = 0; k < len; k++) { row_nrm = fmax(row_nrm, fabs(pa[k])); }
+               const double drop = trunc_tol * row_nrm;
+               double row_sum = 0.0, scale = 0.0;
+               int w = 0;
+               for (int k = 0; k < len; k++)
+               {
+                  row_sum += pa[k];
+                  if (!(fabs(pa[k]) < drop)) { scale += pa[k]; pa[w] = pa[k]; pj[w] = pj[k]; w++; }
+               }
+               d1 = w;
+               if (scale != 0. && scale != row_sum)
+               {
+                  scale = row_sum / scale;
+                  for (int k = 0; k < d1; k++) { pa[k] *= scale; }
+               }
+            }
+            if (max_elmts > 0 && max_elmts < d1)
+            {
+               double row_sum = 0.0;
+               for (int k = 0; k < d1; k++) { row_sum += pa[k]; }
+               qsort2_abs_dev(pj, pa, d1, stack);
+               double scale = 0.0;
+               for (int k = 0; k < max_elmts; k++) { scale += pa[k]; }
+               d1 = max_elmts;
+               if (scale != 0. && scale != row_sum)
+               {
+                  scale = row_sum / scale;
+                  for (int k = 0; k < d1; k++) { pa[k] *= scale; }
+               }
+            }
+            stack[0] = d1;
+         }
+         __syncthreads();
+         len = stack[0];
+         __syncthreads();
+      }
+
+      if (MODE == 0) { if (lane == 0) { rowlen[i] = len; } }
+      else
+      {
+         const size_t o = MODE == 1 ? (size_t) out_off[i] : (size_t) i * (size_t) stride;
+         if (MODE == 2 && lane == 0) { rowlen[i] = len; }
+         for (int k = lane; k < len; k += 64) { Pj[o + k] = pj[k]; Pa[o + k] = pa[k]; }
+      }
+      __syncthreads();
+   }
+}
+
+// rows written with a fixed stride -> CSR
+__global__ void compact_rows_kernel(int n, int stride, const int *__restrict__ Pi, const int *__restrict__ sj, const double *__restrict__ sa,
+                                    int *__restrict__ Pj, double *__restrict__ Pa)
+{
+   const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+   const int i = (int) (t / (size_t) stride), k = (int) (t % (size_t) stride);
+   if (i < n && k < Pi[i + 1] - Pi[i]) { Pj[Pi[i] + k] = sj[t]; Pa[Pi[i] + k] = sa[t]; }
+}
+
+static int pow2_ge(int v) { int p = 16; while (p < v) { p <<= 1; } return p; }
+
+// A (n x n, diagonal first), S (pattern), CF marker and fine -> coarse numbering on the device.  Returns false when a row's
+// interpolatory set does not fit LDS (the caller then uses the host loop).  The result arrays are device allocations.
+bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const int *Si, const int *Sj, const int *CF,
+                  const int *f2c, double trunc_tol, int max_elmts, int **Pi_out, int **Pj_out, double **Pa_out, int *nnz_out,
+                  hipStream_t s)
+{
+   if (max_elmts <= 0 && trunc_tol > 0.0) { return false; }     // lengths would depend on the weights: not built here
+   auto lds = [](int capM, int capR) { return (size_t) 8 * capM + 8 * capR + 4 * capM + 4 * capR + 4 * (4 * capR + 8) + 64; };
+   const size_t budget = 150 * 1024;
+   (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
+   (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
+   (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
+   int *d_flag = nullptr, *rowlen = nullptr;
+   HIP_CHECK(hipMalloc((void **) &d_flag, sizeof(int)));
+   HIP_CHECK(hipMalloc((void **) &rowlen, sizeof(int) * ((size_t) n + 1)));
+   const int waves = std::min(n, handle().num_cus * 32);
+   const bool fixed = max_elmts > 0;          // rows have at most max_elmts entries: one pass into strided storage
+   int *sj = nullptr;
+   double *sa = nullptr;
+   if (fixed)
+   {
+      HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * (size_t) n * (size_t) max_elmts));
+      HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * (size_t) n * (size_t) max_elmts));
+   }
+   int capR = 0, capM = 0, h_flag = 1;
+   for (int attempt = 0; attempt < 2 && h_flag; attempt++)
+   {
+      capR = attempt == 0 ? 256 : 1024;
+      // the map also holds the strong F neighbours of the row
+      capM = pow2_ge(4 * capR);
+      if (lds(capM, capR) > budget) { break; }
+      HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+      if (fixed)
+      {
+         hipLaunchKernelGGL((extpi_rows_kernel<2>), dim3(waves), dim3(64), lds(capM, capR), s, n, Ai, Aj, Aa, Si, Sj, CF, f2c, trunc_tol,
+                            max_elmts, capM, capR, (const int *) nullptr, max_elmts, rowlen, sj, sa, d_flag);
+      }
+      else
+      {
+         hipLaunchKernelGGL((extpi_rows_kernel<0>), dim3(waves), dim3(64), lds(capM, capR), s, n, Ai, Aj, Aa, Si, Sj, CF, f2c, trunc_tol,
+                            max_elmts, capM, capR, (const int *) nullptr, 0, rowlen, (int *) nullptr, (double *) nullptr, d_flag);
+      }
+      HIP_CHECK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+   }
+   auto give_up = [&]() { HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(rowlen)); if (sj) { HIP_CHECK(hipFree(sj)); } if (sa) { HIP_CHECK(hipFree(sa)); } return false; };
+   if (h_flag) { return give_up(); }
+   // row pointers (host scan of n lengths)
+   std::vector<int> hl((size_t) n + 1, 0);
+   HIP_CHECK(hipMemcpyAsync(hl.data(), rowlen, sizeof(int) * (size_t) n, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   long long run = 0;
+   for (int i = 0; i < n; i++) { const int l = hl[(size_t) i]; hl[(size_t) i] = (int) run; run += l; }
+   hl[(size_t) n] = (int) run;
+   if (run > 0x7fffffffLL) { return give_up(); }
+   const int nnz = (int) run;
+   int *Pi = rowlen, *Pj = nullptr;
+   double *Pa = nullptr;
+   HIP_CHECK(hipMemcpyAsync(Pi, hl.data(), sizeof(int) * ((size_t) n + 1), hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipMalloc((void **) &Pj, sizeof(int) * (size_t) std::max(nnz, 1)));
+   HIP_CHECK(hipMalloc((void **) &Pa, sizeof(double) * (size_t) std::max(nnz, 1)));
+   if (fixed)
+   {
+      const size_t tot = (size_t) n * (size_t) max_elmts;
+      hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned) ((tot + 255) / 256)), dim3(256), 0, s, n, max_elmts, Pi, sj, sa, Pj, Pa);
+   }
+   else
+   {
+      HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+      hipLaunchKernelGGL((extpi_rows_kernel<1>), dim3(waves), dim3(64), lds(capM, capR), s, n, Ai, Aj, Aa, Si, Sj, CF, f2c, trunc_tol,
+                         max_elmts, capM, capR, Pi, 0, (int *) nullptr, Pj, Pa, d_flag);
+   }
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(d_flag));
+   if (sj) { HIP_CHECK(hipFree(sj)); }
+   if (sa) { HIP_CHECK(hipFree(sa)); }
+   *Pi_out = Pi; *Pj_out = Pj; *Pa_out = Pa; *nnz_out = nnz;
+   return true;
+}
+
+}  // namespace hamd

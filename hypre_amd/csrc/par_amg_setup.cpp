@@ -639,6 +639,37 @@ static void coarse_parms(MPI_Comm comm, HYPRE_Int n, const HYPRE_Int *CF, HYPRE_
    else { cpts_global[0] = 0; cpts_global[1] = local; *total = local; }
 }
 
+// set by hypre_BoomerAMGSetup while it builds a hierarchy whose home is device memory
+static bool g_setup_targets_device = false;
+static int  g_device_rap_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_RAP"); return e ? atoi(e) : 1; }();
+static int  g_device_rap_min_rows = 20000;
+static int  g_device_rap_count = 0;          // products formed on the device since the last query
+
+// Galerkin products of single-rank setups whose hierarchy lives in device memory are formed on the device (same bits as
+// the host loop): on = 0 keeps the host loop, min_rows = smallest fine level worth the transfers (negative: unchanged).
+// Returns the number of products formed on the device since the previous call.
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows)
+{
+   if (on >= 0) { g_device_rap_on = on; }
+   if (min_rows >= 0) { g_device_rap_min_rows = min_rows; }
+   const int c = g_device_rap_count;
+   g_device_rap_count = 0;
+   return c;
+}
+static bool device_rap_allowed() { return g_setup_targets_device; }
+static bool device_setup_allowed() { return g_setup_targets_device; }
+static int  g_device_interp_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_INTERP"); return e ? atoi(e) : 1; }();
+static int  g_device_interp_count = 0;
+// same for the extended+i interpolation: on = 0 keeps the host loop; returns the number of operators built on the device
+// since the previous call
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on)
+{
+   if (on >= 0) { g_device_interp_on = on; }
+   const int c = g_device_interp_count;
+   g_device_interp_count = 0;
+   return c;
+}
+
 // ===========================================================================
 // truncation of P (par_csr_matrix.c:2874-3400 with rescale = 1, inf-norm)
 // ===========================================================================
@@ -793,6 +824,40 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
    {
       HYPRE_Int c = 0;
       for (HYPRE_Int i = 0; i < n; i++) { if (CF_marker[i] >= 0) { f2c[(size_t) i] = c++; } }
+   }
+   // On the device when the hierarchy's home is device memory (interp_kernels.hip: one wave per row, this loop's order,
+   // same bits; hypre_amd_SetSetupDeviceInterp(0) keeps the host loop)
+   if (!sys && g_device_interp_on && device_setup_allowed() && n >= g_device_rap_min_rows && Ad->num_nonzeros > 0 &&
+       Ad->memory_location == HYPRE_MEMORY_HOST && ensure_device())
+   {
+      hipStream_t st = stream();
+      hypre_CSRMatrix *dA = hypre_CSRMatrixClone_v2(Ad, 1, HYPRE_MEMORY_DEVICE);
+      hypre_CSRMatrix *dS = hypre_CSRMatrixClone_v2(S->diag, 0, HYPRE_MEMORY_DEVICE);
+      HYPRE_Int *dCF = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE), *dF2C = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE);
+      hypre_TMemcpy(dCF, CF_marker, HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      hypre_TMemcpy(dF2C, f2c.data(), HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      int *dPi = nullptr, *dPj = nullptr, pnnz = 0;
+      double *dPa = nullptr;
+      const bool ok = device_extpi(n, dA->i, dA->j, dA->data, dS->i, dS->j, dCF, dF2C, trunc_factor, max_elmts, &dPi, &dPj, &dPa, &pnnz, st);
+      hypre_CSRMatrixDestroy(dA); hypre_CSRMatrixDestroy(dS);
+      hypre_Free(dCF, HYPRE_MEMORY_DEVICE); hypre_Free(dF2C, HYPRE_MEMORY_DEVICE);
+      if (ok)
+      {
+         HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
+         hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_cpts, A->col_starts, cs, 0, pnnz, 0);
+         hypre_ParCSRMatrixInitialize_v2(P, HYPRE_MEMORY_HOST);
+         hypre_TMemcpy(P->diag->i, dPi, HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+         if (pnnz > 0)
+         {
+            hypre_TMemcpy(P->diag->j, dPj, HYPRE_Int, (size_t) pnnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+            hypre_TMemcpy(P->diag->data, dPa, HYPRE_Real, (size_t) pnnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+         }
+         HIP_CHECK(hipFree(dPi)); HIP_CHECK(hipFree(dPj)); HIP_CHECK(hipFree(dPa));
+         hypre_CSRMatrixSetRownnz(P->offd);
+         *P_ptr = P;
+         g_device_interp_count++;
+         return hypre_error_flag;
+      }
    }
    const int T = num_threads_avail();
    std::vector<std::vector<HYPRE_Int>> tj((size_t) T);
@@ -1079,24 +1144,7 @@ HYPRE_Int hypre_BoomerAMGBuildDirInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_mar
 // still runs.  HYPRE_AMD_SETUP_DEVICE_RAP=0 keeps the host loop (tests compare the two).  Returns false when the
 // product was not formed here.
 // ===========================================================================
-// set by hypre_BoomerAMGSetup while it builds a hierarchy whose home is device memory
-static bool g_setup_targets_device = false;
-static int  g_device_rap_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_RAP"); return e ? atoi(e) : 1; }();
-static int  g_device_rap_min_rows = 20000;
-static int  g_device_rap_count = 0;          // products formed on the device since the last query
 
-// Galerkin products of single-rank setups whose hierarchy lives in device memory are formed on the device (same bits as
-// the host loop): on = 0 keeps the host loop, min_rows = smallest fine level worth the transfers (negative: unchanged).
-// Returns the number of products formed on the device since the previous call.
-extern "C" HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows)
-{
-   if (on >= 0) { g_device_rap_on = on; }
-   if (min_rows >= 0) { g_device_rap_min_rows = min_rows; }
-   const int c = g_device_rap_count;
-   g_device_rap_count = 0;
-   return c;
-}
-static bool device_rap_allowed() { return g_setup_targets_device; }
 
 static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
                                     HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr)

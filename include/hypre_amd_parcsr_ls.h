@@ -253,6 +253,10 @@ HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_th
  * unchanged.  Returns the number of products formed on the device since the previous call.  The reference's device setup:
  * parcsr_mv/par_csr_triplemat.c:938-960. */
 HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows);
+/* The same for the extended+i interpolation operators (interp_kernels.hip; scalar problems, levels of at least min_rows
+ * rows): on = 0 keeps the host loop; returns the number built on the device since the previous call.  The reference's
+ * device routine: parcsr_ls/par_lr_interp_device.c:1001. */
+HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on);
 /* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows, default 100000; 0: off) is recorded once as a
  * HIP graph and replayed: its kernels are a few microseconds each behind launches that cost as much.  No reference
  * counterpart (the reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded

@@ -486,6 +486,7 @@ def test_device_galerkin_product_is_the_host_product(gpu_lib, kw):
     hier = []
     for on in (0, 1):
         lib.hypre_amd_SetSetupDeviceRAP(on, 50)
+        lib.hypre_amd_SetSetupDeviceInterp(0)
         opt = ij.IJOptions(relax_type=18, **dict(dict(coarsen_type=8), **kw))
         A = ij.build_matrix(opt)
         s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
@@ -504,6 +505,48 @@ def test_device_galerkin_product_is_the_host_product(gpu_lib, kw):
         hier.append(lv)
         lib.HYPRE_BoomerAMGDestroy(s)
     lib.hypre_amd_SetSetupDeviceRAP(1, 20000)
+    lib.hypre_amd_SetSetupDeviceInterp(1)
+    assert len(hier[0]) == len(hier[1])
+    for m0, m1 in zip(hier[0], hier[1]):
+        for a, b in zip(m0, m1):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(n=(40, 39, 38)), dict(n=(30, 30, 30), problem="27pt"),
+                                dict(n=(36, 35, 34), problem="difconv", c=(1.0, 1.0, 0.001), a=(0.0, 0.0, 0.0)),
+                                dict(n=(34, 33, 32), coarsen_type=10, P_max_elmts=0),
+                                dict(n=(30, 30, 30), problem="27pt", P_max_elmts=6, trunc_factor=0.1),
+                                dict(n=(40, 40, 20), P_max_elmts=2),
+                                dict(n=(32, 32, 32), problem="difconv", c=(1.0, 0.01, 1.0), a=(3.0, 2.0, 1.0), P_max_elmts=0)])
+def test_device_interpolation_is_the_host_interpolation(gpu_lib, kw):
+    """Setup with the extended+i interpolation (and its truncation) computed on the device — one wave per row, the host
+    loop's statement order — and on the host: every interpolation operator and every coarse operator identical array
+    for array (column order included: the truncated rows keep the order the reference's quicksort leaves them in)."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    hier = []
+    for on in (0, 1):
+        lib.hypre_amd_SetSetupDeviceRAP(0, 50)
+        lib.hypre_amd_SetSetupDeviceInterp(on)
+        opt = ij.IJOptions(relax_type=18, **dict(dict(coarsen_type=8), **kw))
+        A = ij.build_matrix(opt)
+        s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+        lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+        B.check()
+        built = lib.hypre_amd_SetSetupDeviceInterp(-1)
+        nl = lib.hypre_amd_BoomerAMGGetNumLevels(s)
+        assert (built >= 2) if on else (built == 0), (on, built, nl)
+        lv = []
+        for l in range(nl):
+            Al = C.cast(lib.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
+            lv.append(B.csr_to_arrays(Al.contents.diag))
+            if l < nl - 1:
+                Pl = C.cast(lib.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+                lv.append(B.csr_to_arrays(Pl.contents.diag))
+        hier.append(lv)
+        lib.HYPRE_BoomerAMGDestroy(s)
+    lib.hypre_amd_SetSetupDeviceRAP(1, 20000)
+    lib.hypre_amd_SetSetupDeviceInterp(1)
     assert len(hier[0]) == len(hier[1])
     for m0, m1 in zip(hier[0], hier[1]):
         for a, b in zip(m0, m1):
