@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <omp.h>
+#include <unordered_map>
 
 using namespace hamd;
 
@@ -307,7 +308,24 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
    std::vector<double> measure((size_t) n + nco, 0.0);
    for (HYPRE_Int k = 0; k < Soi[n]; k++) { measure[(size_t) n + Soj[k]] += 1.0; }
    if (pkg) { halo_reverse<double>(pkg, measure.data() + n, buf.data()); }
-   for (HYPRE_Int k = 0; k < Sdi[n]; k++) { measure[(size_t) Sdj[k]] += 1.0; }
+   // (column counts of S: whole numbers, so the order in which the ones are added does not matter — rows in parallel;
+   // every loop of the independent-set iteration below is order-independent as well: a point's fate depends on the
+   // measures, which the sweeps do not change, and on which neighbours are in the set, which only grows between sweeps.
+   // The reference runs them sequentially, par_coarsen.c:2100-2600; 16.8 M rows took a second that way.)
+   if (n > 100000)
+   {
+#pragma omp parallel for schedule(static)
+      for (HYPRE_Int i = 0; i < n; i++)
+      {
+         for (HYPRE_Int k = Sdi[i]; k < Sdi[i + 1]; k++)
+         {
+            double &m = measure[(size_t) Sdj[k]];
+#pragma omp atomic
+            m += 1.0;
+         }
+      }
+   }
+   else { for (HYPRE_Int k = 0; k < Sdi[n]; k++) { measure[(size_t) Sdj[k]] += 1.0; } }
    for (HYPRE_Int k = 0; k < tot_send; k++) { measure[(size_t) pkg->send_map_elmts[k]] += buf[(size_t) k]; }
    for (HYPRE_Int k = n; k < n + nco; k++) { measure[(size_t) k] = 0; }
    {
@@ -373,6 +391,7 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
       if (global_sum_big(comm, graph_size) == 0) { break; }
       if (!CF_init || iter)
       {
+#pragma omp parallel for schedule(static) if (graph_size > 100000)
          for (HYPRE_Int ig = 0; ig < graph_size; ig++)
          {
             const HYPRE_Int i = graph[(size_t) ig];
@@ -383,7 +402,9 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
             const HYPRE_Int i = graph_offd[(size_t) ig];
             if (measure[(size_t) i + n] > 1) { CF_offd[(size_t) i] = 1; }
          }
-         // knock the smaller of two strongly connected candidates out of the set
+         // knock the smaller of two strongly connected candidates out of the set (rows in parallel: the only writes are
+         // zeros, decided by measures alone)
+#pragma omp parallel for schedule(static) if (graph_size > 100000)
          for (HYPRE_Int ig = 0; ig < graph_size; ig++)
          {
             const HYPRE_Int i = graph[(size_t) ig];
@@ -394,8 +415,8 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
                   const HYPRE_Int j = Sdj[jS];
                   if (measure[(size_t) j] > 1)
                   {
-                     if (measure[(size_t) i] > measure[(size_t) j]) { CF[j] = 0; }
-                     else if (measure[(size_t) j] > measure[(size_t) i]) { CF[i] = 0; }
+                     if (measure[(size_t) i] > measure[(size_t) j]) { __atomic_store_n(&CF[j], 0, __ATOMIC_RELAXED); }
+                     else if (measure[(size_t) j] > measure[(size_t) i]) { __atomic_store_n(&CF[i], 0, __ATOMIC_RELAXED); }
                   }
                }
                for (HYPRE_Int jS = Soi[i]; jS < Soi[i + 1]; jS++)
@@ -404,8 +425,8 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
                   const HYPRE_Int j = n + jj;
                   if (measure[(size_t) j] > 1)
                   {
-                     if (measure[(size_t) i] > measure[(size_t) j]) { CF_offd[(size_t) jj] = 0; }
-                     else if (measure[(size_t) j] > measure[(size_t) i]) { CF[i] = 0; }
+                     if (measure[(size_t) i] > measure[(size_t) j]) { __atomic_store_n(&CF_offd[(size_t) jj], 0, __ATOMIC_RELAXED); }
+                     else if (measure[(size_t) j] > measure[(size_t) i]) { __atomic_store_n(&CF[i], 0, __ATOMIC_RELAXED); }
                   }
                }
             }
@@ -424,16 +445,21 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
          }
       }
       iter++;
+      // (rows in parallel: "CF[j] > 0" — j is in the set — cannot change during this sweep: a point in the set keeps a
+      // positive marker, a point outside it can only be written -1)
+#pragma omp parallel for schedule(static) if (graph_size > 100000)
       for (HYPRE_Int ig = 0; ig < graph_size; ig++)
       {
          const HYPRE_Int i = graph[(size_t) ig];
-         if (measure[(size_t) i] < 1) { CF[i] = F_PT; }
-         if (CF[i] > 0) { CF[i] = C_PT; }
+         HYPRE_Int mine = __atomic_load_n(&CF[i], __ATOMIC_RELAXED);
+         if (measure[(size_t) i] < 1) { mine = F_PT; }
+         if (mine > 0) { mine = C_PT; }
          else
          {
-            for (HYPRE_Int jS = Sdi[i]; jS < Sdi[i + 1]; jS++) { if (CF[Sdj[jS]] > 0) { CF[i] = F_PT; } }
-            for (HYPRE_Int jS = Soi[i]; jS < Soi[i + 1]; jS++) { if (CF_offd[(size_t) Soj[jS]] > 0) { CF[i] = F_PT; } }
+            for (HYPRE_Int jS = Sdi[i]; jS < Sdi[i + 1]; jS++) { if (__atomic_load_n(&CF[Sdj[jS]], __ATOMIC_RELAXED) > 0) { mine = F_PT; } }
+            for (HYPRE_Int jS = Soi[i]; jS < Soi[i + 1]; jS++) { if (CF_offd[(size_t) Soj[jS]] > 0) { mine = F_PT; } }
          }
+         __atomic_store_n(&CF[i], mine, __ATOMIC_RELAXED);
       }
       if (pkg) { halo_forward<HYPRE_Int>(pkg, CF, CF_offd.data()); }
       HYPRE_Int g2 = 0, go2 = 0;
@@ -658,6 +684,64 @@ extern "C" HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_row
 }
 static bool device_rap_allowed() { return g_setup_targets_device; }
 static bool device_setup_allowed() { return g_setup_targets_device; }
+
+// Device twins of host matrices made during a device-targeted setup (operators uploaded for, or produced by, the device
+// kernels).  A later step that needs the same matrix on the device takes the twin instead of uploading again, and when
+// the finished hierarchy moves to device memory a matrix with a twin simply adopts its arrays.  Twins nobody adopted are
+// freed when the setup ends.
+static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> &device_twins()
+{
+   static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> t;
+   return t;
+}
+static hypre_CSRMatrix *device_twin_of(hypre_CSRMatrix *host, int with_data)
+{
+   auto &t = device_twins();
+   auto it = t.find(host);
+   if (it != t.end()) { return it->second; }
+   hypre_CSRMatrix *d = hypre_CSRMatrixClone_v2(host, with_data, HYPRE_MEMORY_DEVICE);
+   t[host] = d;
+   return d;
+}
+static void drop_device_twins()
+{
+   for (auto &kv : device_twins()) { hypre_CSRMatrixDestroy(kv.second); }
+   device_twins().clear();
+}
+// device CSR from arrays that already live on the device (ownership passes to the matrix)
+static hypre_CSRMatrix *wrap_device_csr(HYPRE_Int nr, HYPRE_Int ncl, HYPRE_Int nnz, int *i, int *j, double *a)
+{
+   hypre_CSRMatrix *m = hypre_CSRMatrixCreate(nr, ncl, nnz);
+   m->i = i; m->j = j; m->data = a; m->memory_location = HYPRE_MEMORY_DEVICE; m->owns_data = 1;
+   return m;
+}
+// host -> device for one block of the finished hierarchy: adopt the twin's arrays when there is one
+static void place_on_device(hypre_CSRMatrix *M)
+{
+   auto &t = device_twins();
+   auto it = M ? t.find(M) : t.end();
+   if (it == t.end() || M->memory_location != HYPRE_MEMORY_HOST) { if (M) { hypre_CSRMatrixMigrate(M, HYPRE_MEMORY_DEVICE); } return; }
+   hypre_CSRMatrix *d = it->second;
+   t.erase(it);
+   hypre_Free(M->i, HYPRE_MEMORY_HOST); hypre_Free(M->j, HYPRE_MEMORY_HOST); hypre_Free(M->data, HYPRE_MEMORY_HOST);
+   M->i = d->i; M->j = d->j; M->data = d->data;
+   M->memory_location = HYPRE_MEMORY_DEVICE;
+   d->i = nullptr; d->j = nullptr; d->data = nullptr;
+   hypre_CSRMatrixDestroy(d);
+}
+// device -> fresh host arrays of n items: the destination pages are touched by all threads first (a copy into untouched
+// memory faults them in one by one on one thread: 1.8 GB took 0.4 s that way)
+static void download_bytes(void *host, const void *dev, size_t bytes)
+{
+   if (bytes > (size_t) 1 << 24)
+   {
+      char *p = (char *) host;
+#pragma omp parallel for schedule(static)
+      for (long long o = 0; o < (long long) bytes; o += 4096) { p[o] = 0; }
+   }
+   hypre_Memcpy(host, (void *) dev, bytes, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+}
+#define download(host, dev, n) download_bytes((host), (dev), sizeof(*(host)) * (size_t) (n))
 static int  g_device_interp_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_INTERP"); return e ? atoi(e) : 1; }();
 static int  g_device_interp_count = 0;
 // same for the extended+i interpolation: on = 0 keeps the host loop; returns the number of operators built on the device
@@ -831,7 +915,7 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
        Ad->memory_location == HYPRE_MEMORY_HOST && ensure_device())
    {
       hipStream_t st = stream();
-      hypre_CSRMatrix *dA = hypre_CSRMatrixClone_v2(Ad, 1, HYPRE_MEMORY_DEVICE);
+      hypre_CSRMatrix *dA = device_twin_of(Ad, 1);
       hypre_CSRMatrix *dS = hypre_CSRMatrixClone_v2(S->diag, 0, HYPRE_MEMORY_DEVICE);
       HYPRE_Int *dCF = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE), *dF2C = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE);
       hypre_TMemcpy(dCF, CF_marker, HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
@@ -839,20 +923,20 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       int *dPi = nullptr, *dPj = nullptr, pnnz = 0;
       double *dPa = nullptr;
       const bool ok = device_extpi(n, dA->i, dA->j, dA->data, dS->i, dS->j, dCF, dF2C, trunc_factor, max_elmts, &dPi, &dPj, &dPa, &pnnz, st);
-      hypre_CSRMatrixDestroy(dA); hypre_CSRMatrixDestroy(dS);
+      hypre_CSRMatrixDestroy(dS);
       hypre_Free(dCF, HYPRE_MEMORY_DEVICE); hypre_Free(dF2C, HYPRE_MEMORY_DEVICE);
       if (ok)
       {
          HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
          hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_cpts, A->col_starts, cs, 0, pnnz, 0);
          hypre_ParCSRMatrixInitialize_v2(P, HYPRE_MEMORY_HOST);
-         hypre_TMemcpy(P->diag->i, dPi, HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+         download(P->diag->i, dPi, (size_t) n + 1);
          if (pnnz > 0)
          {
-            hypre_TMemcpy(P->diag->j, dPj, HYPRE_Int, (size_t) pnnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
-            hypre_TMemcpy(P->diag->data, dPa, HYPRE_Real, (size_t) pnnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+            download(P->diag->j, dPj, (size_t) pnnz);
+            download(P->diag->data, dPa, (size_t) pnnz);
          }
-         HIP_CHECK(hipFree(dPi)); HIP_CHECK(hipFree(dPj)); HIP_CHECK(hipFree(dPa));
+         device_twins()[P->diag] = wrap_device_csr(n, (HYPRE_Int) (cs[1] - cs[0]), pnnz, dPi, dPj, dPa);     // the Galerkin product and the finished hierarchy use it
          hypre_CSRMatrixSetRownnz(P->offd);
          *P_ptr = P;
          g_device_interp_count++;
@@ -1155,34 +1239,44 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
    if (nf < g_device_rap_min_rows || A->diag->num_nonzeros <= 0 || P->diag->num_nonzeros <= 0) { return false; }   // small levels: the host loop is quicker than the transfers
    if (!ensure_device()) { return false; }
    hipStream_t s = stream();
-   hypre_CSRMatrix *dA = hypre_CSRMatrixClone_v2(A->diag, 1, HYPRE_MEMORY_DEVICE);
-   hypre_CSRMatrix *dP = hypre_CSRMatrixClone_v2(P->diag, 1, HYPRE_MEMORY_DEVICE);
+   const bool timing = getenv("HYPRE_AMD_SETUP_TIMING") != nullptr;
+   const double t0 = omp_get_wtime();
+   hypre_CSRMatrix *dA = device_twin_of(A->diag, 1);
+   hypre_CSRMatrix *dP = device_twin_of(P->diag, 1);
+   const double t1 = omp_get_wtime();
    hypre_CSRMatrix *dR = nullptr;
    hypre_CSRMatrixTranspose(dP, &dR, 1);            // device transpose: rows of R list the fine rows in ascending order, as the host's
+   const double t2 = omp_get_wtime();
    int maxP = 0;
    for (HYPRE_Int i = 0; i < nf; i++) { maxP = std::max(maxP, (int) (P->diag->i[i + 1] - P->diag->i[i])); }
    int *Ci = nullptr, *Cj = nullptr, nnz = 0;
    double *Ca = nullptr;
    const bool ok = device_rap(nc, nc, maxP, dR->i, dR->j, dR->data, dA->i, dA->j, dA->data, dP->i, dP->j, dP->data, &Ci, &Cj, &Ca, &nnz, s);
-   hypre_CSRMatrixDestroy(dA);
-   hypre_CSRMatrixDestroy(dP);
+   const double t3 = omp_get_wtime();
    if (!ok) { hypre_CSRMatrixDestroy(dR); return false; }
    hypre_ParCSRMatrix *C = hypre_ParCSRMatrixCreate(A->comm, RT->global_num_cols, P->global_num_cols, RT->col_starts,
                                                     P->col_starts, 0, nnz, 0);
    hypre_ParCSRMatrixInitialize_v2(C, HYPRE_MEMORY_HOST);
-   hypre_TMemcpy(C->diag->i, Ci, HYPRE_Int, (size_t) nc + 1, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+   download(C->diag->i, Ci, (size_t) nc + 1);
    if (nnz > 0)
    {
-      hypre_TMemcpy(C->diag->j, Cj, HYPRE_Int, (size_t) nnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
-      hypre_TMemcpy(C->diag->data, Ca, HYPRE_Real, (size_t) nnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      download(C->diag->j, Cj, (size_t) nnz);
+      download(C->diag->data, Ca, (size_t) nnz);
    }
-   HIP_CHECK(hipFree(Ci)); HIP_CHECK(hipFree(Cj)); HIP_CHECK(hipFree(Ca));
-   if (keepTranspose) { hypre_CSRMatrixMigrate(dR, HYPRE_MEMORY_HOST); RT->diagT = dR; } else { hypre_CSRMatrixDestroy(dR); }
+   device_twins()[C->diag] = wrap_device_csr(nc, nc, nnz, Ci, Cj, Ca);      // next level's interpolation and product, finished hierarchy
+   if (keepTranspose)
+   {
+      hypre_CSRMatrix *hR = hypre_CSRMatrixClone_v2(dR, 1, HYPRE_MEMORY_HOST);
+      RT->diagT = hR;
+      device_twins()[hR] = dR;
+   }
+   else { hypre_CSRMatrixDestroy(dR); }
    hypre_CSRMatrixSetRownnz(C->offd);
    hypre_ParCSRMatrixSetNumNonzeros(C);
    hypre_ParCSRMatrixSetDNumNonzeros(C);
    *RAP_ptr = C;
    g_device_rap_count++;
+   if (timing) { fprintf(stderr, "   device RAP: upload %.3fs  transpose %.3fs  product %.3fs  download+rest %.3fs\n", t1 - t0, t2 - t1, t3 - t2, omp_get_wtime() - t3); }
    return true;
 }
 
@@ -1569,6 +1663,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       return hypre_error_flag;
    }
    g_setup_targets_device = (target == HYPRE_MEMORY_DEVICE);
+   drop_device_twins();
    const int max_levels = d->max_levels;
    d->A = A;
    d->A_array = (hypre_ParCSRMatrix **) calloc((size_t) max_levels, sizeof(void *));
@@ -1875,11 +1970,18 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    {
       for (int l = 0; l < num_levels; l++)
       {
-         if (l > 0) { hypre_ParCSRMatrixMigrate(d->A_array[l], HYPRE_MEMORY_DEVICE); }
+         auto place = [&](hypre_ParCSRMatrix *M)
+         {
+            place_on_device(M->diag);
+            hypre_CSRMatrixMigrate(M->offd, HYPRE_MEMORY_DEVICE);
+            if (M->diagT) { place_on_device(M->diagT); }
+            if (M->offdT) { hypre_CSRMatrixMigrate(M->offdT, HYPRE_MEMORY_DEVICE); }
+         };
+         if (l > 0) { place(d->A_array[l]); }
          if (l < num_levels - 1)
          {
             hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]);
-            hypre_ParCSRMatrixMigrate(d->P_array[l], HYPRE_MEMORY_DEVICE);
+            place(d->P_array[l]);
          }
          if (l > 0)
          {
@@ -1906,6 +2008,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    {
       for (int l = 0; l < num_levels - 1; l++) { hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]); }
    }
+   drop_device_twins();
    if (own_host_A0) { hypre_ParCSRMatrixDestroy(hostA[0]); }
    omp_set_num_threads(saved_omp_threads);
    return hypre_error_flag;
