@@ -696,6 +696,7 @@ static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> &device_tw
 }
 static hypre_CSRMatrix *device_twin_of(hypre_CSRMatrix *host, int with_data)
 {
+   if (host->memory_location == HYPRE_MEMORY_DEVICE) { return host; }      // born on the device (an interpolation operator)
    auto &t = device_twins();
    auto it = t.find(host);
    if (it != t.end()) { return it->second; }
@@ -927,16 +928,13 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       hypre_Free(dCF, HYPRE_MEMORY_DEVICE); hypre_Free(dF2C, HYPRE_MEMORY_DEVICE);
       if (ok)
       {
+         // the operator stays where it was made: nothing on the host reads it (the Galerkin product that follows runs
+         // on the device as well; should that fall back to the host loop, it fetches a copy)
          HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
          hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_cpts, A->col_starts, cs, 0, pnnz, 0);
-         hypre_ParCSRMatrixInitialize_v2(P, HYPRE_MEMORY_HOST);
-         download(P->diag->i, dPi, (size_t) n + 1);
-         if (pnnz > 0)
-         {
-            download(P->diag->j, dPj, (size_t) pnnz);
-            download(P->diag->data, dPa, (size_t) pnnz);
-         }
-         device_twins()[P->diag] = wrap_device_csr(n, (HYPRE_Int) (cs[1] - cs[0]), pnnz, dPi, dPj, dPa);     // the Galerkin product and the finished hierarchy use it
+         hypre_CSRMatrixDestroy(P->diag);
+         P->diag = wrap_device_csr(n, (HYPRE_Int) (cs[1] - cs[0]), pnnz, dPi, dPj, dPa);
+         hypre_CSRMatrixInitialize_v2(P->offd, 0, HYPRE_MEMORY_HOST);
          hypre_CSRMatrixSetRownnz(P->offd);
          *P_ptr = P;
          g_device_interp_count++;
@@ -1234,7 +1232,7 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
                                     HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr)
 {
    if (!g_device_rap_on || !device_rap_allowed() || RT != P) { return false; }
-   if (A->diag->memory_location != HYPRE_MEMORY_HOST || P->diag->memory_location != HYPRE_MEMORY_HOST) { return false; }
+   if (A->diag->memory_location != HYPRE_MEMORY_HOST) { return false; }
    const HYPRE_Int nf = A->diag->num_rows, nc = P->diag->num_cols;
    if (nf < g_device_rap_min_rows || A->diag->num_nonzeros <= 0 || P->diag->num_nonzeros <= 0) { return false; }   // small levels: the host loop is quicker than the transfers
    if (!ensure_device()) { return false; }
@@ -1248,7 +1246,8 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
    hypre_CSRMatrixTranspose(dP, &dR, 1);            // device transpose: rows of R list the fine rows in ascending order, as the host's
    const double t2 = omp_get_wtime();
    int maxP = 0;
-   for (HYPRE_Int i = 0; i < nf; i++) { maxP = std::max(maxP, (int) (P->diag->i[i + 1] - P->diag->i[i])); }
+   if (P->diag->memory_location == HYPRE_MEMORY_DEVICE) { maxP = device_max_row_nnz(P->diag->i, nf, s); }
+   else { for (HYPRE_Int i = 0; i < nf; i++) { maxP = std::max(maxP, (int) (P->diag->i[i + 1] - P->diag->i[i])); } }
    int *Ci = nullptr, *Cj = nullptr, nnz = 0;
    double *Ca = nullptr;
    const bool ok = device_rap(nc, nc, maxP, dR->i, dR->j, dR->data, dA->i, dA->j, dA->data, dP->i, dP->j, dP->data, &Ci, &Cj, &Ca, &nnz, s);
@@ -1264,12 +1263,7 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
       download(C->diag->data, Ca, (size_t) nnz);
    }
    device_twins()[C->diag] = wrap_device_csr(nc, nc, nnz, Ci, Cj, Ca);      // next level's interpolation and product, finished hierarchy
-   if (keepTranspose)
-   {
-      hypre_CSRMatrix *hR = hypre_CSRMatrixClone_v2(dR, 1, HYPRE_MEMORY_HOST);
-      RT->diagT = hR;
-      device_twins()[hR] = dR;
-   }
+   if (keepTranspose) { RT->diagT = dR; }          // the restriction operator is used on the device only
    else { hypre_CSRMatrixDestroy(dR); }
    hypre_CSRMatrixSetRownnz(C->offd);
    hypre_ParCSRMatrixSetNumNonzeros(C);
@@ -1292,6 +1286,7 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
    MPI_Comm comm = A->comm;
    if (comm_size(comm) > 1) { return dist_build_coarse_operator(RT, A, P, keepTranspose, RAP_ptr); }
    if (device_galerkin_product(RT, A, P, keepTranspose, RAP_ptr)) { return hypre_error_flag; }
+   if (P->diag->memory_location == HYPRE_MEMORY_DEVICE) { hypre_CSRMatrixMigrate(P->diag, HYPRE_MEMORY_HOST); }     // made on the device, needed here
    hypre_CSRMatrix *R = nullptr;
    hypre_CSRMatrixTranspose(RT->diag, &R, 1);
    const HYPRE_Int nc = R->num_rows, nf = A->diag->num_rows;
