@@ -133,7 +133,8 @@ enum SpmvOp
    OP_AXPBY   = 0,  // y = alpha*(A x) + beta*b
    OP_JACOBI  = 1,  // y = x + w*(b - A x)./d          (b=f, d=l1 or diag vector)
    OP_JACOBI_CF = 2, // same, rows with marker!=pts copy x
-   OP_TSGS    = 3   // y = (A_fill x)./d ; aux += alpha*y   (two-stage GS inner step)
+   OP_TSGS    = 3,  // y = (A_fill x)./d ; aux += alpha*y   (two-stage GS inner step)
+   OP_JACOBI_MAP = 4 // OP_JACOBI on the rows rowmap[] names (marker optional): sweeps over one colour's rows
 };
 
 struct SpmvArgs

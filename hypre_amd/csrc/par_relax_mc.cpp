@@ -250,7 +250,8 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
       a.alpha = relax_weight; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_WHOLE; a.row_offset = 0;
       a.rowmap = m->rowmap[(size_t) c];
       spmv_default_flags(a);
-      launch_spmv(plan, a, (relax_points != 0 && cf_marker) ? OP_JACOBI_CF : OP_JACOBI, s);
+      if (!(relax_points != 0 && cf_marker)) { a.marker = nullptr; }
+      launch_spmv(plan, a, OP_JACOBI_MAP, s);
    }
    u->all_zeros = 0;
    handle().sync_compute = saved;

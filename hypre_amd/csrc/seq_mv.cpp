@@ -222,15 +222,32 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
             if (!cov.empty())
             {
                std::sort(cov.begin(), cov.end());
-               const int need = cov[(size_t) ((cov.size() - 1) * 99 / 100)];
-               const int other = 8 * 264 + 4 * (RP_CAP_HOST + 4) + 64;          // row sums + row pointers beside the products
+               static int pct = -1, verbose = 0;
+               if (pct < 0)
+               {
+                  const char *e = getenv("HYPRE_AMD_SPMV_XS_PCT");
+                  pct = e ? std::min(100, std::max(1, atoi(e))) : 99;
+                  verbose = getenv("HYPRE_AMD_PLAN_VERBOSE") != nullptr;
+               }
+               const int need = cov[(size_t) ((cov.size() - 1) * (size_t) pct / 100)];
+               // what the launch puts beside the products (tiled_lds_bytes of spmv_kernels.hip): row sums and row pointers for
+               // the most rows a tile of THIS matrix holds
+               const int rows = p->max_tile_rows > 0 ? std::min(p->max_tile_rows, RP_CAP_HOST) : RP_CAP_HOST;
+               const int other = 8 * (p->max_row_nnz > 12 ? ((std::min(rows, SPMV_THREADS) + 1) & ~1) : 0) + 4 * (rows + 4) + 64;
                int units = p->xs_max_units;
                for (int wgs = 8; wgs >= 3; wgs--)
                {
-                  const int fit = ((160 * 1024) / wgs - other) / 16;             // units (16 bytes) that leave room for wgs workgroups
+                  const int room = ((160 * 1024) / wgs) / 1280 * 1280;           // LDS is handed out in blocks (1280 bytes on gfx950)
+                  const int fit = (room - other) / 16;                           // units (16 bytes) that leave room for wgs workgroups
                   if (fit >= need) { units = std::min(fit, p->xs_max_units); break; }
                }
                p->xs_launch_units = std::max(units, need);
+               if (verbose)
+               {
+                  fprintf(stderr, "[plan] %d x %d, %d tiles: staged units p50 %d p90 %d p99 %d max %d -> launch %d (%d bytes of LDS)\n",
+                          A->num_rows, A->num_cols, p->num_tiles, cov[cov.size() / 2], cov[(cov.size() - 1) * 9 / 10],
+                          cov[(cov.size() - 1) * 99 / 100], cov.back(), p->xs_launch_units, 16 * p->xs_launch_units + other);
+               }
             }
             p->prod_elems = std::max(p->prod_elems, 2 * p->xs_launch_units + 8);
          }

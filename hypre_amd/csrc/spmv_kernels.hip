@@ -73,7 +73,9 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
 {
    RowOps o;
    o.b = 0.0; o.d = 1.0; o.x = 0.0; o.m = 0;
-   if (p.rowmap) { row = p.rowmap[row]; }
+   // the row map is its own operation: a test on p.rowmap here merges the two paths and the compiler then waits for
+   // every load in flight (the tile's whole stream) before it asks for b, d and x — one more round trip for every sweep
+   if (OP == OP_JACOBI_MAP) { row = p.rowmap[row]; }
    o.g = row;
    if (OP == OP_AXPBY) { if (p.beta != 0.0) { o.b = p.b[row]; } }
    else if (OP == OP_TSGS) { o.d = p.d[row]; }
@@ -81,6 +83,7 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
    {
       o.b = p.b[row]; o.d = p.d[row]; o.x = p.x[row];
       if (OP == OP_JACOBI_CF) { o.m = p.marker[row]; }
+      if (OP == OP_JACOBI_MAP) { o.m = p.marker ? p.marker[row] : p.marker_val; }
    }
    return o;
 }
@@ -108,7 +111,7 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum,
    {
       // Jacobi / l1-Jacobi sweep fused into the SpMV pass (par_relax.c:1216-1244):
       //    y = x + (w f - w (A x)) ./ d      on the marked rows, y = x elsewhere
-      if (OP == OP_JACOBI_CF && o.m != p.marker_val) { p.y[row] = o.x; return; }
+      if ((OP == OP_JACOBI_CF || OP == OP_JACOBI_MAP) && o.m != p.marker_val) { p.y[row] = o.x; return; }
       const double t = p.alpha * o.b - p.alpha * sum;
       p.y[row] = o.x + t / o.d;
    }
@@ -501,6 +504,9 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
 constexpr int XS_SEGS  = SPMV_XS_SEGS;      // pieces per tile: 4 waves x XS_WSEG
 constexpr int XS_WSEG  = XS_SEGS / 4;       // pieces a wave fetches
 constexpr int XS_CAP   = SPMV_XS_CAP;       // doubles a tile may stage at most (the launch sizes LDS by what the matrix needs)
+#ifndef XS_EARLY_STREAM
+#define XS_EARLY_STREAM 1
+#endif
 constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first column of every piece, then (offset << 16 | length)
 
 template <int OP, bool F32, bool HASFILL>
@@ -532,10 +538,17 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int ka = tile * SPMV_TILE;
-   // values and local indices of the tile's window, requested before anything about the tile is known
+   // Values and local indices of the tile's window, then — wave-uniform, through the scalar cache — the tile's bounds
+   // and this wave's twelve piece descriptors: ONE batch of requests issued before anything about the tile is known.
+   // Left alone, the compiler sinks every one of these loads below the first branch that does not need it (the stream
+   // below the empty-tile test, the descriptors below the fallback test), and each such move puts a whole round trip
+   // to memory in front of the x pieces: a tile's life is the sum of its round trips.  The empty asm after the batch
+   // claims it may write what the pointers point to, so no load of the batch can be carried across it; it touches no
+   // loaded value, so nothing waits there.
    TileStream S;
    const int kA = ka + 4 * tid, kB = kA + 4 * SPMV_THREADS;
    const int qA = min(kA, p.last_quad), qB = min(kB, p.last_quad);
+#if XS_EARLY_STREAM
    if (F32)
    {
       S.fA = stream_load<v4f>(p.Aa32 + qA);
@@ -547,13 +560,30 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       S.vB01 = stream_load<v2d>(p.Aa + qB); S.vB23 = stream_load<v2d>(p.Aa + qB + 2);
    }
    const v2i lA = stream_load<v2i>(lidx + qA), lB = stream_load<v2i>(lidx + qB);
-
-   // wave-uniform: bounds and this wave's eight segment descriptors (scalar loads)
+#endif
+   const int *dsc = xs_desc + (size_t) tile * XS_DESC + XS_WSEG * wave;
+   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
+#pragma unroll
+   for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
    const int r0 = tile_row[tile], r1 = tile_row[tile + 1];
-   if (r1 <= r0) { return; }
    const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
-   const int nrows = r1 - r0;
    const int xc = xs_cnt[tile];                // (covered units << 8) | pieces
+   asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aa32) : "memory");
+   if (r1 <= r0) { return; }
+#if !XS_EARLY_STREAM
+   if (F32)
+   {
+      S.fA = stream_load<v4f>(p.Aa32 + qA);
+      S.fB = stream_load<v4f>(p.Aa32 + qB);
+   }
+   else
+   {
+      S.vA01 = stream_load<v2d>(p.Aa + qA); S.vA23 = stream_load<v2d>(p.Aa + qA + 2);
+      S.vB01 = stream_load<v2d>(p.Aa + qB); S.vB23 = stream_load<v2d>(p.Aa + qB + 2);
+   }
+   const v2i lA = stream_load<v2i>(lidx + qA), lB = stream_load<v2i>(lidx + qB);
+#endif
+   const int nrows = r1 - r0;
    const int nseg = (xc >> 8) <= xs_units ? (xc & 0xff) : 0;     // the launch may stage less than the plan allows (occupancy)
 
    if (nseg == 0)
@@ -574,11 +604,6 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
       return;
    }
-
-   const int *dsc = xs_desc + (size_t) tile * XS_DESC + XS_WSEG * wave;
-   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
-#pragma unroll
-   for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
 
    // x pieces (at most 128 doubles each: one 16-byte load per lane), requested in the same trip through the memory
    // pipeline as the stream above and written straight into LDS (global_load_lds: no registers, no ds_write pass; the
@@ -1054,11 +1079,13 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       }
       a.Aa32 = mp->a32;
    }
+   if (a.rowmap && op != OP_JACOBI_MAP) { hypre_error_w_msg(HYPRE_ERROR_ARG, "row map given to an operation that does not read it"); return; }
    switch (op)
    {
       case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, a, s); break;
       case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, a, s); break;
       case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, a, s); break;
+      case OP_JACOBI_MAP: launch_spmv_op<OP_JACOBI_MAP>(plan, a, s); break;
       case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, a, s); break;
    }
 }
