@@ -197,6 +197,13 @@ void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, h
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
 void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows, int ncols, int nnz, int *Ti, int *tj, double *ta,
                       hipStream_t s);     // device CSR transpose, rows of the result in ascending source-row order
+void launch_scan_exclusive(int *data, int n, hipStream_t s);
+// setup_kernels.hip: strength of connection, PMIS, coarse numbering and smoother diagonals of a single-rank level
+void device_strength(int n, const int *Ai, const int *Aj, const double *Aa, double theta, double max_row_sum,
+                     int **Si_out, int **Sj_out, int *nnz_out, hipStream_t s);
+int  device_pmis(int n, const int *Si, const int *Sj, int snnz, unsigned seed, unsigned long long skip, int *CF, hipStream_t s);
+int  device_coarse_numbering(int n, const int *CF, int *f2c, hipStream_t s);
+bool device_l1_norms(int n, const int *Ai, const int *Aj, const double *Aa, int option, const int *cf, double *out, hipStream_t s);
 // Galerkin product R A P on the device, bit-identical to the host setup's (rap_kernels.hip); false: does not fit, use the host
 bool device_rap(int nc, int ncP, int maxP, const int *Ri, const int *Rj, const double *Ra, const int *Ai, const int *Aj,
                 const double *Aa, const int *Pi, const int *Pj, const double *Pa, int **Ci_out, int **Cj_out, double **Ca_out,

@@ -473,6 +473,9 @@ void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows,
    HIP_CHECK(hipFree(tj0));
    if (ta0) { HIP_CHECK(hipFree(ta0)); }
 }
+// in-place exclusive scan of data[0..n), total in data[n] (the array holds n + 1 ints)
+void launch_scan_exclusive(int *data, int n, hipStream_t s)
+{ hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, data, n); }
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s)
 { if (n > 0 && nv > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(((size_t) n * nv + 255) / 256), dim3(256), 0, s, in, out, n, nv); }
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s)

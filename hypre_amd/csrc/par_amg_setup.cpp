@@ -181,6 +181,151 @@ struct RowMarker
 
 }  // namespace
 
+// set by hypre_BoomerAMGSetup while it builds a hierarchy whose home is device memory
+static bool g_setup_targets_device = false;
+static int  g_device_rap_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_RAP"); return e ? atoi(e) : 1; }();
+static int  g_device_rap_min_rows = 20000;
+static int  g_device_rap_count = 0;          // products formed on the device since the last query
+
+// Galerkin products of single-rank setups whose hierarchy lives in device memory are formed on the device (same bits as
+// the host loop): on = 0 keeps the host loop, min_rows = smallest fine level worth the transfers (negative: unchanged).
+// Returns the number of products formed on the device since the previous call.
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows)
+{
+   if (on >= 0) { g_device_rap_on = on; }
+   if (min_rows >= 0) { g_device_rap_min_rows = min_rows; }
+   const int c = g_device_rap_count;
+   g_device_rap_count = 0;
+   return c;
+}
+static bool device_rap_allowed() { return g_setup_targets_device; }
+static bool device_setup_allowed() { return g_setup_targets_device; }
+
+// Device twins of host matrices made during a device-targeted setup (operators uploaded for, or produced by, the device
+// kernels).  A later step that needs the same matrix on the device takes the twin instead of uploading again, and when
+// the finished hierarchy moves to device memory a matrix with a twin simply adopts its arrays.  Twins nobody adopted are
+// freed when the setup ends.
+static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> &device_twins()
+{
+   static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> t;
+   return t;
+}
+static hypre_CSRMatrix *device_twin_of(hypre_CSRMatrix *host, int with_data)
+{
+   if (host->memory_location == HYPRE_MEMORY_DEVICE) { return host; }      // born on the device (an interpolation operator)
+   auto &t = device_twins();
+   auto it = t.find(host);
+   if (it != t.end()) { return it->second; }
+   hypre_CSRMatrix *d = hypre_CSRMatrixClone_v2(host, with_data, HYPRE_MEMORY_DEVICE);
+   t[host] = d;
+   return d;
+}
+static void drop_device_markers();
+static void drop_device_twins()
+{
+   for (auto &kv : device_twins()) { hypre_CSRMatrixDestroy(kv.second); }
+   device_twins().clear();
+   drop_device_markers();
+}
+// device CSR from arrays that already live on the device (ownership passes to the matrix)
+static hypre_CSRMatrix *wrap_device_csr(HYPRE_Int nr, HYPRE_Int ncl, HYPRE_Int nnz, int *i, int *j, double *a)
+{
+   hypre_CSRMatrix *m = hypre_CSRMatrixCreate(nr, ncl, nnz);
+   m->i = i; m->j = j; m->data = a; m->memory_location = HYPRE_MEMORY_DEVICE; m->owns_data = 1;
+   return m;
+}
+// host -> device for one block of the finished hierarchy: adopt the twin's arrays when there is one
+static void place_on_device(hypre_CSRMatrix *M)
+{
+   auto &t = device_twins();
+   auto it = M ? t.find(M) : t.end();
+   if (it == t.end() || M->memory_location != HYPRE_MEMORY_HOST) { if (M) { hypre_CSRMatrixMigrate(M, HYPRE_MEMORY_DEVICE); } return; }
+   hypre_CSRMatrix *d = it->second;
+   t.erase(it);
+   hypre_Free(M->i, HYPRE_MEMORY_HOST); hypre_Free(M->j, HYPRE_MEMORY_HOST); hypre_Free(M->data, HYPRE_MEMORY_HOST);
+   M->i = d->i; M->j = d->j; M->data = d->data;
+   M->memory_location = HYPRE_MEMORY_DEVICE;
+   d->i = nullptr; d->j = nullptr; d->data = nullptr;
+   hypre_CSRMatrixDestroy(d);
+}
+// device -> fresh host arrays of n items: the destination pages are touched by all threads first (a copy into untouched
+// memory faults them in one by one on one thread: 1.8 GB took 0.4 s that way)
+static void download_bytes(void *host, const void *dev, size_t bytes)
+{
+   if (bytes > (size_t) 1 << 24)
+   {
+      char *p = (char *) host;
+#pragma omp parallel for schedule(static)
+      for (long long o = 0; o < (long long) bytes; o += 4096) { p[o] = 0; }
+   }
+   hypre_Memcpy(host, (void *) dev, bytes, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+}
+#define download(host, dev, n) download_bytes((host), (dev), sizeof(*(host)) * (size_t) (n))
+static int  g_device_interp_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_INTERP"); return e ? atoi(e) : 1; }();
+static int  g_device_interp_count = 0;
+static bool g_interp_host_once = false;      // the next interpolation goes to the host loop (the device kernel just declined it)
+// same for the extended+i interpolation: on = 0 keeps the host loop; returns the number of operators built on the device
+// since the previous call
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on)
+{
+   if (on >= 0) { g_device_interp_on = on; }
+   const int c = g_device_interp_count;
+   g_device_interp_count = 0;
+   return c;
+}
+
+
+// Strength of connection and PMIS of single-rank, scalar levels on the device as well (setup_kernels.hip: the host
+// routines' results array for array), so that a coarse operator formed on the device never has to come back:
+// on = 0 keeps the host loops.  Returns the number of levels coarsened on the device since the previous call.
+static int  g_device_coarsen_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_COARSEN"); return e ? atoi(e) : 1; }();
+static int  g_device_coarsen_count = 0;
+static bool g_level_on_device = false;       // set by the setup loop for the level it is working on
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceCoarsen(HYPRE_Int on)
+{
+   if (on >= 0) { g_device_coarsen_on = on; }
+   const int c = g_device_coarsen_count;
+   g_device_coarsen_count = 0;
+   return c;
+}
+// device copies of C/F marker arrays made during the setup (host array -> device array); the finished hierarchy adopts them
+static std::unordered_map<const HYPRE_Int *, HYPRE_Int *> &device_markers()
+{
+   static std::unordered_map<const HYPRE_Int *, HYPRE_Int *> t;
+   return t;
+}
+static void drop_device_markers()
+{
+   for (auto &kv : device_markers()) { hypre_Free(kv.second, HYPRE_MEMORY_DEVICE); }
+   device_markers().clear();
+}
+static HYPRE_Int *device_marker_of(const HYPRE_Int *host, HYPRE_Int n)
+{
+   auto &t = device_markers();
+   auto it = t.find(host);
+   if (it != t.end()) { return it->second; }
+   HYPRE_Int *dd = hypre_TAlloc(HYPRE_Int, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+   hypre_TMemcpy(dd, host, HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   t[host] = dd;
+   return dd;
+}
+// A matrix born on the device is needed by a host loop after all: fetch it; its device arrays stay on as its twin.
+static void make_host_resident(hypre_CSRMatrix *M)
+{
+   if (!M || M->memory_location != HYPRE_MEMORY_DEVICE) { return; }
+   const HYPRE_Int nr = M->num_rows, nnz = M->num_nonzeros;
+   HYPRE_Int *hi = hypre_TAlloc(HYPRE_Int, (size_t) nr + 1, HYPRE_MEMORY_HOST);
+   HYPRE_Int *hj = hypre_TAlloc(HYPRE_Int, (size_t) std::max(nnz, 1), HYPRE_MEMORY_HOST);
+   HYPRE_Real *ha = M->data ? hypre_TAlloc(HYPRE_Real, (size_t) std::max(nnz, 1), HYPRE_MEMORY_HOST) : nullptr;
+   if (M->i) { download(hi, M->i, (size_t) nr + 1); } else { memset(hi, 0, sizeof(HYPRE_Int) * ((size_t) nr + 1)); }
+   if (nnz > 0 && M->j) { download(hj, M->j, (size_t) nnz); }
+   if (nnz > 0 && ha) { download(ha, M->data, (size_t) nnz); }
+   drop_plan(M);
+   device_twins()[M] = wrap_device_csr(nr, M->num_cols, nnz, M->i, M->j, M->data);
+   M->i = hi; M->j = hj; M->data = ha;
+   M->memory_location = HYPRE_MEMORY_HOST;
+}
+
 extern "C" {
 
 // ===========================================================================
@@ -200,6 +345,25 @@ HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_
    hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
    const HYPRE_Int n = Ad->num_rows;
    const HYPRE_Int nco = Ao->num_cols;
+   if (g_level_on_device && num_functions <= 1 && nco == 0 && Ao->num_nonzeros == 0)
+   {
+      // this level of a device-targeted setup: one thread per row, the loops below statement for statement; S stays there
+      hypre_CSRMatrix *dA = device_twin_of(Ad, 1);
+      int *Si = nullptr, *Sj = nullptr, snnz = 0;
+      device_strength(n, dA->i, dA->j, dA->data, theta, max_row_sum, &Si, &Sj, &snnz, stream());
+      hypre_ParCSRMatrix *S = hypre_ParCSRMatrixCreate(A->comm, A->global_num_rows, A->global_num_rows,
+                                                       A->row_starts, A->row_starts, 0, snnz, 0);
+      hypre_CSRMatrixDestroy(S->diag);
+      S->diag = wrap_device_csr(n, n, snnz, Si, Sj, nullptr);
+      hypre_CSRMatrixInitialize_v2(S->offd, 0, HYPRE_MEMORY_HOST);
+      *S_ptr = S;
+      return hypre_error_flag;
+   }
+   if (Ad->memory_location != HYPRE_MEMORY_HOST)
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCreateS: the host loop was handed a device matrix");
+      return hypre_error_flag;
+   }
    const HYPRE_Int *Adi = Ad->i, *Adj = Ad->j, *Aoi = Ao->i, *Aoj = Ao->j;
    const HYPRE_Real *Ada = Ad->data, *Aoa = Ao->data;
 
@@ -293,6 +457,32 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
    const int nprocs = comm_size(comm), my_id = comm_rank(comm);
    hypre_CSRMatrix *Sd = S->diag, *So = S->offd;
    const HYPRE_Int n = Sd->num_rows, nco = So->num_cols;
+   if (Sd->memory_location == HYPRE_MEMORY_DEVICE)
+   {
+      // S was made on the device (a single-rank level of a device-targeted setup): the sweeps below, one thread per
+      // row; the markers come back for the host's bookkeeping and stay on the device for the interpolation
+      if (nprocs > 1 || nco > 0 || (CF_init != 0 && CF_init != 2))
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCoarsenPMIS: device strength matrix outside the single-rank PMIS path");
+         return hypre_error_flag;
+      }
+      if (*CF_marker_ptr == nullptr)
+      {
+         *CF_marker_ptr = hypre_IntArrayCreate(n);
+         hypre_IntArrayInitialize_v2(*CF_marker_ptr, HYPRE_MEMORY_HOST);
+      }
+      HYPRE_Int *CFh = (*CF_marker_ptr)->data;
+      HYPRE_Int *dCF = hypre_TAlloc(HYPRE_Int, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+      device_pmis(n, Sd->i, Sd->j, Sd->num_nonzeros, 2747u + (CF_init == 2 ? 0u : (unsigned) my_id),
+                  CF_init == 2 ? (unsigned long long) S->first_row_index : 0ull, dCF, stream());
+      download(CFh, dCF, (size_t) n);
+      auto &mk = device_markers();
+      auto it = mk.find(CFh);
+      if (it != mk.end()) { hypre_Free(it->second, HYPRE_MEMORY_DEVICE); }
+      mk[CFh] = dCF;
+      g_device_coarsen_count++;
+      return hypre_error_flag;
+   }
    const HYPRE_Int *Sdi = Sd->i, *Sdj = Sd->j, *Soi = So->i, *Soj = So->j;
    hypre_ParCSRCommPkg *pkg = nullptr;
    if (nprocs > 1)
@@ -665,96 +855,6 @@ static void coarse_parms(MPI_Comm comm, HYPRE_Int n, const HYPRE_Int *CF, HYPRE_
    else { cpts_global[0] = 0; cpts_global[1] = local; *total = local; }
 }
 
-// set by hypre_BoomerAMGSetup while it builds a hierarchy whose home is device memory
-static bool g_setup_targets_device = false;
-static int  g_device_rap_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_RAP"); return e ? atoi(e) : 1; }();
-static int  g_device_rap_min_rows = 20000;
-static int  g_device_rap_count = 0;          // products formed on the device since the last query
-
-// Galerkin products of single-rank setups whose hierarchy lives in device memory are formed on the device (same bits as
-// the host loop): on = 0 keeps the host loop, min_rows = smallest fine level worth the transfers (negative: unchanged).
-// Returns the number of products formed on the device since the previous call.
-extern "C" HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows)
-{
-   if (on >= 0) { g_device_rap_on = on; }
-   if (min_rows >= 0) { g_device_rap_min_rows = min_rows; }
-   const int c = g_device_rap_count;
-   g_device_rap_count = 0;
-   return c;
-}
-static bool device_rap_allowed() { return g_setup_targets_device; }
-static bool device_setup_allowed() { return g_setup_targets_device; }
-
-// Device twins of host matrices made during a device-targeted setup (operators uploaded for, or produced by, the device
-// kernels).  A later step that needs the same matrix on the device takes the twin instead of uploading again, and when
-// the finished hierarchy moves to device memory a matrix with a twin simply adopts its arrays.  Twins nobody adopted are
-// freed when the setup ends.
-static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> &device_twins()
-{
-   static std::unordered_map<const hypre_CSRMatrix *, hypre_CSRMatrix *> t;
-   return t;
-}
-static hypre_CSRMatrix *device_twin_of(hypre_CSRMatrix *host, int with_data)
-{
-   if (host->memory_location == HYPRE_MEMORY_DEVICE) { return host; }      // born on the device (an interpolation operator)
-   auto &t = device_twins();
-   auto it = t.find(host);
-   if (it != t.end()) { return it->second; }
-   hypre_CSRMatrix *d = hypre_CSRMatrixClone_v2(host, with_data, HYPRE_MEMORY_DEVICE);
-   t[host] = d;
-   return d;
-}
-static void drop_device_twins()
-{
-   for (auto &kv : device_twins()) { hypre_CSRMatrixDestroy(kv.second); }
-   device_twins().clear();
-}
-// device CSR from arrays that already live on the device (ownership passes to the matrix)
-static hypre_CSRMatrix *wrap_device_csr(HYPRE_Int nr, HYPRE_Int ncl, HYPRE_Int nnz, int *i, int *j, double *a)
-{
-   hypre_CSRMatrix *m = hypre_CSRMatrixCreate(nr, ncl, nnz);
-   m->i = i; m->j = j; m->data = a; m->memory_location = HYPRE_MEMORY_DEVICE; m->owns_data = 1;
-   return m;
-}
-// host -> device for one block of the finished hierarchy: adopt the twin's arrays when there is one
-static void place_on_device(hypre_CSRMatrix *M)
-{
-   auto &t = device_twins();
-   auto it = M ? t.find(M) : t.end();
-   if (it == t.end() || M->memory_location != HYPRE_MEMORY_HOST) { if (M) { hypre_CSRMatrixMigrate(M, HYPRE_MEMORY_DEVICE); } return; }
-   hypre_CSRMatrix *d = it->second;
-   t.erase(it);
-   hypre_Free(M->i, HYPRE_MEMORY_HOST); hypre_Free(M->j, HYPRE_MEMORY_HOST); hypre_Free(M->data, HYPRE_MEMORY_HOST);
-   M->i = d->i; M->j = d->j; M->data = d->data;
-   M->memory_location = HYPRE_MEMORY_DEVICE;
-   d->i = nullptr; d->j = nullptr; d->data = nullptr;
-   hypre_CSRMatrixDestroy(d);
-}
-// device -> fresh host arrays of n items: the destination pages are touched by all threads first (a copy into untouched
-// memory faults them in one by one on one thread: 1.8 GB took 0.4 s that way)
-static void download_bytes(void *host, const void *dev, size_t bytes)
-{
-   if (bytes > (size_t) 1 << 24)
-   {
-      char *p = (char *) host;
-#pragma omp parallel for schedule(static)
-      for (long long o = 0; o < (long long) bytes; o += 4096) { p[o] = 0; }
-   }
-   hypre_Memcpy(host, (void *) dev, bytes, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
-}
-#define download(host, dev, n) download_bytes((host), (dev), sizeof(*(host)) * (size_t) (n))
-static int  g_device_interp_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_INTERP"); return e ? atoi(e) : 1; }();
-static int  g_device_interp_count = 0;
-// same for the extended+i interpolation: on = 0 keeps the host loop; returns the number of operators built on the device
-// since the previous call
-extern "C" HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on)
-{
-   if (on >= 0) { g_device_interp_on = on; }
-   const int c = g_device_interp_count;
-   g_device_interp_count = 0;
-   return c;
-}
-
 // ===========================================================================
 // truncation of P (par_csr_matrix.c:2874-3400 with rescale = 1, inf-norm)
 // ===========================================================================
@@ -899,33 +999,26 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       return dist_build_extpi_interp(A, CF_marker, S, num_cpts_global, ends.back(), sys ? dof_func : nullptr, trunc_factor, max_elmts, P_ptr);
    }
    hypre_CSRMatrix *Ad = A->diag;
-   const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
-   const HYPRE_Real *Aa = Ad->data;
-   const HYPRE_Int *Si = S->diag->i, *Sj = S->diag->j;
    const HYPRE_Int n = Ad->num_rows;
    const HYPRE_BigInt total_cpts = num_cpts_global[1];
 
-   std::vector<HYPRE_Int> f2c((size_t) std::max(n, 1), -1);
-   {
-      HYPRE_Int c = 0;
-      for (HYPRE_Int i = 0; i < n; i++) { if (CF_marker[i] >= 0) { f2c[(size_t) i] = c++; } }
-   }
    // On the device when the hierarchy's home is device memory (interp_kernels.hip: one wave per row, this loop's order,
    // same bits; hypre_amd_SetSetupDeviceInterp(0) keeps the host loop)
-   if (!sys && g_device_interp_on && device_setup_allowed() && n >= g_device_rap_min_rows && Ad->num_nonzeros > 0 &&
-       Ad->memory_location == HYPRE_MEMORY_HOST && ensure_device())
+   if (!sys && g_device_interp_on && !g_interp_host_once && device_setup_allowed() && n >= g_device_rap_min_rows &&
+       Ad->num_nonzeros > 0 && ensure_device())
    {
       hipStream_t st = stream();
       hypre_CSRMatrix *dA = device_twin_of(Ad, 1);
-      hypre_CSRMatrix *dS = hypre_CSRMatrixClone_v2(S->diag, 0, HYPRE_MEMORY_DEVICE);
-      HYPRE_Int *dCF = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE), *dF2C = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE);
-      hypre_TMemcpy(dCF, CF_marker, HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-      hypre_TMemcpy(dF2C, f2c.data(), HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      const bool S_there = S->diag->memory_location == HYPRE_MEMORY_DEVICE;
+      hypre_CSRMatrix *dS = S_there ? S->diag : hypre_CSRMatrixClone_v2(S->diag, 0, HYPRE_MEMORY_DEVICE);
+      HYPRE_Int *dCF = device_marker_of(CF_marker, n);           // left by the device coarsening, or uploaded now
+      HYPRE_Int *dF2C = hypre_TAlloc(HYPRE_Int, (size_t) n, HYPRE_MEMORY_DEVICE);
+      device_coarse_numbering(n, dCF, dF2C, st);
       int *dPi = nullptr, *dPj = nullptr, pnnz = 0;
       double *dPa = nullptr;
       const bool ok = device_extpi(n, dA->i, dA->j, dA->data, dS->i, dS->j, dCF, dF2C, trunc_factor, max_elmts, &dPi, &dPj, &dPa, &pnnz, st);
-      hypre_CSRMatrixDestroy(dS);
-      hypre_Free(dCF, HYPRE_MEMORY_DEVICE); hypre_Free(dF2C, HYPRE_MEMORY_DEVICE);
+      if (!S_there) { hypre_CSRMatrixDestroy(dS); }
+      hypre_Free(dF2C, HYPRE_MEMORY_DEVICE);
       if (ok)
       {
          // the operator stays where it was made: nothing on the host reads it (the Galerkin product that follows runs
@@ -940,6 +1033,21 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
          g_device_interp_count++;
          return hypre_error_flag;
       }
+   }
+   g_interp_host_once = false;
+   if (Ad->memory_location != HYPRE_MEMORY_HOST || S->diag->memory_location != HYPRE_MEMORY_HOST)
+   {
+      // the host loop below needs host copies: the caller (the setup loop) fetches them and asks again
+      *P_ptr = nullptr;
+      return hypre_error_flag;
+   }
+   const HYPRE_Int *Ai = Ad->i, *Aj = Ad->j;
+   const HYPRE_Real *Aa = Ad->data;
+   const HYPRE_Int *Si = S->diag->i, *Sj = S->diag->j;
+   std::vector<HYPRE_Int> f2c((size_t) std::max(n, 1), -1);
+   {
+      HYPRE_Int c = 0;
+      for (HYPRE_Int i = 0; i < n; i++) { if (CF_marker[i] >= 0) { f2c[(size_t) i] = c++; } }
    }
    const int T = num_threads_avail();
    std::vector<std::vector<HYPRE_Int>> tj((size_t) T);
@@ -1232,7 +1340,6 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
                                     HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr)
 {
    if (!g_device_rap_on || !device_rap_allowed() || RT != P) { return false; }
-   if (A->diag->memory_location != HYPRE_MEMORY_HOST) { return false; }
    const HYPRE_Int nf = A->diag->num_rows, nc = P->diag->num_cols;
    if (nf < g_device_rap_min_rows || A->diag->num_nonzeros <= 0 || P->diag->num_nonzeros <= 0) { return false; }   // small levels: the host loop is quicker than the transfers
    if (!ensure_device()) { return false; }
@@ -1255,14 +1362,11 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
    if (!ok) { hypre_CSRMatrixDestroy(dR); return false; }
    hypre_ParCSRMatrix *C = hypre_ParCSRMatrixCreate(A->comm, RT->global_num_cols, P->global_num_cols, RT->col_starts,
                                                     P->col_starts, 0, nnz, 0);
-   hypre_ParCSRMatrixInitialize_v2(C, HYPRE_MEMORY_HOST);
-   download(C->diag->i, Ci, (size_t) nc + 1);
-   if (nnz > 0)
-   {
-      download(C->diag->j, Cj, (size_t) nnz);
-      download(C->diag->data, Ca, (size_t) nnz);
-   }
-   device_twins()[C->diag] = wrap_device_csr(nc, nc, nnz, Ci, Cj, Ca);      // next level's interpolation and product, finished hierarchy
+   // the coarse operator stays where it was made; a later step that runs on the host (a small level, a smoother whose
+   // setup is a host loop) fetches it then (make_host_resident) and the device arrays stay on as its twin
+   hypre_CSRMatrixDestroy(C->diag);
+   C->diag = wrap_device_csr(nc, nc, nnz, Ci, Cj, Ca);
+   hypre_CSRMatrixInitialize_v2(C->offd, 0, HYPRE_MEMORY_HOST);
    if (keepTranspose) { RT->diagT = dR; }          // the restriction operator is used on the device only
    else { hypre_CSRMatrixDestroy(dR); }
    hypre_CSRMatrixSetRownnz(C->offd);
@@ -1270,7 +1374,7 @@ static bool device_galerkin_product(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *
    hypre_ParCSRMatrixSetDNumNonzeros(C);
    *RAP_ptr = C;
    g_device_rap_count++;
-   if (timing) { fprintf(stderr, "   device RAP: upload %.3fs  transpose %.3fs  product %.3fs  download+rest %.3fs\n", t1 - t0, t2 - t1, t3 - t2, omp_get_wtime() - t3); }
+   if (timing) { fprintf(stderr, "   device RAP: upload %.3fs  transpose %.3fs  product %.3fs  rest %.3fs\n", t1 - t0, t2 - t1, t3 - t2, omp_get_wtime() - t3); }
    return true;
 }
 
@@ -1286,6 +1390,12 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
    MPI_Comm comm = A->comm;
    if (comm_size(comm) > 1) { return dist_build_coarse_operator(RT, A, P, keepTranspose, RAP_ptr); }
    if (device_galerkin_product(RT, A, P, keepTranspose, RAP_ptr)) { return hypre_error_flag; }
+   if (A->diag->memory_location != HYPRE_MEMORY_HOST)
+   {
+      // the host loop below needs a host copy of A: the caller (the setup loop) fetches it and asks again
+      *RAP_ptr = nullptr;
+      return hypre_error_flag;
+   }
    if (P->diag->memory_location == HYPRE_MEMORY_DEVICE) { hypre_CSRMatrixMigrate(P->diag, HYPRE_MEMORY_HOST); }     // made on the device, needed here
    hypre_CSRMatrix *R = nullptr;
    hypre_CSRMatrixTranspose(RT->diag, &R, 1);
@@ -1678,10 +1788,28 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    }
 
    // the setup works on host copies; a device-resident A is cloned once
+   // (a level that qualifies — single rank, one function, PMIS, extended+i, no small level — is worked on where the
+   // hierarchy will live: strength, coarsening, interpolation and the Galerkin product on the device, nothing fetched)
    std::vector<hypre_ParCSRMatrix *> hostA((size_t) max_levels, nullptr);
    const bool A_on_device = A->diag->memory_location == HYPRE_MEMORY_DEVICE;
-   hostA[0] = A_on_device ? hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST) : A;
-   bool own_host_A0 = A_on_device;
+   const bool single_rank = comm_size(comm) == 1;
+   auto level_runs_on_device = [&](hypre_ParCSRMatrix *M, HYPRE_Int ct)
+   {
+      return target == HYPRE_MEMORY_DEVICE && g_device_coarsen_on && g_device_interp_on && g_device_rap_on && single_rank &&
+             d->num_functions <= 1 && (ct == 8 || ct == 9) && d->interp_type == 6 && M->offd->num_cols == 0 &&
+             M->offd->num_nonzeros == 0 && M->diag->num_rows >= g_device_rap_min_rows && M->diag->num_nonzeros > 0;
+   };
+   const bool A_stays = A_on_device && level_runs_on_device(A, d->coarsen_type);
+   hostA[0] = (A_on_device && !A_stays) ? hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST) : A;
+   bool own_host_A0 = A_on_device && !A_stays;
+   // a host loop needs level l after all: the caller's matrix is copied, a matrix of ours is fetched (and keeps its twin)
+   auto fetch_level = [&](int l)
+   {
+      hypre_ParCSRMatrix *M = hostA[(size_t) l];
+      if (!M || M->diag->memory_location != HYPRE_MEMORY_DEVICE) { return; }
+      if (l == 0 && M == A) { hostA[0] = hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST); own_host_A0 = true; }
+      else { make_host_resident(M->diag); }
+   };
    if (d->num_functions > 1 && pv->filter_functions)
    {
       // par_amg_setup.c:774-780: the hierarchy (S, P, coarse operators, smoother diagonals) comes from the filtered
@@ -1721,6 +1849,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    omp_set_num_threads(thread_cap);
    while (not_finished)
    {
+      g_level_on_device = level_runs_on_device(hostA[(size_t) level], coarsen_type);
+      if (!g_level_on_device) { fetch_level(level); }
       hypre_ParCSRMatrix *Al = hostA[(size_t) level];
       omp_set_num_threads(std::max(1, std::min(thread_cap, Al->diag->num_rows / 4096)));
       fine_size = Al->global_num_rows;
@@ -1792,6 +1922,15 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       if (d->interp_type == 6)
       {
          hypre_BoomerAMGBuildExtPIInterp(Al, CF, S, cpts, d->num_functions, dofs, 0, d->trunc_factor, d->P_max_elmts, &P);
+         if (!P && !hypre_error_flag)
+         {
+            // the device kernel declined (a row beyond its tables) and the level lives on the device: host copies, host loop
+            fetch_level(level);
+            Al = hostA[(size_t) level];
+            make_host_resident(S->diag);
+            g_interp_host_once = true;
+            hypre_BoomerAMGBuildExtPIInterp(Al, CF, S, cpts, d->num_functions, dofs, 0, d->trunc_factor, d->P_max_elmts, &P);
+         }
       }
       else if (d->interp_type == 3)
       {
@@ -1809,6 +1948,12 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       const double t_r0 = omp_get_wtime();
       hypre_ParCSRMatrix *AH = nullptr;
       hypre_BoomerAMGBuildCoarseOperatorKT(P, Al, P, 1, &AH);
+      if (!AH && !hypre_error_flag && Al->diag->memory_location == HYPRE_MEMORY_DEVICE)
+      {
+         fetch_level(level);
+         Al = hostA[(size_t) level];
+         hypre_BoomerAMGBuildCoarseOperatorKT(P, Al, P, 1, &AH);
+      }
       if (getenv("HYPRE_AMD_SETUP_TIMING") && comm_rank(comm) == 0)
       {
          fprintf(stderr, "setup level %d: rows %lld  strength %.2fs  coarsen %.2fs  interp %.2fs  RAP %.2fs  (threads %d)\n", level,
@@ -1828,6 +1973,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          not_finished = false;
       }
    }
+   g_level_on_device = false;
    omp_set_num_threads(thread_cap);
    const int num_levels = level + 1;
    d->num_levels = num_levels;
@@ -1846,8 +1992,13 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          hypre_ParCSRMatrix *Ac = hostA[(size_t) num_levels - 1];
          if (Ac->global_num_rows <= (HYPRE_BigInt) d->max_coarse_size)
          {
+            fetch_level(num_levels - 1);
+            Ac = hostA[(size_t) num_levels - 1];
+            // (the dense factorisation reads a host copy; level 0 of a one-level hierarchy stays the caller's matrix)
+            hypre_ParCSRMatrix *keep = d->A_array[num_levels - 1];
             d->A_array[num_levels - 1] = Ac;
             hypre_GaussElimSetup(d, num_levels - 1, gt[3]);
+            d->A_array[num_levels - 1] = keep;
          }
          else { gt[3] = gt[1]; }
       }
@@ -1859,7 +2010,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       for (int j = 0; j < num_levels; j++)
       {
          HYPRE_Real *l1 = nullptr;
-         hypre_ParCSRMatrix *Al = hostA[(size_t) j];
+         bool l1_on_device = false;
          HYPRE_Int *cf = (d->relax_order && d->CF_marker_array[j]) ? d->CF_marker_array[j]->data : nullptr;
          const bool last = (j == num_levels - 1);
          auto any = [&](int a, int b, int c, int e) { return gt[1] == a || gt[1] == b || gt[1] == c || gt[1] == e ||
@@ -1867,29 +2018,41 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          auto last_is = [&](int a, int b, int c, int e) { return gt[3] == a || gt[3] == b || gt[3] == c || gt[3] == e; };
          // ams.c:541-548: the host routine switches to the thread-block variant when OpenMP has > 1 thread
          const int gs_threads = ((AmgPrivate *) d->amd_private)->emulated_threads;
-         auto l1_norms = [&](hypre_ParCSRMatrix *M, HYPRE_Int option, HYPRE_Int *cfm, HYPRE_Real **out)
+         auto l1_norms = [&](HYPRE_Int option, HYPRE_Int *cfm)
          {
-            if (gs_threads > 1) { hypre_ParCSRComputeL1NormsThreads(M, option, gs_threads, cfm, out); }
-            else { hypre_ParCSRComputeL1Norms(M, option, cfm, out); }
+            if (l1) { hypre_Free(l1, l1_on_device ? HYPRE_MEMORY_DEVICE : HYPRE_MEMORY_HOST); l1 = nullptr; }
+            hypre_ParCSRMatrix *M = hostA[(size_t) j];
+            if (M->diag->memory_location == HYPRE_MEMORY_DEVICE && gs_threads <= 1 && M->offd->num_cols == 0)
+            {
+               // a level that never left the device: one thread per row, the host routine's sums in the host's order
+               const HYPRE_Int n = M->diag->num_rows;
+               l1 = hypre_TAlloc(HYPRE_Real, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+               l1_on_device = true;
+               const HYPRE_Int *dcf = cfm ? device_marker_of(cfm, n) : nullptr;
+               if (!device_l1_norms(n, M->diag->i, M->diag->j, M->diag->data, option, dcf, l1, stream())) { hypre_error_in_arg(1); }
+               return;
+            }
+            fetch_level(j);
+            M = hostA[(size_t) j];
+            l1_on_device = false;
+            if (gs_threads > 1) { hypre_ParCSRComputeL1NormsThreads(M, option, gs_threads, cfm, &l1); }
+            else { hypre_ParCSRComputeL1Norms(M, option, cfm, &l1); }
          };
-         if (!last && any(8, 89, 13, 14)) { l1_norms(Al, 4, cf, &l1); }
-         else if (last && last_is(8, 89, 13, 14)) { l1_norms(Al, 4, nullptr, &l1); }
-         if (!last && (gt[1] == 88 || gt[2] == 88)) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 6, cf, &l1); }
-         else if (last && gt[3] == 88) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 6, nullptr, &l1); }
-         if (!last && (gt[1] == 18 || gt[2] == 18)) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 1, cf, &l1); }
-         else if (last && gt[3] == 18) { hypre_Free(l1, HYPRE_MEMORY_HOST); l1_norms(Al, 1, nullptr, &l1); }
+         if (!last && any(8, 89, 13, 14)) { l1_norms(4, cf); }
+         else if (last && last_is(8, 89, 13, 14)) { l1_norms(4, nullptr); }
+         if (!last && (gt[1] == 88 || gt[2] == 88)) { l1_norms(6, cf); }
+         else if (last && gt[3] == 88) { l1_norms(6, nullptr); }
+         if (!last && (gt[1] == 18 || gt[2] == 18)) { l1_norms(1, cf); }
+         else if (last && gt[3] == 18) { l1_norms(1, nullptr); }
          auto diag_smoother = [](HYPRE_Int t) { return t == 7 || t == 11 || t == 12 || t == 21 || t == 22; };
-         if (diag_smoother(gt[1]) || diag_smoother(gt[2]) || (diag_smoother(gt[3]) && last))
-         {
-            hypre_Free(l1, HYPRE_MEMORY_HOST);
-            l1_norms(Al, 5, nullptr, &l1);
-         }
+         if (diag_smoother(gt[1]) || diag_smoother(gt[2]) || (diag_smoother(gt[3]) && last)) { l1_norms(5, nullptr); }
          if (l1)
          {
-            d->l1_norms[j] = hypre_SeqVectorCreate(Al->diag->num_rows);
+            const HYPRE_MemoryLocation where = l1_on_device ? HYPRE_MEMORY_DEVICE : HYPRE_MEMORY_HOST;
+            d->l1_norms[j] = hypre_SeqVectorCreate(hostA[(size_t) j]->diag->num_rows);
             d->l1_norms[j]->data = l1;
-            d->l1_norms[j]->memory_location = HYPRE_MEMORY_HOST;
-            hypre_SeqVectorInitialize_v2(d->l1_norms[j], HYPRE_MEMORY_HOST);
+            d->l1_norms[j]->memory_location = where;
+            hypre_SeqVectorInitialize_v2(d->l1_norms[j], where);
          }
       }
    }
@@ -1909,6 +2072,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       {
          const bool last = (j == num_levels - 1);
          if (!(gt[1] == 16 || gt[2] == 16 || (gt[3] == 16 && last))) { continue; }
+         fetch_level(j);
          hypre_ParCSRMatrix *Al = hostA[(size_t) j];
          HYPRE_Real max_eig = 0.0, min_eig = 0.0, *coefs = nullptr, *ds = nullptr;
          if (d->cheby_eig_est) { hypre_ParCSRMaxEigEstimateCG(Al, d->cheby_scale, d->cheby_eig_est, &max_eig, &min_eig); }
@@ -1988,8 +2152,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          if (d->CF_marker_array[l])
          {
             hypre_IntArray *a = d->CF_marker_array[l];
-            HYPRE_Int *dd = hypre_TAlloc(HYPRE_Int, std::max(a->size, 1), HYPRE_MEMORY_DEVICE);
-            hypre_TMemcpy(dd, a->data, HYPRE_Int, a->size, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+            HYPRE_Int *dd = device_marker_of(a->data, a->size);       // the copy the device coarsening left, or a fresh one
+            device_markers().erase(a->data);
             hypre_Free(a->data, HYPRE_MEMORY_HOST);
             a->data = dd; a->memory_location = HYPRE_MEMORY_DEVICE;
          }

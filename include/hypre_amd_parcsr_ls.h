@@ -257,6 +257,13 @@ HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows);
  * rows): on = 0 keeps the host loop; returns the number built on the device since the previous call.  The reference's
  * device routine: parcsr_ls/par_lr_interp_device.c:1001. */
 HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on);
+/* And for strength of connection, PMIS coarsening and the smoother diagonals (setup_kernels.hip; the HOST routines'
+ * measures and results, not the reference's device variant with its own random numbers): with all three switches on, a
+ * single-rank scalar level of at least min_rows rows is set up without leaving the device — the coarse operator is not
+ * fetched, and a matrix handed over in device memory is not copied to the host.  on = 0 keeps the host loops; returns the
+ * number of levels coarsened on the device since the previous call.  The reference's device routines:
+ * parcsr_ls/par_strength_device.c, parcsr_ls/par_coarsen_device.c:30. */
+HYPRE_Int hypre_amd_SetSetupDeviceCoarsen(HYPRE_Int on);
 /* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows, default 100000; 0: off) is recorded once as a
  * HIP graph and replayed: its kernels are a few microseconds each behind launches that cost as much.  No reference
  * counterpart (the reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded

@@ -551,3 +551,67 @@ def test_device_interpolation_is_the_host_interpolation(gpu_lib, kw):
     for m0, m1 in zip(hier[0], hier[1]):
         for a, b in zip(m0, m1):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(n=(40, 39, 38)), dict(n=(30, 30, 30), problem="27pt"),
+                                dict(n=(36, 35, 34), problem="difconv", c=(1.0, 1.0, 0.001), a=(0.0, 0.0, 0.0)),
+                                dict(n=(40, 39, 38), relax_type=8), dict(n=(34, 33, 32), relax_type=7),
+                                dict(n=(34, 33, 32), relax_type=18, relax_order=1),
+                                dict(n=(30, 30, 30), problem="27pt", coarsen_type=9, P_max_elmts=6, trunc_factor=0.1),
+                                dict(n=(32, 32, 32), problem="difconv", c=(1.0, 0.01, 1.0), a=(3.0, 2.0, 1.0), max_row_sum=0.8),
+                                dict(n=(40, 40, 20), strong_threshold=0.6),
+                                dict(n=(40, 39, 38), matrix_on_device=True),
+                                # the device interpolation declines these (truncation by threshold alone): host loop on fetched copies
+                                dict(n=(30, 30, 30), P_max_elmts=0, trunc_factor=0.2),
+                                dict(n=(30, 30, 30), P_max_elmts=0, trunc_factor=0.2, matrix_on_device=True),
+                                dict(n=(20, 20, 20), max_levels=2, matrix_on_device=True)])
+def test_device_coarsening_is_the_host_coarsening(gpu_lib, kw):
+    """Setup with strength of connection, PMIS, interpolation, Galerkin product and smoother diagonals all on the device
+    (nothing fetched between levels; with matrix_on_device the caller's matrix is not copied to the host either) and the
+    host setup: C/F markers, interpolation operators, coarse operators and smoother diagonals identical array for array."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    kw = dict(kw)
+    on_device = kw.pop("matrix_on_device", False)
+    hier = []
+    for on in (0, 1):
+        lib.hypre_amd_SetSetupDeviceRAP(on, 50)
+        lib.hypre_amd_SetSetupDeviceInterp(on)
+        lib.hypre_amd_SetSetupDeviceCoarsen(on)
+        opt = ij.IJOptions(**dict(dict(coarsen_type=8, relax_type=18), **kw))
+        A = ij.build_matrix(opt)
+        if on and on_device:
+            lib.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+        s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+        lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+        B.check()
+        levels = lib.hypre_amd_SetSetupDeviceCoarsen(-1)
+        nl = lib.hypre_amd_BoomerAMGGetNumLevels(s)
+        assert (levels >= min(2, nl - 1)) if on else (levels == 0), (on, levels, nl)
+        if on and on_device:
+            assert A.contents.diag.contents.memory_location == B.HYPRE_MEMORY_DEVICE
+        lv = []
+        for l in range(nl):
+            Al = C.cast(lib.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
+            if l > 0:
+                assert Al.contents.diag.contents.memory_location == B.HYPRE_MEMORY_DEVICE
+                lv.append(B.csr_to_arrays(Al.contents.diag))
+            if l < nl - 1:
+                Pl = C.cast(lib.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+                lv.append(B.csr_to_arrays(Pl.contents.diag))
+                lv.append(B.csr_to_arrays(Pl.contents.diagT))
+                cf = C.cast(lib.hypre_amd_BoomerAMGGetCFMarker(s, l), C.POINTER(B.IntArray)).contents
+                lv.append((B.fetch(cf.data, cf.size, np.int32, cf.memory_location),))
+            l1p = lib.hypre_amd_BoomerAMGGetL1Norms(s, l)
+            if l1p:
+                lv.append((B.vec_to_numpy(C.cast(l1p, C.POINTER(B.Vector))),))
+        hier.append(lv)
+        lib.HYPRE_BoomerAMGDestroy(s)
+    lib.hypre_amd_SetSetupDeviceRAP(1, 20000)
+    lib.hypre_amd_SetSetupDeviceInterp(1)
+    lib.hypre_amd_SetSetupDeviceCoarsen(1)
+    assert len(hier[0]) == len(hier[1])
+    for m0, m1 in zip(hier[0], hier[1]):
+        assert len(m0) == len(m1)
+        for a, b in zip(m0, m1):
+            assert np.array_equal(a, b)
