@@ -110,6 +110,8 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
 
    for (int i = blockIdx.x; i < n; i += gridDim.x)
    {
+      // some row did not fit the tables: this attempt is lost, leave it to the next one
+      if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { break; }
       tag++;
       int len = 0;
       bool bad = false;
@@ -320,10 +322,15 @@ bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const i
       HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * (size_t) n * (size_t) max_elmts));
       HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * (size_t) n * (size_t) max_elmts));
    }
+   // Tables sized by what rows of such operators need, smallest first: the rows are walked neighbour by neighbour and
+   // the kernel lives on the number of rows in flight (64 entries: 32 waves a CU; 256: 8).  Short rows of A (a stencil
+   // on the fine level) start at the bottom of the ladder; an overflowing row sends everyone to the next rung.
+   const int maxA = device_max_row_nnz(Ai, n, s);
+   const int room[4] = {64, 128, 256, 1024};
    int capR = 0, capM = 0, h_flag = 1;
-   for (int attempt = 0; attempt < 2 && h_flag; attempt++)
+   for (int attempt = maxA <= 8 ? 0 : (maxA <= 32 ? 1 : 2); attempt < 4 && h_flag; attempt++)
    {
-      capR = attempt == 0 ? 256 : 1024;
+      capR = room[attempt];
       // the map also holds the strong F neighbours of the row
       capM = pow2_ge(4 * capR);
       if (lds(capM, capR) > budget) { break; }

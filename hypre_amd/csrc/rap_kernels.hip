@@ -62,7 +62,32 @@ __device__ __forceinline__ int lanes_below(unsigned long long ballot, int lane)
 
 }  // namespace
 
+// inclusive scan of one int per lane over the wave
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+{
+   for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off, 64); if (lane >= off) { v += u; } }
+   return v;
+}
+
+// Which of the (up to 64) source rows whose inclusive entry counts are incl[0..63] holds flattened entry t: the first s
+// with incl[s] > t.
+__device__ __forceinline__ int owner_of(const int *incl, int t)
+{
+   int lo = 0;
+#pragma unroll
+   for (int step = 32; step > 0; step >>= 1) { if (incl[lo + step - 1] <= t) { lo += step; } }
+   return lo;
+}
+
 // FILL = false: row lengths only.  One wave per workgroup; workgroups walk the rows with stride gridDim.
+//
+// The host loop nests "for every entry of R(ic,:) — for every entry of that row of A" and "for every entry of RA — for
+// every entry of that row of P".  Walking it that way costs a round trip to memory per outer entry (pointer, then row),
+// 160 of them for a row of the fine level's product and thousands further down, and the kernel spent its time waiting.
+// Here the outer entries are taken 64 at a time: their row pointers in one request, then the rows' entries FLATTENED —
+// 64 consecutive entries of the concatenated rows per request, whichever rows they belong to — and only the table
+// work (look-up, append in entry order, accumulate) still goes row by row, on what already sits in registers.  The
+// order of every append and of every sum is the host's.
 template <bool FILL>
 __global__ __launch_bounds__(64)
 void rap_rows_kernel(int nc, int square,
@@ -71,17 +96,20 @@ void rap_rows_kernel(int nc, int square,
                      const int *__restrict__ Pi, const int *__restrict__ Pj, const double *__restrict__ Pa,
                      int capA, int capRA, int capP, int capO,
                      int *__restrict__ rowlen, const int *__restrict__ Ci, int *__restrict__ Cj, double *__restrict__ Ca,
-                     int *__restrict__ overflow)
+                     int *overflow)
 {
    extern __shared__ __align__(16) unsigned char smem[];
    unsigned long long *Akey = reinterpret_cast<unsigned long long *>(smem);
    unsigned long long *Pkey = Akey + capA;
    double *raa = reinterpret_cast<double *>(Pkey + capP);
    double *oa  = raa + capRA;
-   int *Apos = reinterpret_cast<int *>(oa + capO);
+   double *sval = oa + capO;                   // [64] multiplier of every source row of the batch
+   int *Apos = reinterpret_cast<int *>(sval + 64);
    int *Ppos = Apos + capA;
    int *raj  = Ppos + capP;
    int *oj   = raj + capRA;
+   int *sincl = oj + capO;                     // [64] inclusive entry counts of the batch's source rows
+   int *sbeg  = sincl + 64;                    // [64] where every source row starts in its matrix
    const int lane = threadIdx.x;
    for (int i = lane; i < capA; i += 64) { Akey[i] = 0; }
    for (int i = lane; i < capP; i += 64) { Pkey[i] = 0; }
@@ -90,37 +118,56 @@ void rap_rows_kernel(int nc, int square,
    unsigned tag = 0;
    for (int ic = blockIdx.x; ic < nc; ic += gridDim.x)
    {
+      // some row did not fit the tables: this attempt is lost, leave it to the next one
+      if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { break; }
       tag++;                                   // tag 0 = the cleared table
       // ---- RA = sum r * A(i1,:), first-touch order
       int nRA = 0;
       bool bad = false;
-      for (int j1 = Ri[ic]; j1 < Ri[ic + 1]; j1++)
+      const int r0 = Ri[ic], r1 = Ri[ic + 1];
+      for (int rb = r0; rb < r1 && !bad; rb += 64)
       {
-         const int i1 = Rj[j1];
-         const double r = FILL ? Ra[j1] : 0.0;
-         const int a0 = Ai[i1], a1 = Ai[i1 + 1];
-         for (int base = a0; base < a1; base += 64)
+         const int j1 = rb + lane;
+         const bool src_here = j1 < r1;
+         const int i1 = src_here ? Rj[j1] : 0;
+         const int a0 = src_here ? Ai[i1] : 0;
+         const int len = src_here ? Ai[i1 + 1] - a0 : 0;
+         const int incl = wave_scan_incl(len, lane);
+         sincl[lane] = incl; sbeg[lane] = a0;
+         if (FILL) { sval[lane] = src_here ? Ra[j1] : 0.0; }
+         __syncthreads();
+         const int total = sincl[63];
+         for (int cb = 0; cb < total && !bad; cb += 64)
          {
-            const int j2 = base + lane;
-            const bool have = j2 < a1;
+            const int t = cb + lane;
+            const bool have = t < total;
+            const int src = have ? owner_of(sincl, t) : 64;
+            const int j2 = have ? sbeg[src] + (t - (src ? sincl[src - 1] : 0)) : 0;
             const int i2 = have ? Aj[j2] : -1;
-            const double v = (FILL && have) ? r * Aa[j2] : 0.0;
-            const int m = have ? table_find(Akey, Apos, capA - 1, tag, i2) : 0;
-            const bool fresh = have && m < 0;
-            const unsigned long long ball = __ballot(fresh);
-            const int p = nRA + lanes_below(ball, lane);
-            if (nRA + __popcll(ball) > capRA) { bad = true; break; }
-            if (fresh)
+            const double v = (FILL && have) ? sval[src] * Aa[j2] : 0.0;
+            const int s_lo = __builtin_amdgcn_readfirstlane(src);
+            const int s_hi = __builtin_amdgcn_readfirstlane(owner_of(sincl, min(cb + 63, total - 1)));
+            for (int sr = s_lo; sr <= s_hi; sr++)
             {
-               table_insert(Akey, Apos, capA - 1, tag, i2, p);
-               raj[p] = i2;
-               if (FILL) { raa[p] = v; }
+               const bool mine = have && src == sr;
+               if (__ballot(mine) == 0ull) { continue; }
+               const int m = mine ? table_find(Akey, Apos, capA - 1, tag, i2) : 0;
+               const bool fresh = mine && m < 0;
+               const unsigned long long ball = __ballot(fresh);
+               const int p = nRA + lanes_below(ball, lane);
+               if (nRA + __popcll(ball) > capRA) { bad = true; break; }
+               if (fresh)
+               {
+                  table_insert(Akey, Apos, capA - 1, tag, i2, p);
+                  raj[p] = i2;
+                  if (FILL) { raa[p] = v; }
+               }
+               else if (FILL && mine) { raa[m] += v; }
+               nRA += __popcll(ball);
+               __syncthreads();
             }
-            else if (FILL && have) { raa[m] += v; }
-            nRA += __popcll(ball);
-            __syncthreads();
          }
-         if (bad) { break; }
+         __syncthreads();
       }
       // ---- row = RA * P, first-touch order behind the diagonal slot
       int nO = 0;
@@ -132,31 +179,49 @@ void rap_rows_kernel(int nc, int square,
             nO = 1;
             __syncthreads();
          }
-         for (int q = 0; q < nRA && !bad; q++)
+         for (int qb = 0; qb < nRA && !bad; qb += 64)
          {
-            const int i1 = raj[q];
-            const double rap = FILL ? raa[q] : 0.0;
-            const int p0 = Pi[i1], p1 = Pi[i1 + 1];
-            for (int base = p0; base < p1; base += 64)
+            const int q = qb + lane;
+            const bool src_here = q < nRA;
+            const int i1 = src_here ? raj[q] : 0;
+            const int p0 = src_here ? Pi[i1] : 0;
+            const int len = src_here ? Pi[i1 + 1] - p0 : 0;
+            const int incl = wave_scan_incl(len, lane);
+            sincl[lane] = incl; sbeg[lane] = p0;
+            if (FILL) { sval[lane] = src_here ? raa[q] : 0.0; }
+            __syncthreads();
+            const int total = sincl[63];
+            for (int cb = 0; cb < total && !bad; cb += 64)
             {
-               const int j2 = base + lane;
-               const bool have = j2 < p1;
+               const int t = cb + lane;
+               const bool have = t < total;
+               const int src = have ? owner_of(sincl, t) : 64;
+               const int j2 = have ? sbeg[src] + (t - (src ? sincl[src - 1] : 0)) : 0;
                const int i2 = have ? Pj[j2] : -1;
-               const int m = have ? table_find(Pkey, Ppos, capP - 1, tag, i2) : 0;
-               const bool fresh = have && m < 0;
-               const unsigned long long ball = __ballot(fresh);
-               const int p = nO + lanes_below(ball, lane);
-               if (nO + __popcll(ball) > capO) { bad = true; break; }
-               if (fresh)
+               const double v = (FILL && have) ? sval[src] * Pa[j2] : 0.0;
+               const int s_lo = __builtin_amdgcn_readfirstlane(src);
+               const int s_hi = __builtin_amdgcn_readfirstlane(owner_of(sincl, min(cb + 63, total - 1)));
+               for (int sr = s_lo; sr <= s_hi; sr++)
                {
-                  table_insert(Pkey, Ppos, capP - 1, tag, i2, p);
-                  oj[p] = i2;
-                  if (FILL) { oa[p] = rap * Pa[j2]; }
+                  const bool mine = have && src == sr;
+                  if (__ballot(mine) == 0ull) { continue; }
+                  const int m = mine ? table_find(Pkey, Ppos, capP - 1, tag, i2) : 0;
+                  const bool fresh = mine && m < 0;
+                  const unsigned long long ball = __ballot(fresh);
+                  const int p = nO + lanes_below(ball, lane);
+                  if (nO + __popcll(ball) > capO) { bad = true; break; }
+                  if (fresh)
+                  {
+                     table_insert(Pkey, Ppos, capP - 1, tag, i2, p);
+                     oj[p] = i2;
+                     if (FILL) { oa[p] = v; }
+                  }
+                  else if (FILL && mine) { oa[m] += v; }
+                  nO += __popcll(ball);
+                  __syncthreads();
                }
-               else if (FILL && have) { oa[m] += rap * Pa[j2]; }
-               nO += __popcll(ball);
-               __syncthreads();
             }
+            __syncthreads();
          }
       }
       if (bad) { if (lane == 0) { atomicExch(overflow, 1); } nO = 0; }
@@ -206,10 +271,10 @@ bool device_rap(int nc, int ncP, int maxP,
    HIP_CHECK(hipStreamSynchronize(s));
    const int ubA = std::max(h_scr[0], 1);
    auto lds_bytes = [](int capA, int capRA, int capP, int capO)
-   { return (size_t) 8 * capA + 8 * capP + 8 * capRA + 8 * capO + 4 * capA + 4 * capP + 4 * capRA + 4 * capO + 64; };
+   { return (size_t) 8 * capA + 8 * capP + 8 * capRA + 8 * capO + 8 * 64 + 4 * capA + 4 * capP + 4 * capRA + 4 * capO + 4 * 128 + 64; };
    // Pass 1 (lengths).  The tables are sized by what rows of such products usually need, not by the worst case the
    // bounds allow (RA <= sum of the touched rows of A; the row <= RA x longest row of P): a first attempt with small
-   // tables (six workgroups per CU), a second one with four times the room if any row overflowed, the host after that.
+   // tables, the next with four times the room if any row overflowed, the host after the last.
    const long long ubO = std::min<long long>((long long) ubA * std::max(maxP, 1) + 1, (long long) ncP);
    const size_t budget = 150 * 1024;
    (void) hipFuncSetAttribute((const void *) rap_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
@@ -219,11 +284,14 @@ bool device_rap(int nc, int ncP, int maxP,
    const int waves = std::min(nc, handle().num_cus * 32);
    int capRA = 0, capA = 0, capO = 0, capP = 0;
    bool done = false;
-   for (int attempt = 0; attempt < 2 && !done; attempt++)
+   // (the rows are walked entry by entry: the kernel lives on the number of rows in flight, i.e. on small tables.
+   // Products of a fine level with short rows — RA of at most 128 columns — start with tables a quarter the size.)
+   const int roomRA[3] = {128, 384, 1536}, roomO[3] = {64, 192, 768};
+   for (int attempt = ubA <= roomRA[0] ? 0 : 1; attempt < 3 && !done; attempt++)
    {
-      capRA = (std::min(ubA, attempt == 0 ? 384 : 1536) + 1) & ~1;
+      capRA = (std::min(ubA, roomRA[attempt]) + 1) & ~1;
       capA = pow2_at_least(2 * capRA);
-      capO = (int) ((std::min<long long>(ubO, attempt == 0 ? 192 : 768) + 1) & ~1LL);
+      capO = (int) ((std::min<long long>(ubO, roomO[attempt]) + 1) & ~1LL);
       capP = pow2_at_least(2 * capO);
       if (lds_bytes(capA, capRA, capP, capO) > budget) { break; }
       HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
