@@ -1856,8 +1856,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       fine_size = Al->global_num_rows;
       if (level > 0)
       {
-         d->F_array[level] = new_vec(comm, fine_size, Al->row_starts, HYPRE_MEMORY_HOST);
-         d->U_array[level] = new_vec(comm, fine_size, Al->row_starts, HYPRE_MEMORY_HOST);
+         d->F_array[level] = new_vec(comm, fine_size, Al->row_starts, target);
+         d->U_array[level] = new_vec(comm, fine_size, Al->row_starts, target);
       }
       hypre_ParCSRMatrix *S = nullptr;
       const double t_s0 = omp_get_wtime();
@@ -1980,8 +1980,8 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    if (num_levels > 1 && !d->F_array[num_levels - 1])
    {
       hypre_ParCSRMatrix *Al = hostA[(size_t) num_levels - 1];
-      d->F_array[num_levels - 1] = new_vec(comm, Al->global_num_rows, Al->row_starts, HYPRE_MEMORY_HOST);
-      d->U_array[num_levels - 1] = new_vec(comm, Al->global_num_rows, Al->row_starts, HYPRE_MEMORY_HOST);
+      d->F_array[num_levels - 1] = new_vec(comm, Al->global_num_rows, Al->row_starts, target);
+      d->U_array[num_levels - 1] = new_vec(comm, Al->global_num_rows, Al->row_starts, target);
    }
 
    // coarsest-level solver (par_amg_setup.c:3165-3200)
@@ -2093,13 +2093,13 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    }
 
    // work vectors sized for the finest level (par_amg_setup.c:846-880: Chebyshev needs two more)
-   d->Vtemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
-   d->Ztemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
+   d->Vtemp = new_vec(comm, A->global_num_rows, A->row_starts, target);
+   d->Ztemp = new_vec(comm, A->global_num_rows, A->row_starts, target);
    d->Rtemp = nullptr; d->Ptemp = nullptr;
    if (uses_cheby)
    {
-      d->Ptemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
-      d->Rtemp = new_vec(comm, A->global_num_rows, A->row_starts, HYPRE_MEMORY_HOST);
+      d->Ptemp = new_vec(comm, A->global_num_rows, A->row_starts, target);
+      d->Rtemp = new_vec(comm, A->global_num_rows, A->row_starts, target);
    }
 
    // algorithmic bytes of one V(1,1) cycle on this hierarchy: per level below the

@@ -228,11 +228,22 @@ void rap_rows_kernel(int nc, int square,
       if (!FILL) { if (lane == 0) { rowlen[ic] = nO; } }
       else
       {
-         const int c0 = Ci[ic];
+         // exact offsets (second pass of two) or a fixed stride per row (single pass: lengths come out as well)
+         const size_t c0 = Ci ? (size_t) Ci[ic] : (size_t) ic * (size_t) capO;
+         if (!Ci && lane == 0) { rowlen[ic] = nO; }
          for (int k = lane; k < nO; k += 64) { Cj[c0 + k] = oj[k]; Ca[c0 + k] = oa[k]; }
       }
       __syncthreads();
    }
+}
+
+// rows written with a fixed stride -> CSR
+__global__ void rap_compact_kernel(int n, int stride, const int *__restrict__ Ci, const int *__restrict__ sj, const double *__restrict__ sa,
+                                   int *__restrict__ Cj, double *__restrict__ Ca)
+{
+   const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+   const int i = (int) (t / (size_t) stride), k = (int) (t % (size_t) stride);
+   if (i < n && k < Ci[i + 1] - Ci[i]) { Cj[Ci[i] + k] = sj[t]; Ca[Ci[i] + k] = sa[t]; }
 }
 
 // per coarse row: sum of the lengths of the rows of A it touches (bounds the length of RA), maximum over all rows
@@ -283,10 +294,16 @@ bool device_rap(int nc, int ncP, int maxP,
    HIP_CHECK(hipMalloc((void **) &rowlen, sizeof(int) * ((size_t) nc + 1)));
    const int waves = std::min(nc, handle().num_cus * 32);
    int capRA = 0, capA = 0, capO = 0, capP = 0;
-   bool done = false;
+   bool done = false, single = false;
+   int *sj = nullptr;
+   double *sa = nullptr;
    // (the rows are walked entry by entry: the kernel lives on the number of rows in flight, i.e. on small tables.
    // Products of a fine level with short rows — RA of at most 128 columns — start with tables a quarter the size.)
+   // The walk is the cost, so it is done ONCE where memory allows: rows go to a scratch array with room for capO entries
+   // each, their lengths come out of the same pass, a copy packs them.  (With less room: lengths first, then a second
+   // walk that writes at the exact offsets.)
    const int roomRA[3] = {128, 384, 1536}, roomO[3] = {64, 192, 768};
+   const size_t scratch_limit = (size_t) 24 << 30;
    for (int attempt = ubA <= roomRA[0] ? 0 : 1; attempt < 3 && !done; attempt++)
    {
       capRA = (std::min(ubA, roomRA[attempt]) + 1) & ~1;
@@ -295,40 +312,61 @@ bool device_rap(int nc, int ncP, int maxP,
       capP = pow2_at_least(2 * capO);
       if (lds_bytes(capA, capRA, capP, capO) > budget) { break; }
       HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
-      hipLaunchKernelGGL((rap_rows_kernel<false>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
-                         Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, (int *) nullptr,
-                         (double *) nullptr, d_scr + 1);
+      const size_t slots = (size_t) nc * (size_t) capO;
+      single = slots * 12 <= scratch_limit;
+      if (single)
+      {
+         HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * slots));
+         HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * slots));
+         hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
+                            Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, sj, sa, d_scr + 1);
+      }
+      else
+      {
+         hipLaunchKernelGGL((rap_rows_kernel<false>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
+                            Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, (int *) nullptr,
+                            (double *) nullptr, d_scr + 1);
+      }
       HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
       done = h_scr[1] == 0;
+      if (!done && single) { HIP_CHECK(hipFree(sj)); HIP_CHECK(hipFree(sa)); sj = nullptr; sa = nullptr; }
       if (capRA >= ubA && capO >= ubO) { break; }        // the bounds themselves fitted: nothing larger to try
    }
-   if (!done) { HIP_CHECK(hipFree(rowlen)); HIP_CHECK(hipFree(d_scr)); return false; }
-   // row pointers: exclusive scan on the host (one pass over nc integers)
-   std::vector<int> hl((size_t) nc + 1, 0);
-   HIP_CHECK(hipMemcpyAsync(hl.data(), rowlen, sizeof(int) * (size_t) nc, hipMemcpyDeviceToHost, s));
+   auto give_up = [&]() { HIP_CHECK(hipFree(rowlen)); HIP_CHECK(hipFree(d_scr)); if (sj) { HIP_CHECK(hipFree(sj)); } if (sa) { HIP_CHECK(hipFree(sa)); } return false; };
+   if (!done) { return give_up(); }
+   // row pointers: exclusive scan of the lengths, in place
+   launch_scan_exclusive(rowlen, nc, s);
+   int nnz = 0;
+   HIP_CHECK(hipMemcpyAsync(&nnz, rowlen + nc, sizeof(int), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
-   int maxlen = 0;
-   long long run = 0;
-   for (int i = 0; i < nc; i++) { const int l = hl[(size_t) i]; maxlen = std::max(maxlen, l); hl[(size_t) i] = (int) run; run += l; }
-   hl[(size_t) nc] = (int) run;
-   if (run > 0x7fffffffLL) { HIP_CHECK(hipFree(rowlen)); HIP_CHECK(hipFree(d_scr)); return false; }
-   const int nnz = (int) run;
+   if (nnz < 0) { return give_up(); }               // more than 2^31 - 1 entries
    int *Ci = rowlen, *Cj = nullptr;
    double *Ca = nullptr;
-   HIP_CHECK(hipMemcpyAsync(Ci, hl.data(), sizeof(int) * ((size_t) nc + 1), hipMemcpyHostToDevice, s));
    HIP_CHECK(hipMalloc((void **) &Cj, sizeof(int) * (size_t) std::max(nnz, 1)));
    HIP_CHECK(hipMalloc((void **) &Ca, sizeof(double) * (size_t) std::max(nnz, 1)));
-   // pass 2 (columns and values): the output tables need only hold the longest row found
-   capO = (std::max(maxlen, 1) + 1) & ~1;
-   capP = pow2_at_least(2 * capO);
-   HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
-   hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
-                      Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, (int *) nullptr, Ci, Cj, Ca, d_scr + 1);
-   HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
-   HIP_CHECK(hipStreamSynchronize(s));
-   HIP_CHECK(hipFree(d_scr));
-   if (h_scr[1]) { HIP_CHECK(hipFree(Ci)); HIP_CHECK(hipFree(Cj)); HIP_CHECK(hipFree(Ca)); return false; }
+   if (single)
+   {
+      const size_t slots = (size_t) nc * (size_t) capO;
+      hipLaunchKernelGGL(rap_compact_kernel, dim3((unsigned) ((slots + 255) / 256)), dim3(256), 0, s, nc, capO, Ci, sj, sa, Cj, Ca);
+      HIP_CHECK(hipStreamSynchronize(s));
+      HIP_CHECK(hipFree(sj)); HIP_CHECK(hipFree(sa));
+      HIP_CHECK(hipFree(d_scr));
+   }
+   else
+   {
+      // pass 2 (columns and values): the output tables need only hold the longest row found
+      const int maxlen = device_max_row_nnz(Ci, nc, s);
+      capO = (std::max(maxlen, 1) + 1) & ~1;
+      capP = pow2_at_least(2 * capO);
+      HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
+      hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
+                         Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, (int *) nullptr, Ci, Cj, Ca, d_scr + 1);
+      HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      HIP_CHECK(hipFree(d_scr));
+      if (h_scr[1]) { HIP_CHECK(hipFree(Ci)); HIP_CHECK(hipFree(Cj)); HIP_CHECK(hipFree(Ca)); return false; }
+   }
    *Ci_out = Ci; *Cj_out = Cj; *Ca_out = Ca; *nnz_out = nnz;
    return true;
 }
