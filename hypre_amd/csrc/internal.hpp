@@ -210,8 +210,8 @@ bool device_rap(int nc, int ncP, int maxP, const int *Ri, const int *Rj, const d
                 int *nnz_out, hipStream_t s);
 // extended+i interpolation rows on the device, bit-identical to the host setup's (interp_kernels.hip); false: use the host
 bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const int *Si, const int *Sj, const int *CF,
-                  const int *f2c, double trunc_tol, int max_elmts, int **Pi_out, int **Pj_out, double **Pa_out, int *nnz_out,
-                  hipStream_t s);
+                  const int *f2c, double trunc_tol, int max_elmts, int first_rung, int **Pi_out, int **Pj_out, double **Pa_out,
+                  int *nnz_out, hipStream_t s);
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s);   // [entry][component] -> column by column
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s);
 void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s);

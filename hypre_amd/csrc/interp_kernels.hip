@@ -56,16 +56,39 @@ __device__ __forceinline__ void map_set(unsigned long long *tab, int *val, int m
 
 __device__ __forceinline__ int below(unsigned long long ballot, int lane) { return __popcll(ballot & ((1ull << lane) - 1ull)); }
 
+// v of lane l, l the same for the whole wave (v_readlane: no trip through the LDS crossbar)
+__device__ __forceinline__ double lane_value(double v, int l)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+   return __hiloint2double(hi, lo);
+}
+// inclusive scan of one int per lane over the wave
+__device__ __forceinline__ int wave_scan_incl(int v, int lane)
+{
+   for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(v, off, 64); if (lane >= off) { v += u; } }
+   return v;
+}
+// which of the batch's source rows (inclusive entry counts incl[0..63]) holds flattened entry t: the first s with incl[s] > t
+__device__ __forceinline__ int owner_of(const int *incl, int t)
+{
+   int lo = 0;
+#pragma unroll
+   for (int step = 32; step > 0; step >>= 1) { if (incl[lo + step - 1] <= t) { lo += step; } }
+   return lo;
+}
+
 // utilities/qsort.c:395-417 (decreasing |w|; the tie order is part of the contract), recursion unrolled on a stack:
 // the left part of a split is sorted before the right one, as the recursive routine does
-__device__ void qsort2_abs_dev(int *v, double *w, int n, int *stack)
+// Only the first `keep` entries of the sorted row are used afterwards, in the order the sort leaves them: a part that
+// lies entirely behind them is not sorted (a partition permutes its own range only, so the front does not notice).
+__device__ void qsort2_abs_dev(int *v, double *w, int n, int keep, int *stack)
 {
    int top = 0;
    stack[top++] = 0; stack[top++] = n - 1;
    while (top > 0)
    {
       const int right = stack[--top], left = stack[--top];
-      if (left >= right) { continue; }
+      if (left >= right || left >= keep) { continue; }
       const int mid = (left + right) / 2;
       { const int tv = v[left]; v[left] = v[mid]; v[mid] = tv; const double tw = w[left]; w[left] = w[mid]; w[mid] = tw; }
       int last = left;
@@ -99,9 +122,15 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
    extern __shared__ __align__(16) unsigned char smem[];
    unsigned long long *Mkey = reinterpret_cast<unsigned long long *>(smem);
    double *pa = reinterpret_cast<double *>(Mkey + capM);
-   int *Mval = reinterpret_cast<int *>(pa + capR);
+   double *s_a = pa + capR;              // [64] value of every source entry of the batch
+   int *Mval = reinterpret_cast<int *>(s_a + 64);
    int *pj = Mval + capM;
    int *stack = pj + capR;               // 4 * capR + 8 ints
+   int *sincl = stack + 4 * capR + 8;    // [64] inclusive entry counts of the batch's source rows
+   int *sbeg  = sincl + 64;              // [64] where every source row starts in its matrix
+   int *s_i1  = sbeg + 64;               // [64] the source entries' columns
+   int *s_cf  = s_i1 + 64;               // [64] their C/F markers
+   int *s_x   = s_cf + 64;               // [64] their coarse numbers (set discovery) / map values (weights)
    const int lane = threadIdx.x;
    for (int i = lane; i < capM; i += 64) { Mkey[i] = 0; }
    __syncthreads();
@@ -124,104 +153,164 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
       }
       else if (cf_i != -3)
       {
+         // The host loop walks the strong neighbours one by one and, for an F neighbour, that neighbour's own strong
+         // neighbours: a round trip to memory per step.  Here the row's neighbours are taken 64 at a time (columns,
+         // markers, coarse numbers, row pointers: two requests), the F neighbours' rows FLATTENED (64 consecutive entries
+         // of their concatenation per request, with markers and coarse numbers), and the walk itself — look-ups, appends
+         // in entry order — runs over what sits in registers and LDS, in the host's order.
          // ---- the interpolatory set, in first-touch order
-         for (int jj = Si[i]; jj < Si[i + 1] && !bad; jj++)
+         const int s0 = Si[i], s1 = Si[i + 1];
+         for (int sb = s0; sb < s1 && !bad; sb += 64)
          {
-            const int i1 = Sj[jj];
-            const int cf1 = CF[i1];
-            if (cf1 >= 0)
+            const int jj = sb + lane;
+            const bool src_here = jj < s1;
+            const int i1 = src_here ? Sj[jj] : 0;
+            const int cf1 = src_here ? CF[i1] : -3;
+            const bool ftype = src_here && cf1 < 0 && cf1 != -3;
+            const int b0 = ftype ? Si[i1] : 0;
+            const int len1 = ftype ? Si[i1 + 1] - b0 : 0;
+            const int fc = src_here ? f2c[i1] : 0;
+            const int incl = wave_scan_incl(len1, lane);
+            sincl[lane] = incl; sbeg[lane] = b0; s_i1[lane] = i1; s_cf[lane] = cf1; s_x[lane] = fc;
+            __syncthreads();
+            const int nsrc = min(64, s1 - sb), total = sincl[63];
+            int loaded = -1, k1 = 0, fck = 0;
+            bool isc = false;
+            for (int sl = 0; sl < nsrc && !bad; sl++)
             {
-               const int m = map_get(Mkey, Mval, mask, tag, i1);
-               if (m < 0)
+               const int ci1 = s_i1[sl], ccf = s_cf[sl];
+               if (ccf >= 0)
                {
-                  if (len + 1 > capR) { bad = true; break; }
-                  if (lane == 0) { map_set(Mkey, Mval, mask, tag, i1, len); pj[len] = f2c[i1]; pa[len] = 0.0; }
-                  len++;
-               }
-               __syncthreads();
-            }
-            else if (cf1 != -3)
-            {
-               if (lane == 0) { map_set(Mkey, Mval, mask, tag, i1, STRONG_F); }
-               __syncthreads();
-               const int s0 = Si[i1], s1 = Si[i1 + 1];
-               for (int base = s0; base < s1; base += 64)
-               {
-                  const int kk = base + lane;
-                  const bool have = kk < s1;
-                  const int k1 = have ? Sj[kk] : 0;
-                  const bool isc = have && CF[k1] >= 0;
-                  const bool fresh = isc && map_get(Mkey, Mval, mask, tag, k1) < 0;
-                  const unsigned long long ball = __ballot(fresh);
-                  if (len + __popcll(ball) > capR) { bad = true; break; }
-                  if (fresh)
+                  const int m = map_get(Mkey, Mval, mask, tag, ci1);
+                  if (m < 0)
                   {
-                     const int p = len + below(ball, lane);
-                     map_set(Mkey, Mval, mask, tag, k1, p);
-                     pj[p] = f2c[k1]; pa[p] = 0.0;
+                     if (len + 1 > capR) { bad = true; break; }
+                     if (lane == 0) { map_set(Mkey, Mval, mask, tag, ci1, len); pj[len] = s_x[sl]; pa[len] = 0.0; }
+                     len++;
                   }
-                  len += __popcll(ball);
                   __syncthreads();
                }
+               else if (ccf != -3)
+               {
+                  if (lane == 0) { map_set(Mkey, Mval, mask, tag, ci1, STRONG_F); }
+                  __syncthreads();
+                  const int e0 = sl ? sincl[sl - 1] : 0, e1 = sincl[sl];
+                  for (int c = e0 >> 6; (c << 6) < e1; c++)
+                  {
+                     const int t = (c << 6) + lane;
+                     if (c != loaded)
+                     {
+                        const bool have = t < total;
+                        const int src = have ? owner_of(sincl, t) : 0;
+                        const int kk = have ? sbeg[src] + (t - (src ? sincl[src - 1] : 0)) : 0;
+                        k1 = have ? Sj[kk] : 0;
+                        isc = have && CF[k1] >= 0;
+                        fck = have ? f2c[k1] : 0;
+                        loaded = c;
+                     }
+                     const bool mine = t >= e0 && t < e1;
+                     const bool fresh = mine && isc && map_get(Mkey, Mval, mask, tag, k1) < 0;
+                     const unsigned long long ball = __ballot(fresh);
+                     if (len + __popcll(ball) > capR) { bad = true; break; }
+                     if (fresh)
+                     {
+                        const int p = len + below(ball, lane);
+                        map_set(Mkey, Mval, mask, tag, k1, p);
+                        pj[p] = fck; pa[p] = 0.0;
+                     }
+                     len += __popcll(ball);
+                     __syncthreads();
+                  }
+               }
             }
+            __syncthreads();
          }
          // ---- the weights
          if (!bad && MODE != 0)
          {
-            double diagonal = Aa[Ai[i]];
-            for (int jj = Ai[i] + 1; jj < Ai[i + 1]; jj++)
+            const int a0 = Ai[i], a1 = Ai[i + 1];
+            double diagonal = Aa[a0];
+            for (int ab = a0 + 1; ab < a1; ab += 64)
             {
-               const int i1 = Aj[jj];
-               const double a = Aa[jj];
-               const int m = map_get(Mkey, Mval, mask, tag, i1);
-               if (m >= 0)
+               const int jj = ab + lane;
+               const bool src_here = jj < a1;
+               const int i1 = src_here ? Aj[jj] : 0;
+               const double a = src_here ? Aa[jj] : 0.0;
+               const int m = src_here ? map_get(Mkey, Mval, mask, tag, i1) : ABSENT;
+               const bool sf = src_here && m == STRONG_F;
+               // a strong F neighbour's row is taken whole, diagonal entry (its first) included: its sign is needed
+               const int b0 = sf ? Ai[i1] : 0;
+               const int len1 = sf ? Ai[i1 + 1] - b0 : 0;
+               const int cfo = (src_here && m == ABSENT) ? CF[i1] : 0;
+               const int incl = wave_scan_incl(len1, lane);
+               sincl[lane] = incl; sbeg[lane] = b0; s_x[lane] = m; s_cf[lane] = cfo; s_a[lane] = a;
+               __syncthreads();
+               const int nsrc = min(64, a1 - ab), total = sincl[63];
+               int loaded = -1, i2 = 0;
+               double v = 0.0;
+               auto load_chunk = [&](int c)
                {
-                  if (lane == 0) { pa[m] += a; }
-                  __syncthreads();
-               }
-               else if (m == STRONG_F)
+                  const int t = (c << 6) + lane;
+                  const bool have = t < total;
+                  const int src = have ? owner_of(sincl, t) : 0;
+                  const int kk = have ? sbeg[src] + (t - (src ? sincl[src - 1] : 0)) : 0;
+                  i2 = have ? Aj[kk] : 0;
+                  v = have ? Aa[kk] : 0.0;
+                  loaded = c;
+               };
+               for (int sl = 0; sl < nsrc; sl++)
                {
-                  const int b0 = Ai[i1] + 1, b1 = Ai[i1 + 1];
-                  const int sgn = Aa[Ai[i1]] < 0 ? -1 : 1;
-                  // sum of the couplings of i1 to the set (and to i itself) that have the sign opposite to its diagonal,
-                  // added in entry order
-                  double sum = 0.0;
-                  for (int base = b0; base < b1; base += 64)
+                  const int cm = s_x[sl];
+                  const double ca = s_a[sl];
+                  if (cm >= 0)
                   {
-                     const int j1 = base + lane;
-                     const bool have = j1 < b1;
-                     const int i2 = have ? Aj[j1] : 0;
-                     const double v = have ? Aa[j1] : 0.0;
-                     const bool take = have && (sgn * v) < 0 && (i2 == i || map_get(Mkey, Mval, mask, tag, i2) >= 0);
-                     unsigned long long ball = __ballot(take);
-                     while (ball)
-                     {
-                        const int b = __ffsll((long long) ball) - 1;
-                        sum += __shfl(v, b, 64);
-                        ball &= ball - 1;
-                     }
-                  }
-                  if (sum != 0)
-                  {
-                     const double distribute = a / sum;
-                     for (int base = b0; base < b1; base += 64)
-                     {
-                        const int j1 = base + lane;
-                        const bool have = j1 < b1;
-                        const int i2 = have ? Aj[j1] : 0;
-                        const double v = have ? Aa[j1] : 0.0;
-                        const bool neg = have && (sgn * v) < 0;
-                        const int m2 = neg ? map_get(Mkey, Mval, mask, tag, i2) : ABSENT;
-                        if (m2 >= 0) { pa[m2] += distribute * v; }
-                        // at most one entry of the row is i itself
-                        const unsigned long long self = __ballot(neg && i2 == i);
-                        if (self) { diagonal += distribute * __shfl(v, __ffsll((long long) self) - 1, 64); }
-                     }
+                     if (lane == 0) { pa[cm] += ca; }
                      __syncthreads();
                   }
-                  else { diagonal += a; }
+                  else if (cm == STRONG_F)
+                  {
+                     const int e0 = sl ? sincl[sl - 1] : 0, e1 = sincl[sl];     // entry e0 is the neighbour's diagonal
+                     // sum of the couplings of i1 to the set (and to i itself) that have the sign opposite to its diagonal,
+                     // added in entry order
+                     double sum = 0.0;
+                     int sgn = 1;
+                     for (int c = e0 >> 6; (c << 6) < e1; c++)
+                     {
+                        if (c != loaded) { load_chunk(c); }
+                        if (c == (e0 >> 6)) { sgn = lane_value(v, e0 & 63) < 0 ? -1 : 1; }
+                        const int t = (c << 6) + lane;
+                        const bool mine = t > e0 && t < e1;
+                        const bool take = mine && (sgn * v) < 0 && (i2 == i || map_get(Mkey, Mval, mask, tag, i2) >= 0);
+                        unsigned long long ball = __ballot(take);
+                        while (ball)
+                        {
+                           const int b = __ffsll((long long) ball) - 1;
+                           sum += lane_value(v, b);
+                           ball &= ball - 1;
+                        }
+                     }
+                     if (sum != 0)
+                     {
+                        const double distribute = ca / sum;
+                        for (int c = e0 >> 6; (c << 6) < e1; c++)
+                        {
+                           if (c != loaded) { load_chunk(c); }
+                           const int t = (c << 6) + lane;
+                           const bool mine = t > e0 && t < e1;
+                           const bool neg = mine && (sgn * v) < 0;
+                           const int m2 = neg ? map_get(Mkey, Mval, mask, tag, i2) : ABSENT;
+                           if (m2 >= 0) { pa[m2] += distribute * v; }
+                           // at most one entry of the row is i itself
+                           const unsigned long long self = __ballot(neg && i2 == i);
+                           if (self) { diagonal += distribute * lane_value(v, __ffsll((long long) self) - 1); }
+                        }
+                        __syncthreads();
+                     }
+                     else { diagonal += ca; }
+                  }
+                  else if (s_cf[sl] != -3) { diagonal += ca; }       // weak neighbour: lumped into the diagonal
                }
-               else if (CF[i1] != -3) { diagonal += a; }       // weak neighbour: lumped into the diagonal
+               __syncthreads();
             }
             if (diagonal != 0.0) { for (int k = lane; k < len; k += 64) { pa[k] /= -diagonal; } }
             __syncthreads();
@@ -259,7 +348,7 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
             {
                double row_sum = 0.0;
                for (int k = 0; k < d1; k++) { row_sum += pa[k]; }
-               qsort2_abs_dev(pj, pa, d1, stack);
+               qsort2_abs_dev(pj, pa, d1, max_elmts, stack);
                double scale = 0.0;
                for (int k = 0; k < max_elmts; k++) { scale += pa[k]; }
                d1 = max_elmts;
@@ -301,11 +390,11 @@ static int pow2_ge(int v) { int p = 16; while (p < v) { p <<= 1; } return p; }
 // A (n x n, diagonal first), S (pattern), CF marker and fine -> coarse numbering on the device.  Returns false when a row's
 // interpolatory set does not fit LDS (the caller then uses the host loop).  The result arrays are device allocations.
 bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const int *Si, const int *Sj, const int *CF,
-                  const int *f2c, double trunc_tol, int max_elmts, int **Pi_out, int **Pj_out, double **Pa_out, int *nnz_out,
-                  hipStream_t s)
+                  const int *f2c, double trunc_tol, int max_elmts, int first_rung, int **Pi_out, int **Pj_out, double **Pa_out,
+                  int *nnz_out, hipStream_t s)
 {
    if (max_elmts <= 0 && trunc_tol > 0.0) { return false; }     // lengths would depend on the weights: not built here
-   auto lds = [](int capM, int capR) { return (size_t) 8 * capM + 8 * capR + 4 * capM + 4 * capR + 4 * (4 * capR + 8) + 64; };
+   auto lds = [](int capM, int capR) { return (size_t) 8 * capM + 8 * capR + 8 * 64 + 4 * capM + 4 * capR + 4 * (4 * capR + 8) + 4 * 64 * 5 + 64; };
    const size_t budget = 150 * 1024;
    (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
    (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
@@ -322,15 +411,18 @@ bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const i
       HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * (size_t) n * (size_t) max_elmts));
       HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * (size_t) n * (size_t) max_elmts));
    }
-   // Tables sized by what rows of such operators need, smallest first: the rows are walked neighbour by neighbour and
-   // the kernel lives on the number of rows in flight (64 entries: 32 waves a CU; 256: 8).  Short rows of A (a stencil
-   // on the fine level) start at the bottom of the ladder; an overflowing row sends everyone to the next rung.
-   const int maxA = device_max_row_nnz(Ai, n, s);
+   // Tables sized by what rows of such operators need, smallest first: the kernel lives on the number of rows in flight
+   // (tables for 64 entries: 23 waves a CU; for 256: 7), and the interpolatory sets of the benchmark hierarchy stay below
+   // 64 points on every level although the rows of A grow to 134 entries.  An overflowing row sends everyone to the next
+   // rung (the waves leave the lost attempt at their next row).
    const int room[4] = {64, 128, 256, 1024};
    int capR = 0, capM = 0, h_flag = 1;
-   for (int attempt = maxA <= 8 ? 0 : (maxA <= 32 ? 1 : 2); attempt < 4 && h_flag; attempt++)
+   const bool verbose = getenv("HYPRE_AMD_SETUP_TIMING") != nullptr;
+   const int maxA = verbose ? device_max_row_nnz(Ai, n, s) : 0;
+   for (int attempt = std::min(std::max(first_rung, 0), 3); attempt < 4 && h_flag; attempt++)
    {
       capR = room[attempt];
+      if (verbose) { fprintf(stderr, "   interpolation: %d rows, longest row of A %d, tables for %d entries\n", n, maxA, capR); }
       // the map also holds the strong F neighbours of the row
       capM = pow2_ge(4 * capR);
       if (lds(capM, capR) > budget) { break; }
@@ -350,18 +442,14 @@ bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const i
    }
    auto give_up = [&]() { HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(rowlen)); if (sj) { HIP_CHECK(hipFree(sj)); } if (sa) { HIP_CHECK(hipFree(sa)); } return false; };
    if (h_flag) { return give_up(); }
-   // row pointers (host scan of n lengths)
-   std::vector<int> hl((size_t) n + 1, 0);
-   HIP_CHECK(hipMemcpyAsync(hl.data(), rowlen, sizeof(int) * (size_t) n, hipMemcpyDeviceToHost, s));
+   // row pointers: exclusive scan of the lengths, in place
+   launch_scan_exclusive(rowlen, n, s);
+   int nnz = 0;
+   HIP_CHECK(hipMemcpyAsync(&nnz, rowlen + n, sizeof(int), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
-   long long run = 0;
-   for (int i = 0; i < n; i++) { const int l = hl[(size_t) i]; hl[(size_t) i] = (int) run; run += l; }
-   hl[(size_t) n] = (int) run;
-   if (run > 0x7fffffffLL) { return give_up(); }
-   const int nnz = (int) run;
+   if (nnz < 0) { return give_up(); }
    int *Pi = rowlen, *Pj = nullptr;
    double *Pa = nullptr;
-   HIP_CHECK(hipMemcpyAsync(Pi, hl.data(), sizeof(int) * ((size_t) n + 1), hipMemcpyHostToDevice, s));
    HIP_CHECK(hipMalloc((void **) &Pj, sizeof(int) * (size_t) std::max(nnz, 1)));
    HIP_CHECK(hipMalloc((void **) &Pa, sizeof(double) * (size_t) std::max(nnz, 1)));
    if (fixed)

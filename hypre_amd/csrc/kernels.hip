@@ -299,6 +299,38 @@ __global__ __launch_bounds__(1024) void scan_exclusive_kernel(int *__restrict__ 
    if (tid == 0) { data[n] = carry; }
 }
 
+// long arrays (launch_scan_exclusive): sum of every block of 4096 elements ...
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(const int *__restrict__ data, int n, int *__restrict__ sums)
+{
+   __shared__ int wsum[16];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const size_t base = (size_t) blockIdx.x * 4096;
+   int t = 0;
+   for (int q = 0; q < 4; q++) { const size_t i = base + 4 * (size_t) tid + q; if (i < (size_t) n) { t += data[i]; } }
+   for (int off = 32; off > 0; off >>= 1) { t += __shfl_xor(t, off, 64); }
+   if (lane == 0) { wsum[wave] = t; }
+   __syncthreads();
+   if (tid == 0) { int a = 0; for (int w = 0; w < 16; w++) { a += wsum[w]; } sums[blockIdx.x] = a; }
+}
+// ... and, the block sums scanned, every block's own exclusive scan from its offset; the last block writes the total
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(int *__restrict__ data, int n, const int *__restrict__ sums, int nb)
+{
+   __shared__ int wsum[16];
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const size_t base = (size_t) blockIdx.x * 4096;
+   int v[4], t = 0;
+   for (int q = 0; q < 4; q++) { const size_t i = base + 4 * (size_t) tid + q; v[q] = i < (size_t) n ? data[i] : 0; t += v[q]; }
+   int inc = t;
+   for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(inc, off, 64); if (lane >= off) { inc += u; } }
+   if (lane == 63) { wsum[wave] = inc; }
+   __syncthreads();
+   int before = sums[blockIdx.x];
+   for (int w = 0; w < wave; w++) { before += wsum[w]; }
+   int run = before + inc - t;
+   for (int q = 0; q < 4; q++) { const size_t i = base + 4 * (size_t) tid + q; if (i < (size_t) n) { data[i] = run; } run += v[q]; }
+   if (blockIdx.x == nb - 1 && tid == 0) { data[n] = sums[nb]; }
+}
+
 __global__ void scatter_transpose_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa,
                                          int nrows, int *__restrict__ cursor, int *__restrict__ tj, double *__restrict__ ta)
 {
@@ -459,7 +491,7 @@ void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows,
    if (nnz <= 0 || nrows <= 0) { return; }
    int grid = (int) std::min<size_t>(((size_t) nnz + 255) / 256, 65536);
    hipLaunchKernelGGL(count_columns_kernel, dim3(grid), dim3(256), 0, s, Aj, nnz, Ti);
-   hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, Ti, ncols);
+   launch_scan_exclusive(Ti, ncols, s);
    int *cursor = nullptr, *tj0 = nullptr;
    double *ta0 = nullptr;
    HIP_CHECK(hipMalloc((void **) &cursor, sizeof(int) * ((size_t) ncols + 1)));
@@ -473,9 +505,30 @@ void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows,
    HIP_CHECK(hipFree(tj0));
    if (ta0) { HIP_CHECK(hipFree(ta0)); }
 }
-// in-place exclusive scan of data[0..n), total in data[n] (the array holds n + 1 ints)
+// in-place exclusive scan of data[0..n), total in data[n] (the array holds n + 1 ints).  Short arrays: one workgroup
+// walks them; long ones: sums of 4096-element blocks, their scan (this routine again), then every block scans itself
+// from its offset.
 void launch_scan_exclusive(int *data, int n, hipStream_t s)
-{ hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, data, n); }
+{
+   if (n <= 16384) { hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, data, n); return; }
+   static int *sums[2] = {nullptr, nullptr};
+   static size_t room[2] = {0, 0};
+   static int depth = 0;
+   const int nb = (n + 4095) / 4096;
+   const int d = depth;
+   if (d >= 2) { hipLaunchKernelGGL(scan_exclusive_kernel, dim3(1), dim3(1024), 0, s, data, n); return; }
+   if (room[d] < (size_t) nb + 1)
+   {
+      if (sums[d]) { HIP_CHECK(hipFree(sums[d])); }
+      room[d] = (size_t) nb + 1 + 1024;
+      HIP_CHECK(hipMalloc((void **) &sums[d], sizeof(int) * room[d]));
+   }
+   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nb), dim3(1024), 0, s, data, n, sums[d]);
+   depth++;
+   launch_scan_exclusive(sums[d], nb, s);
+   depth--;
+   hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(1024), 0, s, data, n, sums[d], nb);
+}
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s)
 { if (n > 0 && nv > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(((size_t) n * nv + 255) / 256), dim3(256), 0, s, in, out, n, nv); }
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s)

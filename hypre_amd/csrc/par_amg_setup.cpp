@@ -1016,7 +1016,7 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       device_coarse_numbering(n, dCF, dF2C, st);
       int *dPi = nullptr, *dPj = nullptr, pnnz = 0;
       double *dPa = nullptr;
-      const bool ok = device_extpi(n, dA->i, dA->j, dA->data, dS->i, dS->j, dCF, dF2C, trunc_factor, max_elmts, &dPi, &dPj, &dPa, &pnnz, st);
+      const bool ok = device_extpi(n, dA->i, dA->j, dA->data, dS->i, dS->j, dCF, dF2C, trunc_factor, max_elmts, g_device_interp_on - 1, &dPi, &dPj, &dPa, &pnnz, st);
       if (!S_there) { hypre_CSRMatrixDestroy(dS); }
       hypre_Free(dF2C, HYPRE_MEMORY_DEVICE);
       if (ok)

@@ -254,8 +254,10 @@ HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_th
  * parcsr_mv/par_csr_triplemat.c:938-960. */
 HYPRE_Int hypre_amd_SetSetupDeviceRAP(HYPRE_Int on, HYPRE_Int min_rows);
 /* The same for the extended+i interpolation operators (interp_kernels.hip; scalar problems, levels of at least min_rows
- * rows): on = 0 keeps the host loop; returns the number built on the device since the previous call.  The reference's
- * device routine: parcsr_ls/par_lr_interp_device.c:1001. */
+ * rows): on = 0 keeps the host loop; on = 1 + k starts the kernel's ladder of table sizes (64, 128, 256, 1024 entries per
+ * row; an overflowing row moves everyone up) at rung k — the results do not depend on it, tests walk the rungs; returns
+ * the number built on the device since the previous call.  The reference's device routine:
+ * parcsr_ls/par_lr_interp_device.c:1001. */
 HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on);
 /* And for strength of connection, PMIS coarsening and the smoother diagonals (setup_kernels.hip; the HOST routines'
  * measures and results, not the reference's device variant with its own random numbers): with all three switches on, a

@@ -518,7 +518,8 @@ def test_device_galerkin_product_is_the_host_product(gpu_lib, kw):
                                 dict(n=(30, 30, 30), problem="27pt", P_max_elmts=6, trunc_factor=0.1),
                                 dict(n=(40, 40, 20), P_max_elmts=2),
                                 dict(n=(32, 32, 32), problem="difconv", c=(1.0, 0.01, 1.0), a=(3.0, 2.0, 1.0), P_max_elmts=0)])
-def test_device_interpolation_is_the_host_interpolation(gpu_lib, kw):
+@pytest.mark.parametrize("rung", [0, 2])
+def test_device_interpolation_is_the_host_interpolation(gpu_lib, kw, rung):
     """Setup with the extended+i interpolation (and its truncation) computed on the device — one wave per row, the host
     loop's statement order — and on the host: every interpolation operator and every coarse operator identical array
     for array (column order included: the truncated rows keep the order the reference's quicksort leaves them in)."""
@@ -527,7 +528,7 @@ def test_device_interpolation_is_the_host_interpolation(gpu_lib, kw):
     hier = []
     for on in (0, 1):
         lib.hypre_amd_SetSetupDeviceRAP(0, 50)
-        lib.hypre_amd_SetSetupDeviceInterp(on)
+        lib.hypre_amd_SetSetupDeviceInterp(on * (1 + rung))          # first rung of the kernel's table sizes
         opt = ij.IJOptions(relax_type=18, **dict(dict(coarsen_type=8), **kw))
         A = ij.build_matrix(opt)
         s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
