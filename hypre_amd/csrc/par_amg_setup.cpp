@@ -309,6 +309,19 @@ static HYPRE_Int *device_marker_of(const HYPRE_Int *host, HYPRE_Int n)
    t[host] = dd;
    return dd;
 }
+// a matrix of the setup goes away: so must the twins registered under its blocks' addresses (the next matrix allocated
+// there would inherit them)
+static void destroy_with_twins(hypre_ParCSRMatrix *M)
+{
+   if (!M) { return; }
+   auto &t = device_twins();
+   for (hypre_CSRMatrix *blk : {M->diag, M->offd, M->diagT, M->offdT})
+   {
+      auto it = blk ? t.find(blk) : t.end();
+      if (it != t.end()) { hypre_CSRMatrixDestroy(it->second); t.erase(it); }
+   }
+   hypre_ParCSRMatrixDestroy(M);
+}
 // A matrix born on the device is needed by a host loop after all: fetch it; its device arrays stay on as its twin.
 static void make_host_resident(hypre_CSRMatrix *M)
 {
@@ -1873,7 +1886,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       else
       {
          hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: coarsen_type must be 8 (PMIS), 9 (PMIS, sequential random numbers) or 10 (HMIS)");
-         hypre_ParCSRMatrixDestroy(S);
+         destroy_with_twins(S);
          break;
       }
       const double t_c1 = omp_get_wtime();
@@ -1895,7 +1908,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
             d->num_grid_sweeps[3] = 1;
             if (d->grid_relax_points) { d->grid_relax_points[3][0] = 0; }
          }
-         hypre_ParCSRMatrixDestroy(S);
+         destroy_with_twins(S);
          if (level > 0)
          {
             hypre_IntArrayDestroy(d->CF_marker_array[level]); d->CF_marker_array[level] = nullptr;
@@ -1907,7 +1920,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       }
       if (coarse_size < (HYPRE_BigInt) d->min_coarse_size)
       {
-         hypre_ParCSRMatrixDestroy(S);
+         destroy_with_twins(S);
          hypre_IntArrayDestroy(d->CF_marker_array[level]); d->CF_marker_array[level] = nullptr;
          if (level > 0)
          {
@@ -1940,7 +1953,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       {
          hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: interp_type must be 6 (extended+i) or 3 (direct)");
       }
-      hypre_ParCSRMatrixDestroy(S);
+      destroy_with_twins(S);
       if (!P || hypre_error_flag) { break; }
       hypre_ParCSRMatrixSetNumNonzeros(P);
       hypre_ParCSRMatrixSetDNumNonzeros(P);

@@ -17,6 +17,7 @@
 // in form.
 #include "internal.hpp"
 #include <algorithm>
+#include <omp.h>
 
 // r * a and the accumulation are separate roundings on the host (no fused multiply-add in the host build): keep them so
 #pragma clang fp contract(off)
@@ -96,7 +97,7 @@ void rap_rows_kernel(int nc, int square,
                      const int *__restrict__ Pi, const int *__restrict__ Pj, const double *__restrict__ Pa,
                      int capA, int capRA, int capP, int capO,
                      int *__restrict__ rowlen, const int *__restrict__ Ci, int *__restrict__ Cj, double *__restrict__ Ca,
-                     int *overflow)
+                     int *overflow, int row_step, int *__restrict__ maxima)
 {
    extern __shared__ __align__(16) unsigned char smem[];
    unsigned long long *Akey = reinterpret_cast<unsigned long long *>(smem);
@@ -116,7 +117,8 @@ void rap_rows_kernel(int nc, int square,
    __syncthreads();
 
    unsigned tag = 0;
-   for (int ic = blockIdx.x; ic < nc; ic += gridDim.x)
+   // row_step > 1: a pilot over every row_step-th row that only records how long RA and the row get (maxima[0], [1])
+   for (int ic = blockIdx.x * row_step; ic < nc; ic += gridDim.x * row_step)
    {
       // some row did not fit the tables: this attempt is lost, leave it to the next one
       if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { break; }
@@ -225,7 +227,8 @@ void rap_rows_kernel(int nc, int square,
          }
       }
       if (bad) { if (lane == 0) { atomicExch(overflow, 1); } nO = 0; }
-      if (!FILL) { if (lane == 0) { rowlen[ic] = nO; } }
+      if (maxima) { if (lane == 0) { atomicMax(&maxima[0], nRA); atomicMax(&maxima[1], nO); } }
+      else if (!FILL) { if (lane == 0) { rowlen[ic] = nO; } }
       else
       {
          // exact offsets (second pass of two) or a fixed stride per row (single pass: lengths come out as well)
@@ -271,6 +274,9 @@ bool device_rap(int nc, int ncP, int maxP,
                 hipStream_t s)
 {
    const bool square = (nc == ncP);
+   const bool timing = getenv("HYPRE_AMD_SETUP_TIMING") != nullptr;
+   const double t_begin = omp_get_wtime();
+   double t_alloc = 0.0, t_walk = 0.0;
    int *d_scr = nullptr;
    HIP_CHECK(hipMalloc((void **) &d_scr, sizeof(int) * 2));
    HIP_CHECK(hipMemsetAsync(d_scr, 0, sizeof(int) * 2, s));
@@ -297,41 +303,78 @@ bool device_rap(int nc, int ncP, int maxP,
    bool done = false, single = false;
    int *sj = nullptr;
    double *sa = nullptr;
-   // (the rows are walked entry by entry: the kernel lives on the number of rows in flight, i.e. on small tables.
-   // Products of a fine level with short rows — RA of at most 128 columns — start with tables a quarter the size.)
+   // The rows are walked entry by entry: the kernel lives on the number of rows in flight, i.e. on SMALL tables, and the
+   // bounds (RA <= sum of the touched rows of A; the row <= RA x longest row of P) are several times what rows need.
+   // So a pilot walks every 61st row with the largest tables that fit and reports the longest RA and the longest row it
+   // met; the tables of the real walk take that plus a quarter.  A row that overflows them sends everyone to tables
+   // half as large again (the waves leave the lost attempt at their next row), the host loop after the last.
    // The walk is the cost, so it is done ONCE where memory allows: rows go to a scratch array with room for capO entries
    // each, their lengths come out of the same pass, a copy packs them.  (With less room: lengths first, then a second
    // walk that writes at the exact offsets.)
-   const int roomRA[3] = {128, 384, 1536}, roomO[3] = {64, 192, 768};
-   const size_t scratch_limit = (size_t) 24 << 30;
-   for (int attempt = ubA <= roomRA[0] ? 0 : 1; attempt < 3 && !done; attempt++)
+   auto table_for = [](int entries) { return pow2_at_least((entries * 29 + 19) / 20); };      // load factor <= 0.69
+   int needRA = std::min(ubA, 384), needO = (int) std::min<long long>(ubO, 192);      // without a pilot (few rows)
    {
-      capRA = (std::min(ubA, roomRA[attempt]) + 1) & ~1;
-      capA = pow2_at_least(2 * capRA);
-      capO = (int) ((std::min<long long>(ubO, roomO[attempt]) + 1) & ~1LL);
-      capP = pow2_at_least(2 * capO);
+      int pRA = std::min(ubA, 1536), pO = (int) std::min<long long>(ubO, 768);
+      pRA = (pRA + 1) & ~1; pO = (pO + 1) & ~1;
+      const int pA = table_for(pRA), pP = table_for(pO);
+      if (lds_bytes(pA, pRA, pP, pO) <= budget && nc >= 4096)
+      {
+         int *d_max = nullptr;
+         HIP_CHECK(hipMalloc((void **) &d_max, sizeof(int) * 2));
+         HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int) * 2, s));
+         HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
+         const int step = 61, rows = (nc + step - 1) / step;
+         hipLaunchKernelGGL((rap_rows_kernel<false>), dim3(std::min(rows, handle().num_cus * 8)), dim3(64), lds_bytes(pA, pRA, pP, pO), s,
+                            nc, square ? 1 : 0, Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, pA, pRA, pP, pO, (int *) nullptr, (const int *) nullptr,
+                            (int *) nullptr, (double *) nullptr, d_scr + 1, step, d_max);
+         int h_max[2] = {0, 0};
+         HIP_CHECK(hipMemcpyAsync(h_max, d_max, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+         HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+         HIP_CHECK(hipStreamSynchronize(s));
+         HIP_CHECK(hipFree(d_max));
+         if (h_scr[1] == 0)
+         {
+            needRA = std::min(ubA, h_max[0] + h_max[0] / 4 + 16);
+            needO = (int) std::min<long long>(ubO, (long long) h_max[1] + h_max[1] / 4 + 8);
+         }
+      }
+   }
+   const size_t scratch_limit = (size_t) 24 << 30;
+   for (int attempt = 0; attempt < 6 && !done; attempt++)
+   {
+      capRA = (std::min(ubA, needRA) + 1) & ~1;
+      capA = table_for(capRA);
+      capO = (int) ((std::min<long long>(ubO, needO) + 1) & ~1LL);
+      capP = table_for(capO);
       if (lds_bytes(capA, capRA, capP, capO) > budget) { break; }
       HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
       const size_t slots = (size_t) nc * (size_t) capO;
       single = slots * 12 <= scratch_limit;
       if (single)
       {
+         const double ta = omp_get_wtime();
          HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * slots));
          HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * slots));
+         t_alloc += omp_get_wtime() - ta;
          hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
-                            Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, sj, sa, d_scr + 1);
+                            Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, sj, sa, d_scr + 1,
+                            1, (int *) nullptr);
       }
       else
       {
          hipLaunchKernelGGL((rap_rows_kernel<false>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
                             Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, (int *) nullptr,
-                            (double *) nullptr, d_scr + 1);
+                            (double *) nullptr, d_scr + 1, 1, (int *) nullptr);
       }
+      const double tw = omp_get_wtime();
       HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
+      t_walk += omp_get_wtime() - tw;
       done = h_scr[1] == 0;
       if (!done && single) { HIP_CHECK(hipFree(sj)); HIP_CHECK(hipFree(sa)); sj = nullptr; sa = nullptr; }
       if (capRA >= ubA && capO >= ubO) { break; }        // the bounds themselves fitted: nothing larger to try
+      needRA = std::min(ubA, needRA + needRA / 2 + 16);
+      needO = (int) std::min<long long>(ubO, (long long) needO + needO / 2 + 8);
    }
    auto give_up = [&]() { HIP_CHECK(hipFree(rowlen)); HIP_CHECK(hipFree(d_scr)); if (sj) { HIP_CHECK(hipFree(sj)); } if (sa) { HIP_CHECK(hipFree(sa)); } return false; };
    if (!done) { return give_up(); }
@@ -358,14 +401,19 @@ bool device_rap(int nc, int ncP, int maxP,
       // pass 2 (columns and values): the output tables need only hold the longest row found
       const int maxlen = device_max_row_nnz(Ci, nc, s);
       capO = (std::max(maxlen, 1) + 1) & ~1;
-      capP = pow2_at_least(2 * capO);
+      capP = table_for(capO);
       HIP_CHECK(hipMemsetAsync(d_scr + 1, 0, sizeof(int), s));
       hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
-                         Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, (int *) nullptr, Ci, Cj, Ca, d_scr + 1);
+                         Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, (int *) nullptr, Ci, Cj, Ca, d_scr + 1, 1, (int *) nullptr);
       HIP_CHECK(hipMemcpyAsync(h_scr, d_scr, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
       HIP_CHECK(hipFree(d_scr));
       if (h_scr[1]) { HIP_CHECK(hipFree(Ci)); HIP_CHECK(hipFree(Cj)); HIP_CHECK(hipFree(Ca)); return false; }
+   }
+   if (timing)
+   {
+      fprintf(stderr, "   product: %d rows, RA <= %d, tables %d / %d, %s: scratch allocation %.3fs, walk %.3fs, all %.3fs\n", nc, ubA, capRA, capO,
+              single ? "one walk" : "two walks", t_alloc, t_walk, omp_get_wtime() - t_begin);
    }
    *Ci_out = Ci; *Cj_out = Cj; *Ca_out = Ca; *nnz_out = nnz;
    return true;

@@ -4,7 +4,7 @@ set -e
 m=gpurun_out/r02_measure
 for f in c2 c4 c5 mc128 mc256 gs128 2rank_rehearsal; do tail -1 $m/bench_$f.json > profiles/r02_bench_$f.json; done
 cp $m/prof_c2/b_kernel_stats.csv profiles/r02_bench256_kernel_stats.csv
-cp $m/prof_c4/b_kernel_stats.csv profiles/r02_c4_27pt160_tsgs_kernel_stats.csv
+cp $m/prof_c4/b_kernel_stats.csv profiles/r02_c4_27pt256_tsgs_kernel_stats.csv
 cp $m/prof_c5/b_kernel_stats.csv profiles/r02_c5_difconv256_mixed_kernel_stats.csv
 python tools/trace_summary.py $m/prof_c2/b_kernel_trace.csv profiles/r02_bench256_roofline_kernel_from_trace.json
 l=gpurun_out/r02_levels_xs

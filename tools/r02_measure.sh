@@ -5,8 +5,8 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python bench.py > $out/bench_c2.json 2> $out/bench_c2.err; echo "c2 exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c2 -o b --output-format csv -- python3 bench.py --no-cpu-baseline > $out/prof_c2.log 2>&1; echo "prof exit $?"
-timeout -k 10 300 python bench.py --problem 27pt --relax 11 --grid 160 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 exit $?"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c4 -o b --output-format csv -- python3 bench.py --problem 27pt --relax 11 --grid 160 --no-cpu-baseline > $out/prof_c4.log 2>&1
+timeout -k 10 400 python bench.py --problem 27pt --relax 11 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 exit $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c4 -o b --output-format csv -- python3 bench.py --problem 27pt --relax 11 --no-cpu-baseline > $out/prof_c4.log 2>&1
 timeout -k 10 300 python bench.py --problem difconv --mixed > $out/bench_c5.json 2> $out/bench_c5.err; echo "c5 exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c5 -o b --output-format csv -- python3 bench.py --problem difconv --mixed --no-cpu-baseline > $out/prof_c5.log 2>&1
 timeout -k 10 300 python bench.py --grid 128 --relax 21 --relax-up 22 --cpu-cycles 1 > $out/bench_mc128.json 2> $out/bench_mc128.err; echo "mc128 exit $?"
