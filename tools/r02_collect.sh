@@ -10,3 +10,5 @@ python tools/trace_summary.py $m/prof_c2/b_kernel_trace.csv profiles/r02_bench25
 l=gpurun_out/r02_levels_xs
 cp $l/trace/t_kernel_stats.csv profiles/r02_levels_xs_kernel_stats.csv
 cp $l/summary.json profiles/r02_levels_xs_summary.json 2>/dev/null || true
+cp $m/prof_setup/s_kernel_stats.csv profiles/r02_setup256_kernel_stats.csv
+grep -h "setup [0-9] \|matrix generation\|setup level\|product:\|interpolation:" $m/setup_device.log $m/setup_host.log > profiles/r02_setup256_timing.txt

@@ -14,4 +14,8 @@ timeout -k 10 300 python bench.py --relax 21 --relax-up 22 --cpu-cycles 1 > $out
 timeout -k 10 300 python bench.py --grid 128 --relax 13 --relax-up 14 --cpu-cycles 1 > $out/bench_gs128.json 2> $out/bench_gs128.err; echo "gs128 exit $?"
 HYPRE_AMD_BENCH_TRANSPORT=gloo HYPRE_AMD_BENCH_SHARE_GPU=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --grid 128 --steps 10 --warmup 3 > $out/bench_2rank_rehearsal.json 2> $out/bench_2rank_rehearsal.err; echo "2rank exit $?"
 tail -2 $out/bench_2rank_rehearsal.err
+# HYPRE_BoomerAMGSetup alone (matrix handed over in device / host memory), and its kernels
+HYPRE_AMD_SETUP_TIMING=1 timeout -k 10 300 python tools/setup_time.py 256 device 3 > $out/setup_device.log 2>&1; echo "setup exit $?"
+timeout -k 10 300 python tools/setup_time.py 256 host 2 > $out/setup_host.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_setup -o s --output-format csv -- python3 tools/setup_time.py 256 device 1 > $out/prof_setup.log 2>&1
 ls $out
