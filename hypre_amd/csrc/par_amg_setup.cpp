@@ -2171,6 +2171,14 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
             a->data = dd; a->memory_location = HYPRE_MEMORY_DEVICE;
          }
       }
+      // the kernels' per-matrix plans (tile bounds, placement tables, x-staging descriptors and local indices) are part of
+      // the setup: built here, not inside the first cycle
+      for (int l = 0; l < num_levels; l++)
+      {
+         auto plan_of = [](hypre_CSRMatrix *M) { if (M && M->memory_location == HYPRE_MEMORY_DEVICE && M->num_nonzeros > 0) { (void) get_plan(M); } };
+         plan_of(d->A_array[l]->diag);
+         if (l < num_levels - 1) { plan_of(d->P_array[l]->diag); plan_of(d->P_array[l]->diagT); }
+      }
       hypre_ParVectorMigrate(d->Vtemp, HYPRE_MEMORY_DEVICE);
       hypre_ParVectorMigrate(d->Ztemp, HYPRE_MEMORY_DEVICE);
       if (d->Ptemp) { hypre_ParVectorMigrate(d->Ptemp, HYPRE_MEMORY_DEVICE); }

@@ -700,25 +700,23 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
    int *desc = xs_desc + (size_t) tile * XS_DESC;
    for (int i = tid; i < XS_DESC; i += SPMV_THREADS) { desc[i] = 0; }
    if (m <= 0 || m > XS_SORT) { if (tid == 0) { xs_cnt[tile] = 0; } return; }
-   for (int i = tid; i < XS_SORT; i += SPMV_THREADS) { key[i] = i < m ? (Aj[k0 + i] >> 1) : 0x7fffffff; }
+   // Distinct units first (a hash set in LDS: a tile's 2048 - 3000 entries name 700 - 1400 units), then a sort of those
+   // only: the bitonic network over all entries took 140 us a tile, 85 ms for the 24 matrices of the benchmark hierarchy.
+   constexpr int EMPTY = 0x7fffffff;
+   for (int i = tid; i < XS_SORT; i += SPMV_THREADS) { key[i] = EMPTY; }
    __syncthreads();
-   for (int k = 2; k <= XS_SORT; k <<= 1)
+   for (int i = tid; i < m; i += SPMV_THREADS)
    {
-      for (int j = k >> 1; j > 0; j >>= 1)
+      const int q = Aj[k0 + i] >> 1;
+      unsigned h = ((unsigned) q * 2654435761u) >> 20;            // 12 bits: XS_SORT slots
+      while (true)
       {
-         for (int i = tid; i < XS_SORT; i += SPMV_THREADS)
-         {
-            const int l = i ^ j;
-            if (l > i)
-            {
-               const int a = key[i], b = key[l];
-               const bool up = (i & k) == 0;
-               if ((a > b) == up) { key[i] = b; key[l] = a; }
-            }
-         }
-         __syncthreads();
+         const int old = atomicCAS(&key[h & (XS_SORT - 1)], EMPTY, q);
+         if (old == EMPTY || old == q) { break; }
+         h++;
       }
    }
+   __syncthreads();
    // block-wide exclusive scan of one value per lane (part[] in, part[] out inclusive; returns the total)
    auto scan = [&](int mine) -> int
    {
@@ -733,23 +731,38 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
       }
       return part[SPMV_THREADS - 1];
    };
-   // distinct units, in order: every lane scans 16 consecutive slots
+   // the set, packed (every lane looks at 16 consecutive slots) ...
    constexpr int PER = XS_SORT / SPMV_THREADS;
    int heads = 0;
-   for (int i = tid * PER; i < (tid + 1) * PER; i++)
-   {
-      if (key[i] != 0x7fffffff && (i == 0 || key[i] != key[i - 1])) { heads++; }
-   }
+   for (int i = tid * PER; i < (tid + 1) * PER; i++) { if (key[i] != EMPTY) { heads++; } }
    const int U = scan(heads);
    if (U > XS_UNITS) { if (tid == 0) { xs_cnt[tile] = 0; } return; }
    {
       int r = part[tid] - heads;
-      for (int i = tid * PER; i < (tid + 1) * PER; i++)
+      for (int i = tid * PER; i < (tid + 1) * PER; i++) { if (key[i] != EMPTY) { uniq[r++] = key[i]; } }
+   }
+   int P2 = 2;
+   while (P2 < U) { P2 <<= 1; }
+   for (int i = U + tid; i < P2; i += SPMV_THREADS) { uniq[i] = EMPTY; }
+   __syncthreads();
+   // ... and put in ascending order
+   for (int k = 2; k <= P2; k <<= 1)
+   {
+      for (int j = k >> 1; j > 0; j >>= 1)
       {
-         if (key[i] != 0x7fffffff && (i == 0 || key[i] != key[i - 1])) { uniq[r++] = key[i]; }
+         for (int i = tid; i < P2; i += SPMV_THREADS)
+         {
+            const int l = i ^ j;
+            if (l > i)
+            {
+               const int a = uniq[i], b = uniq[l];
+               const bool up = (i & k) == 0;
+               if ((a > b) == up) { uniq[i] = b; uniq[l] = a; }
+            }
+         }
+         __syncthreads();
       }
    }
-   __syncthreads();
    // Cut threshold T in {0, 1, 2, 4, ...}: a gap of more than T units between two distinct units ends a segment; a
    // segment is staged in pieces of at most XS_PIECE units.  The smallest T whose pieces fit the descriptor table wins
    // (the covered length grows with T; once it exceeds the staging capacity the tile is given up).
@@ -757,7 +770,38 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
    constexpr int XS_PIECE = 64;                 // units (2 doubles) per piece: one 16-byte load per lane of a wave
    int T = 0, npieces = 0, covered_units = 0;
    bool fits = false;
-   for (int step = 0; step < 24; step++)
+   // Where to start: a gap g is cut at thresholds 0, 1, 2, 4, ... below g; a histogram of the gaps by the last threshold
+   // that cuts them gives, for every threshold at once, the number of segments and the covered length.  A threshold that
+   // leaves more segments than descriptors, or more 64-unit pieces' worth of length, cannot fit: the exact evaluation
+   // below starts at the first one that can (level 1 of the benchmark hierarchy: at 8 instead of 0), and a tile no
+   // threshold can serve (most tiles of a restriction operator) is given up here.
+   __shared__ int hcnt[24], hsum[24];
+   if (tid < 24) { hcnt[tid] = 0; hsum[tid] = 0; }
+   __syncthreads();
+   for (int i = tid * UPER; i < (tid + 1) * UPER && i < U - 1; i++)
+   {
+      const int g = uniq[i + 1] - uniq[i] - 1;
+      if (g > 0)
+      {
+         const int last = g >= 2 ? min(32 - __clz(g - 1), 23) : 0;      // cut at thresholds 0 .. last
+         atomicAdd(&hcnt[last], 1); atomicAdd(&hsum[last], g);
+      }
+   }
+   __syncthreads();
+   int first = 24;
+   {
+      const int span = uniq[U - 1] - uniq[0] + 1;
+      int ncut = 0, cut = 0;
+      for (int k = 23; k >= 0; k--)
+      {
+         ncut += hcnt[k]; cut += hsum[k];
+         const int covered = span - cut, nseg = ncut + 1;
+         if (covered <= XS_UNITS && max(nseg, (covered + XS_PIECE - 1) / XS_PIECE) <= XS_SEGS) { first = k; }
+      }
+   }
+   if (first >= 24) { if (tid == 0) { xs_cnt[tile] = 0; } return; }
+   T = first == 0 ? 0 : 1 << (first - 1);
+   for (int step = first; step < 24; step++)
    {
       // staged position of unit i = uniq[i] - uniq[0] - (sum of the cut gaps before it); a lane owns UPER consecutive units
       int cut = 0;
