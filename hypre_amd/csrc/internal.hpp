@@ -162,7 +162,6 @@ struct SpmvArgs
    const int           *rowmap;      // epilogue row indirection (multicolour sweeps: row r of the matrix is row rowmap[r] of
                                      // the vectors b, d, x, y, marker), or null
    int                  variant;     // 0: x gathered through the cache; 2: x staged through LDS from the plan's chunk lists
-   int                  pipe_wgs;    // unused
 };
 void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 

@@ -22,15 +22,14 @@ namespace hamd {
 
 // kernel variant of the tiled family (hypre_amd_SpmvSetVariant, or HYPRE_AMD_SPMV_VARIANT read once): 2 = x staged through
 // LDS (spmv_xs_kernel; plans carry the chunk lists), 0 = x gathered through the cache (spmv_tiled_kernel)
-struct SpmvVariant { int variant, pipe_wgs; };
+struct SpmvVariant { int variant; };
 static SpmvVariant &spmv_variant()
 {
-   static SpmvVariant v = {-1, 4};
+   static SpmvVariant v = {-1};
    if (v.variant < 0)
    {
       const char *e = getenv("HYPRE_AMD_SPMV_VARIANT");
       v.variant = e ? atoi(e) : 2;
-      if ((e = getenv("HYPRE_AMD_SPMV_PIPE_WGS"))) { v.pipe_wgs = atoi(e); }
    }
    return v;
 }
@@ -53,7 +52,7 @@ void spmv_default_flags(SpmvArgs &a)
       xcd = e ? atoi(e) : 8;
    }
    a.gather_t = gt; a.xcd_map = xcd;
-   a.variant = spmv_variant().variant; a.pipe_wgs = spmv_variant().pipe_wgs;
+   a.variant = spmv_variant().variant;
    // Row-sum width of the multi-lane reduction: 8 lanes per row up to a mean row length of 128 (32 rows per pass), 32 lanes
    // beyond.  Measured on level 2 of the 256^3 hierarchy (70 entries per row, 29 rows per tile): 32 lanes per row (the
    // round-1 choice above 48) 0.123 ms, 8 lanes 0.104 ms — with the x gathers out of the way the kernel is bound by
@@ -319,11 +318,11 @@ extern "C" HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int mi
 
 // Kernel variant of the tiled SpMV family from now on: 2 = x staged through LDS (plans built from now on carry the
 // chunk lists), 0 = x gathered through the cache.  Speed only: same products, same summation order.
-extern "C" HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int pipe_wgs)
+extern "C" HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int unused)
 {
+   (void) unused;
    hamd::SpmvVariant &v = hamd::spmv_variant();
    if (variant >= 0) { v.variant = variant; }
-   if (pipe_wgs != 0) { v.pipe_wgs = pipe_wgs; }
    return hypre_error_flag;
 }
 
@@ -506,23 +505,8 @@ HYPRE_Int hypre_CSRMatrixTranspose(hypre_CSRMatrix *A, hypre_CSRMatrix **AT_ptr,
       *AT_ptr = AT;
       return hypre_error_flag;
    }
-   std::vector<HYPRE_Int> hi, hj;
-   std::vector<HYPRE_Complex> ha;
    const HYPRE_Int *Ai = A->i, *Aj = A->j;
    const HYPRE_Complex *Aa = A->data;
-   if (loc == HYPRE_MEMORY_DEVICE)
-   {
-      hi.resize((size_t) nr + 1); hj.resize((size_t) nnz);
-      hypre_TMemcpy(hi.data(), A->i, HYPRE_Int, nr + 1, HYPRE_MEMORY_HOST, loc);
-      if (nnz) { hypre_TMemcpy(hj.data(), A->j, HYPRE_Int, nnz, HYPRE_MEMORY_HOST, loc); }
-      Ai = hi.data(); Aj = hj.data();
-      if (data && A->data)
-      {
-         ha.resize((size_t) nnz);
-         if (nnz) { hypre_TMemcpy(ha.data(), A->data, HYPRE_Complex, nnz, HYPRE_MEMORY_HOST, loc); }
-         Aa = ha.data();
-      }
-   }
    const bool with_data = data && A->data;
    std::vector<HYPRE_Int> ti((size_t) nc + 1, 0), tj((size_t) nnz);
    std::vector<HYPRE_Complex> ta(with_data ? (size_t) nnz : 0);

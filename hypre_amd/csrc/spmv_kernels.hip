@@ -490,15 +490,18 @@ void spmv_tiled_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *
 // of resident tiles that sets the rate.
 //
 // So the x values a tile needs are fetched in the SAME trip as its matrix stream.  The plan records per tile up to 48
-// pieces of x, 128 doubles at most each, that cover the columns of its entries (a 2048-entry tile touches 850 - 1100
-// distinct columns in a handful of clusters: rows that are neighbours in the matrix share most of their columns), and
-// per entry a 16-bit index into the concatenation of those pieces.  The piece descriptors are wave-uniform and arrive
-// through the scalar cache (its own path, a few hundred ns); each wave then issues one 16-byte load per lane for each of
-// its twelve pieces right behind the (value, index) stream loads, the copy lands in LDS, and the "gathers" are eight LDS
-// reads per lane.  The column array
-// is not read at all: 8 + 2 bytes per entry instead of 12.  Tiles whose columns do not fit 48 pieces / 3072 doubles
-// (restriction operators: a row of P^T reaches far) take the gather path of spmv_tiled_kernel inside the same launch.
-// The staged copy and the products share LDS.
+// pieces of x, 128 doubles at most each, that cover the columns of its entries (a 2048-entry tile touches 700 - 1400
+// distinct 2-column units in a handful of clusters: rows that are neighbours in the matrix share most of their
+// columns), and per entry a 16-bit index into the concatenation of those pieces.  The piece descriptors are
+// wave-uniform and arrive through the scalar cache in one batch with the tile's bounds; each wave then issues one
+// 16-byte load per lane for each of its twelve pieces right behind the (value, index) stream loads, the copy lands in
+// LDS (global_load_lds), and the "gathers" are eight LDS reads per lane.  The column array is not read at all: 8 + 2
+// bytes per entry instead of 12.  Tiles whose columns do not fit 48 pieces / 4096 doubles (most tiles of the
+// restriction operators below level 0: a row of P^T reaches far) take the gather path of spmv_tiled_kernel inside the
+// same launch.  The staged copy and the products share LDS.
+// Tried and dropped: pieces of up to two loads (256 doubles) — fewer, longer pieces, but 24 predicated load slots per
+// wave instead of 12: levels 1 - 2 of the benchmark hierarchy 4 - 7 % slower, the restriction operators no better
+// (what keeps their tiles out is the staged volume, not the number of pieces).
 // Reference counterpart of the whole family: seq_mv/csr_spmv_device.c:35-260 (no LDS, gathers through the cache).
 // ---------------------------------------------------------------------------
 constexpr int XS_SEGS  = SPMV_XS_SEGS;      // pieces per tile: 4 waves x XS_WSEG

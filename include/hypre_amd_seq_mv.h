@@ -141,7 +141,7 @@ HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int min_tiles, HY
  * tile needs through LDS from per-tile chunk lists kept in the plan, 0 gathers x through the cache.  Takes effect for
  * plans built afterwards (a plan built under 0 has no chunk lists and keeps gathering).  variant < 0: unchanged;
  * the second argument is unused. */
-HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int pipe_wgs);
+HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int unused);
 /* x staging of the plan of the device matrix A: returns the number of tiles that take the LDS-staged path of the tiled
  * kernel; fills the plan's tile count and the mean number of x pieces of a staged tile. */
 HYPRE_Int hypre_amd_CSRMatrixPlanStaging(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Real *mean_pieces);
