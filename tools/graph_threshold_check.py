@@ -12,9 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hypre_amd import binding as B, ij   # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+relax = [int(x) for x in os.environ.get("RELAX", "18,18").split(",")]
 rows = [int(a) for a in sys.argv[2:]] or [0, 100000, 1000000, 100000000]
 L = B.load_library()
-opt = ij.IJOptions(n=(n, n, n), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=18, num_sweeps=1)
+opt = ij.IJOptions(n=(n, n, n), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=relax[0], num_sweeps=1)
+opt.relax_down, opt.relax_up = relax[0], relax[1]
 A = ij.build_matrix(opt)
 L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
 s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
