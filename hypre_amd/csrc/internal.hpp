@@ -155,7 +155,7 @@ struct SpmvArgs
    int                  row_offset;
    int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
    int                  x_last;      // num_cols - 1: largest valid index into x
-   int                  w8_max;      // tiles whose mean row length is at most this reduce with 8 lanes per row, longer ones with 32
+   int                  reduce_w;      // lanes per row of the tile reduction: 0 = per tile (all its rows in one pass), else fixed (power of two)
    int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
    const int           *tile_perm;   // workgroup -> tile table (overrides xcd_map), or null

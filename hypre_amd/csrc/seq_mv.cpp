@@ -53,11 +53,8 @@ void spmv_default_flags(SpmvArgs &a)
    }
    a.gather_t = gt; a.xcd_map = xcd;
    a.variant = spmv_variant().variant;
-   // Row-sum width of the multi-lane reduction: 8 lanes per row up to a mean row length of 128 (32 rows per pass), 32 lanes
-   // beyond.  Measured on level 2 of the 256^3 hierarchy (70 entries per row, 29 rows per tile): 32 lanes per row (the
-   // round-1 choice above 48) 0.123 ms, 8 lanes 0.104 ms — with the x gathers out of the way the kernel is bound by
-   // instruction issue, and four passes of 8 rows cost more instructions than one pass of 32.
-   { static int w8 = -1; if (w8 < 0) { const char *e = getenv("HYPRE_AMD_SPMV_W8MAX"); w8 = e ? atoi(e) : 128; } a.w8_max = w8; }
+   // Lanes per row of the multi-lane reduction: 0 = chosen per tile (spmv_kernels.hip: tile_reduce), else fixed.
+   { static int w = -1; if (w < 0) { const char *e = getenv("HYPRE_AMD_SPMV_REDUCE_W"); w = e ? atoi(e) : 0; } a.reduce_w = w; }
 }
 
 // Band-aware XCD placement.  Workgroup g runs on XCD g % 8 and every XCD has its own L2.  A matrix from a

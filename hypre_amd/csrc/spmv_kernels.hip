@@ -152,51 +152,29 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
    else
    {
       // avg > 12  =>  nrows <= (TILE + MAXROW)/13 < SPMV_THREADS: row sums fit rowsum[]
-      if (avg <= p.w8_max)
+      // W lanes per row, W the largest power of two (at most 32) that takes all rows of the tile in ONE pass: a second
+      // pass with most lanes idle costs as much as the first (level 1 of the benchmark hierarchy: 70 rows a tile were
+      // three passes of 32 rows with 8 lanes each; two lanes a row take them at once)
+      int W = p.reduce_w;                                   // > 0: fixed (tuning knob)
+      if (W <= 0) { W = 32; while (W > 1 && nrows * W > SPMV_THREADS) { W >>= 1; } }
+      const int G = SPMV_THREADS / W, sub = tid & (W - 1), grp = tid / W;
+      for (int base = 0; base < nrows; base += G)
       {
-         constexpr int W = 8, G = SPMV_THREADS / W;
-         const int sub = tid & (W - 1);
-         for (int base = 0; base < nrows; base += G)
+         const int rr = base + grp;
+         double sum = 0.0;
+         if (rr < nrows)
          {
-            const int rr = base + tid / W;
-            double sum = 0.0;
-            if (rr < nrows)
+            const int row = r0 + rr;
+            const int s = rp[rr], e = rp[rr + 1];
+            for (int k = s + sub; k < e; k += W)
             {
-               const int row = r0 + rr;
-               const int s = rp[rr], e = rp[rr + 1];
-               for (int k = s + sub; k < e; k += W)
-               {
-                  double t = prod[k - ka];
-                  if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-                  sum += t;
-               }
+               double t = prod[k - ka];
+               if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
+               sum += t;
             }
-            sum = subwave_sum<W>(sum);
-            if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
          }
-      }
-      else
-      {
-         constexpr int W = 32, G = SPMV_THREADS / W;
-         const int sub = tid & (W - 1);
-         for (int base = 0; base < nrows; base += G)
-         {
-            const int rr = base + tid / W;
-            double sum = 0.0;
-            if (rr < nrows)
-            {
-               const int row = r0 + rr;
-               const int s = rp[rr], e = rp[rr + 1];
-               for (int k = s + sub; k < e; k += W)
-               {
-                  double t = prod[k - ka];
-                  if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-                  sum += t;
-               }
-            }
-            sum = subwave_sum<W>(sum);
-            if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
-         }
+         for (int off = W >> 1; off > 0; off >>= 1) { sum += __shfl_xor(sum, off, 64); }
+         if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
       }
       __syncthreads();
       if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, rowsum[tid], ops); }
