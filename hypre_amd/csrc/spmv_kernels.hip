@@ -120,6 +120,34 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum,
 constexpr int RP_CAP = 640;      // upper bound of the row pointers staged in LDS per tile (the plan asks for fewer
                                  // when no tile of the matrix holds that many rows)
 
+// row sums of a tile with W lanes per row (products in LDS, sums to rowsum[]); W is a compile-time width: the shuffle
+// tree and the lane arithmetic unroll (a run-time W cost levels 2+ of the benchmark hierarchy 5 %)
+template <bool HASFILL, int W>
+__device__ __forceinline__ void tile_row_sums(const SpmvArgs &p, int r0, int nrows, int ka, const double *prod, double *rowsum,
+                                              const int *rp)
+{
+   constexpr int G = SPMV_THREADS / W;
+   const int tid = threadIdx.x, sub = tid & (W - 1);
+   for (int base = 0; base < nrows; base += G)
+   {
+      const int rr = base + tid / W;
+      double sum = 0.0;
+      if (rr < nrows)
+      {
+         const int row = r0 + rr;
+         const int s = rp[rr], e = rp[rr + 1];
+         for (int k = s + sub; k < e; k += W)
+         {
+            double t = prod[k - ka];
+            if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
+            sum += t;
+         }
+      }
+      sum = subwave_sum<W>(sum);
+      if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
+   }
+}
+
 // Per-row reduction of the products parked in LDS and the row epilogue.
 // prod[k - ka] holds entry k of the tile, rp[rr] the row pointer of row r0 + rr
 // (the first rp_cap + 1 of them), ops the epilogue operands of row r0 + tid.
@@ -157,24 +185,14 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
       // three passes of 32 rows with 8 lanes each; two lanes a row take them at once)
       int W = p.reduce_w;                                   // > 0: fixed (tuning knob)
       if (W <= 0) { W = 32; while (W > 1 && nrows * W > SPMV_THREADS) { W >>= 1; } }
-      const int G = SPMV_THREADS / W, sub = tid & (W - 1), grp = tid / W;
-      for (int base = 0; base < nrows; base += G)
+      switch (W)
       {
-         const int rr = base + grp;
-         double sum = 0.0;
-         if (rr < nrows)
-         {
-            const int row = r0 + rr;
-            const int s = rp[rr], e = rp[rr + 1];
-            for (int k = s + sub; k < e; k += W)
-            {
-               double t = prod[k - ka];
-               if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-               sum += t;
-            }
-         }
-         for (int off = W >> 1; off > 0; off >>= 1) { sum += __shfl_xor(sum, off, 64); }
-         if (rr < nrows && sub == 0) { rowsum[rr] = sum; }
+         case 1:  tile_row_sums<HASFILL, 1>(p, r0, nrows, ka, prod, rowsum, rp); break;
+         case 2:  tile_row_sums<HASFILL, 2>(p, r0, nrows, ka, prod, rowsum, rp); break;
+         case 4:  tile_row_sums<HASFILL, 4>(p, r0, nrows, ka, prod, rowsum, rp); break;
+         case 8:  tile_row_sums<HASFILL, 8>(p, r0, nrows, ka, prod, rowsum, rp); break;
+         case 16: tile_row_sums<HASFILL, 16>(p, r0, nrows, ka, prod, rowsum, rp); break;
+         default: tile_row_sums<HASFILL, 32>(p, r0, nrows, ka, prod, rowsum, rp); break;
       }
       __syncthreads();
       if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, rowsum[tid], ops); }
