@@ -29,6 +29,13 @@ REFERENCE_CPU_SURVEY = {"config": "ij -n 256 256 256 -P 2 2 2 -solver 1 -rlx 18 
                         "spmv_ms": 37.8, "spmv_GBps": 46.0, "pcg_s_per_iteration": 0.44, "pcg_iterations": 23,
                         "MDOF_per_s_per_pcg_iteration": 38.0,
                         "port_in_same_container": "profiles/r02_cpu_port_vs_reference_survey_container.json"}
+# the reference's own GPU run of this problem (regression-perf files of test/TEST_bench, job #14:
+# 256^3 7-pt, 1 GPU, PMIS / ext+i / l1-Jacobi, AMG-PCG to 1e-8).  OTHER hardware and the reference's device PMIS (other
+# random numbers: 21 iterations there, 22 with the host routine's here): context for the solve and setup times below,
+# not a baseline for the metric (which is the V-cycle rate).
+REFERENCE_GPU_PUBLISHED = {"job": "test/TEST_bench/benchmark_ij.jobs:52 (#14)", "hardware": "1 GCD of AMD MI250X (tioga), ROCm 5.2",
+                           "pcg_solve_s": 0.680926, "pcg_iterations": 21, "pcg_setup_s": 0.953187,
+                           "source": "test/TEST_bench/benchmark_ij.perf.saved.tioga:40-42"}
 
 
 def parse():
@@ -254,6 +261,8 @@ def main():
         pcg_info = {"iterations": its.value, "final_rel_resid": rel.value, "solve_ms": 1e3 * pcg_s,
                     "ms_per_iteration": 1e3 * pcg_s / max(its.value, 1),
                     "dof_per_s_per_iteration": nglob * max(its.value, 1) / pcg_s}
+        if world == 1 and args.problem == "laplacian" and args.n == 256 and args.relax == 18 and not args.mixed:
+            pcg_info["reference_published_other_hardware"] = REFERENCE_GPU_PUBLISHED
     except Exception as exc:      # noqa: BLE001 - the headline metric above stands on its own
         pcg_info = {"error": str(exc)}
         L.HYPRE_ClearAllErrors()
