@@ -591,11 +591,16 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       S.cA = stream_load<v4i>(p.Aj + qA);
       S.cB = stream_load<v4i>(p.Aj + qB);
       stream_issue_spill<F32>(p, ka, k1, S);
-#pragma unroll
-      for (int j = 0; j < (RP_CAP + SPMV_THREADS) / SPMV_THREADS; j++)
+      // row pointers: loaded unconditionally (clamped) and stored afterwards — a conditional load-and-store here makes
+      // the compiler wait for everything in flight before each store: three more round trips per tile
       {
-         const int t = tid + j * SPMV_THREADS;
-         if (t <= nrows && t <= rp_cap) { rp[t] = p.Ai[r0 + t]; }
+         constexpr int RPJ = (RP_CAP + SPMV_THREADS) / SPMV_THREADS;
+         const int lim = min(nrows, rp_cap);
+         int rpv[RPJ];
+#pragma unroll
+         for (int j = 0; j < RPJ; j++) { rpv[j] = p.Ai[r0 + min(tid + j * SPMV_THREADS, lim)]; }
+#pragma unroll
+         for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
       }
       const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
       stream_consume_gt<F32>(p, k0, k1, ka, S, prod);
