@@ -23,7 +23,8 @@ namespace hamd {
 namespace {
 
 constexpr int TB = 256;
-inline int grid_for(size_t n) { return (int) std::min<size_t>((n + TB - 1) / TB, (size_t) 1 << 22); }
+// one thread per item; the strided kernels below (column_count) take fewer workgroups than that happily
+inline int grid_for(size_t n) { return (int) std::min<size_t>((n + TB - 1) / TB, (size_t) 0x7fffffff); }
 
 // ---- strength ----------------------------------------------------------------------------------------------------
 // the first stored entry of a row is its diagonal (hypre's convention for square ParCSR blocks)
@@ -147,8 +148,17 @@ void pmis_retire_kernel(int n, double *__restrict__ measure, const int *__restri
    {
       if (CF[i] != 0) { measure[i] = 0.0; } else { stay = 1; }
    }
+   // one atomic per workgroup (16.8 M rows are 262 144 waves: their atomics on one counter took 0.4 ms a sweep)
+   __shared__ int wave_count[TB / 64];
    const unsigned long long b = __ballot(stay);
-   if ((threadIdx.x & 63) == 0 && b) { atomicAdd(left, __popcll(b)); }
+   if ((threadIdx.x & 63) == 0) { wave_count[threadIdx.x >> 6] = __popcll(b); }
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      int c = 0;
+      for (int w = 0; w < TB / 64; w++) { c += wave_count[w]; }
+      if (c) { atomicAdd(left, c); }
+   }
 }
 
 // ---- coarse numbering: f2c[i] = number of C points before i, or -1 ---------------------------------------------------
