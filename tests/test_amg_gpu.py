@@ -562,6 +562,10 @@ def test_device_interpolation_is_the_host_interpolation(gpu_lib, kw, rung):
                                 dict(n=(32, 32, 32), problem="difconv", c=(1.0, 0.01, 1.0), a=(3.0, 2.0, 1.0), max_row_sum=0.8),
                                 dict(n=(40, 40, 20), strong_threshold=0.6),
                                 dict(n=(40, 39, 38), matrix_on_device=True),
+                                # other generators of the reference driver: rotated anisotropy (2-D, 9-point), jumping coefficients
+                                dict(n=(150, 140, 1), problem="rotate", alpha=60.0, eps=0.1),
+                                dict(n=(34, 33, 32), problem="vardifconv", eps=0.1),
+                                dict(n=(36, 35, 34), problem="difconv", c=(1.0, 1.0, 1.0), a=(10.0, 10.0, 10.0)),
                                 # the device interpolation declines these (truncation by threshold alone): host loop on fetched copies
                                 dict(n=(30, 30, 30), P_max_elmts=0, trunc_factor=0.2),
                                 dict(n=(30, 30, 30), P_max_elmts=0, trunc_factor=0.2, matrix_on_device=True),
