@@ -620,3 +620,69 @@ def test_device_coarsening_is_the_host_coarsening(gpu_lib, kw):
         assert len(m0) == len(m1)
         for a, b in zip(m0, m1):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("relax_type", [18, 8])
+def test_device_setup_on_an_unstructured_matrix(gpu_lib, tmp_path, relax_type):
+    """The reference's own unstructured test matrix (test/TEST_ij/data/tucker21935, four IJ files merged into one rank's):
+    irregular rows, rows without strong couplings, positive off-diagonal entries.  Device setup == host setup, array for
+    array, and the hierarchy solves the system."""
+    import os
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ij_files", "data", "tucker21935")
+    rows, n = [], 0
+    for r in range(4):
+        with open(os.path.join(src, "IJ.A.%05d" % r)) as fh:
+            head = fh.readline().split()
+            n = max(n, int(head[1]) + 1)
+            rows.append(fh.read())
+    merged = tmp_path / "IJ.A.00000"
+    merged.write_text("0 %d 0 %d\n" % (n - 1, n - 1) + "".join(rows))
+    hier, solves = [], []
+    for on in (0, 1):
+        lib.hypre_amd_SetSetupDeviceRAP(on, -1)
+        lib.hypre_amd_SetSetupDeviceInterp(on)
+        lib.hypre_amd_SetSetupDeviceCoarsen(on)
+        opt = ij.IJOptions(fromfile=str(tmp_path / "IJ.A"), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=relax_type)
+        A = ij.build_matrix(opt)
+        assert A.contents.diag.contents.num_rows == n and n > 20000          # large enough for the device path by default
+        s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+        lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+        B.check()
+        levels = lib.hypre_amd_SetSetupDeviceCoarsen(-1)
+        assert (levels >= 1) if on else (levels == 0)
+        nl = lib.hypre_amd_BoomerAMGGetNumLevels(s)
+        lv = []
+        for l in range(nl):
+            Al = C.cast(lib.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
+            if l > 0:
+                lv.append(B.csr_to_arrays(Al.contents.diag))
+            if l < nl - 1:
+                Pl = C.cast(lib.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+                lv.append(B.csr_to_arrays(Pl.contents.diag))
+                cf = C.cast(lib.hypre_amd_BoomerAMGGetCFMarker(s, l), C.POINTER(B.IntArray)).contents
+                lv.append((B.fetch(cf.data, cf.size, np.int32, cf.memory_location),))
+            l1p = lib.hypre_amd_BoomerAMGGetL1Norms(s, l)
+            if l1p:
+                lv.append((B.vec_to_numpy(C.cast(l1p, C.POINTER(B.Vector))),))
+        hier.append(lv)
+        lib.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+        b, u = B.parvec_from_numpy(np.ones(n)), B.parvec_from_numpy(np.zeros(n))
+        lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+        lib.HYPRE_BoomerAMGSetMaxIter(s, 10)                 # ten cycles (the reference solves this one with PCG)
+        lib.HYPRE_BoomerAMGSolve(s, A, b, u)
+        lib.HYPRE_ClearAllErrors()                           # "not converged within max_iter": expected
+        rel = C.c_double()
+        lib.HYPRE_BoomerAMGGetFinalRelativeResidualNorm(s, C.byref(rel))
+        solves.append((rel.value, B.parvec_to_numpy(u)))
+        lib.HYPRE_BoomerAMGDestroy(s)
+    lib.hypre_amd_SetSetupDeviceRAP(1, 20000)
+    lib.hypre_amd_SetSetupDeviceInterp(1)
+    lib.hypre_amd_SetSetupDeviceCoarsen(1)
+    assert len(hier[0]) == len(hier[1])
+    for m0, m1 in zip(hier[0], hier[1]):
+        for a, b in zip(m0, m1):
+            assert np.array_equal(a, b)
+    assert solves[0][0] == solves[1][0] < 0.5
+    assert np.array_equal(solves[0][1], solves[1][1])
