@@ -69,4 +69,8 @@ void launch_cheby_step(const double *r, const double *v, const double *ds, const
    hipLaunchKernelGGL(cheby_step_kernel, dim3(ew_grid(n)), dim3(256), 0, s, r, v, ds, orig, mult, last ? 1 : 0, u, tmp, n);
 }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_cheby_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) cheby_start_kernel); (void) hipGetLastError(); }
+
 }  // namespace hamd

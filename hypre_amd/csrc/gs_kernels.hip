@@ -226,4 +226,8 @@ void launch_gs_run(const GsArgs &a, int lanes, const int *d_lev_start, int lev_b
    }
 }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_gs_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) gs_level_kernel<8>); (void) hipGetLastError(); }
+
 }  // namespace hamd

@@ -471,4 +471,8 @@ bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const i
    return true;
 }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_interp_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) extpi_rows_kernel<2>); (void) hipGetLastError(); }
+
 }  // namespace hamd

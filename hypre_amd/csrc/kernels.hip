@@ -536,4 +536,8 @@ void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t
 void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s)
 { if (n) hipLaunchKernelGGL(f64_to_f32_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, y, n); }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_vector_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) set_kernel); (void) hipGetLastError(); }
+
 }  // namespace hamd

@@ -419,4 +419,8 @@ bool device_rap(int nc, int ncP, int maxP,
    return true;
 }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_rap_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) rap_rows_kernel<true>); (void) hipGetLastError(); }
+
 }  // namespace hamd

@@ -115,6 +115,8 @@ bool ensure_device()
       return false;
    }
    h.device_ok = true;
+   preload_cheby_kernels(); preload_gs_kernels(); preload_interp_kernels(); preload_vector_kernels();
+   preload_rap_kernels(); preload_setup_kernels(); preload_spmv_kernels();
    return true;
 }
 

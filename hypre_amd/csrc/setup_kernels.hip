@@ -292,4 +292,8 @@ bool device_l1_norms(int n, const int *Ai, const int *Aj, const double *Aa, int 
    return h == 0;
 }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_setup_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) strength_kernel<false>); (void) hipGetLastError(); }
+
 }  // namespace hamd

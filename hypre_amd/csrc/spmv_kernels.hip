@@ -1152,4 +1152,8 @@ void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs 
    hipLaunchKernelGGL(spmv_rownnz_kernel, dim3(grid), dim3(SPMV_THREADS), 0, s, args, rownnz, num_rownnz);
 }
 
+// The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
+// the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+void preload_spmv_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) (spmv_xs_kernel<0, false, false>)); (void) hipGetLastError(); }
+
 }  // namespace hamd
