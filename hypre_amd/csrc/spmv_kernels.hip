@@ -617,11 +617,13 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
 #pragma unroll
    for (int j = 0; j < XS_WSEG; j++)
    {
-      const int off = seg_ol[j] >> 16, len = seg_ol[j] & 0xffff;
-      if (2 * lane < len)
+      // (the plan keeps what the slot needs as it needs it: the piece's LDS offset in bytes, its length in lanes, an
+      // unsigned first column — a slot is a dozen instructions per wave whether it loads or not)
+      const unsigned offb = (unsigned) seg_ol[j] >> 16, lanes = (unsigned) seg_ol[j] & 0xffffu;
+      if ((unsigned) lane < lanes)
       {
-         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + seg_start[j] + 2 * lane),
-                                          (__attribute__((address_space(3))) void *) (prod + off), 16, 0, 0);
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + (size_t) (unsigned) seg_start[j] + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(prod) + offb), 16, 0, 0);
       }
    }
    // spill of the tile's last row past the window (one entry per lane), row pointers, epilogue operands: same trip
@@ -863,7 +865,7 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
             {
                const int slot = (pidx & 3) * XS_WSEG + (pidx >> 2);  // pieces dealt to the four waves, a wave's own contiguous
                desc[slot] = 2 * (uniq[i] + o);
-               desc[XS_SEGS + slot] = ((2 * (pos[i] + o)) << 16) | (2 * min(XS_PIECE, len_units - o));
+               desc[XS_SEGS + slot] = ((16 * (pos[i] + o)) << 16) | min(XS_PIECE, len_units - o);     // LDS byte offset | lanes
                pidx++;
             }
          }
