@@ -2178,6 +2178,12 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          auto plan_of = [](hypre_CSRMatrix *M) { if (M && M->memory_location == HYPRE_MEMORY_DEVICE && M->num_nonzeros > 0) { (void) get_plan(M); } };
          plan_of(d->A_array[l]->diag);
          if (l < num_levels - 1) { plan_of(d->P_array[l]->diag); plan_of(d->P_array[l]->diagT); }
+         // two-stage Gauss-Seidel sweeps multiply by the strictly lower copy of the operator: made here as well
+         const HYPRE_Int *gt = d->grid_relax_type;
+         const bool last = (l == num_levels - 1);
+         const bool two_stage = last ? (gt[3] == 11 || gt[3] == 12) : (gt[1] == 11 || gt[1] == 12 || gt[2] == 11 || gt[2] == 12);
+         hypre_CSRMatrix *Ad = d->A_array[l]->diag;
+         if (two_stage && single_rank && Ad->memory_location == HYPRE_MEMORY_DEVICE && Ad->num_nonzeros > 0) { plan_of(strict_lower_of(Ad)); }
       }
       hypre_ParVectorMigrate(d->Vtemp, HYPRE_MEMORY_DEVICE);
       hypre_ParVectorMigrate(d->Ztemp, HYPRE_MEMORY_DEVICE);
