@@ -204,8 +204,8 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
                         const int src = have ? owner_of(sincl, t) : 0;
                         const int kk = have ? sbeg[src] + (t - (src ? sincl[src - 1] : 0)) : 0;
                         k1 = have ? Sj[kk] : 0;
-                        isc = have && CF[k1] >= 0;
-                        fck = have ? f2c[k1] : 0;
+                        fck = have ? f2c[k1] : -1;           // the coarse number says it all: -1 for every point that is not C
+                        isc = fck >= 0;
                         loaded = c;
                      }
                      const bool mine = t >= e0 && t < e1;
