@@ -91,6 +91,25 @@ void dev_halo_end(hypre_ParCSRCommHandle *h);
 void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMatrix *> &hostA);
 void destroy_replicated_tail(hypre_ParAMGData *d);
 
+// device twins and markers of the setup in progress (par_amg_setup.cpp)
+hypre_CSRMatrix *setup_device_twin_of(hypre_CSRMatrix *host, int with_data);
+hypre_CSRMatrix *setup_wrap_device_csr(HYPRE_Int nr, HYPRE_Int ncl, HYPRE_Int nnz, int *i, int *j, double *a);
+void setup_register_device_marker(const HYPRE_Int *host, HYPRE_Int *dev);     // the table takes ownership of dev
+HYPRE_Int *setup_device_marker_of(const HYPRE_Int *host, HYPRE_Int n);
+
+// distributed levels of a device-targeted setup (par_amg_setup_dist.cpp): the single-rank device kernels on the extended
+// numbering.  *_ptr == nullptr with a clear error flag: some rank's tables overflowed — every rank comes back that way
+// (the verdict is agreed on), and the caller repeats the step with the host routine.
+HYPRE_Int dist_device_create_S(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_Real max_row_sum, hypre_ParCSRMatrix **S_ptr);
+HYPRE_Int dist_device_pmis(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *A, HYPRE_Int CF_init, HYPRE_Int *CF_host);
+HYPRE_Int dist_device_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                   HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts, HYPRE_Real trunc_factor,
+                                   HYPRE_Int max_elmts, HYPRE_Int first_rung, hypre_ParCSRMatrix **P_ptr);
+HYPRE_Int dist_device_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
+                                      HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr);
+// true on every rank or on none
+bool all_ranks_agree(MPI_Comm comm, bool mine);
+
 // distributed setup pieces (par_amg_setup_dist.cpp)
 HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
                                   HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts,

@@ -213,7 +213,40 @@ bool device_rap(int nc, int ncP, int maxP, const int *Ri, const int *Rj, const d
 // extended+i interpolation rows on the device, bit-identical to the host setup's (interp_kernels.hip); false: use the host
 bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const int *Si, const int *Sj, const int *CF,
                   const int *f2c, double trunc_tol, int max_elmts, int first_rung, int **Pi_out, int **Pj_out, double **Pa_out,
-                  int *nnz_out, hipStream_t s);
+                  int *nnz_out, hipStream_t s, int split = -1, int **Oi_out = nullptr, int **Oj_out = nullptr,
+                  double **Oa_out = nullptr, int *onnz_out = nullptr);
+// ---- distributed levels on the device (dist_setup_kernels.hip, setup_kernels.hip, rap_kernels.hip): the single-rank kernels
+// on the extended numbering [local points | ghost points]
+void preload_dist_setup_kernels();
+void device_extend_csr(int n, const int *Di, const int *Dj, const double *Da, const int *Oi, const int *Oj, const double *Oa, int ooff,
+                       int ng, const int *Gi, const int *Gj, const double *Ga, int **Ei_out, int **Ej_out, double **Ea_out,
+                       int *nnz_out, hipStream_t s);
+void device_extract_rows(int filter, int tot, const int *d_elmts, const int *Di, const int *Dj, const double *Da,
+                         const int *Oi, const int *Oj, const double *Oa, long long first_col, const long long *d_cmap, const int *CF,
+                         std::vector<int> &hi, std::vector<long long> &hj, std::vector<double> &ha, hipStream_t s);
+void device_extract_S_rows(int tot, const int *d_elmts, int n, const int *Si, const int *Sj, long long first_col, const long long *d_cmap,
+                           const int *CFext, std::vector<int> &hi, std::vector<long long> &hj, hipStream_t s);
+void device_split_strided(int n, int stride, int *len, int *nd, const int *sj, const double *sa, int split,
+                          int **Di_out, int **Dj_out, double **Da_out, int *dnnz, int **Oi_out, int **Oj_out, double **Oa_out, int *onnz,
+                          hipStream_t s);
+void device_split_pattern(int n, const int *Si, const int *Sj, int split, int **Di_out, int **Dj_out, int *dnnz,
+                          int **Oi_out, int **Oj_out, int *onnz, hipStream_t s);
+void launch_mark_used(const int *j, size_t nnz, int *used, hipStream_t s);
+void launch_renumber(int *j, size_t nnz, int split, const int *map, hipStream_t s);
+void launch_gather_int(const int *x, const int *idx, int *out, size_t n, hipStream_t s);
+bool device_l1_norms_blocks(int n, const int *Di, const int *Dj, const double *Da, const int *Oi, const int *Oj, const double *Oa,
+                            int option, const int *cf, const int *cfo, double *out, hipStream_t s);
+void device_strength_blocks(int n, const int *Di, const int *Dj, const double *Da, const int *Oi, const int *Oj, const double *Oa,
+                            double theta, double max_row_sum, int **Si_out, int **Sj_out, int *nnz_out, hipStream_t s);
+int  device_pmis_dist(int n, int nco, const int *Si, const int *Sj, int snnz, unsigned seed, unsigned long long skip,
+                      hypre_ParCSRCommPkg *pkg, const int *d_elmts, const int *d_prev, MPI_Comm comm, int *CF, hipStream_t s);
+bool device_rap_dist(bool direct, int nc, int square, int ncols_out, int maxP, int max_seed,
+                     const int *Ri, const int *Rj, const double *Ra, const int *Ai, const int *Aj, const double *Aa,
+                     const int *A2i, const int *A2j, const double *A2a, int a2_off, int nfine,
+                     const int *Pi, const int *Pj, const double *Pa,
+                     const int *Fi, const int *Fj, const int *Xi, const int *Xj, const double *Xa, int split,
+                     int **Di_out, int **Dj_out, double **Da_out, int *dnnz, int **Oi_out, int **Oj_out, double **Oa_out, int *onnz,
+                     hipStream_t s);
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s);   // [entry][component] -> column by column
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s);
 void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s);

@@ -117,7 +117,8 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
                        const int *__restrict__ Si, const int *__restrict__ Sj, const int *__restrict__ CF,
                        const int *__restrict__ f2c, double trunc_tol, int max_elmts, int capM, int capR,
                        const int *__restrict__ out_off, int stride, int *__restrict__ rowlen,
-                       int *__restrict__ Pj, double *__restrict__ Pa, int *__restrict__ overflow)
+                       int *__restrict__ Pj, double *__restrict__ Pa, int *__restrict__ overflow,
+                       int split, int *__restrict__ rowlen_d)
 {
    extern __shared__ __align__(16) unsigned char smem[];
    unsigned long long *Mkey = reinterpret_cast<unsigned long long *>(smem);
@@ -319,49 +320,75 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
       if (bad) { if (lane == 0) { atomicExch(overflow, 1); } len = 0; }
 
       // ---- truncation (par_csr_matrix.c:2874-3400 with rescale, inf-norm): relative threshold, then the max_elmts
-      // largest; one lane, the host's statement order
-      if (MODE != 0 && !bad && cf_i < 0 && cf_i != -3 && (trunc_tol > 0.0 || (max_elmts > 0 && max_elmts < len)))
+      // largest; one lane, the host's statement order.
+      // split >= 0 (a distributed level, extended numbering): columns >= split are off-rank coarse points.  The host keeps
+      // a row's diagonal-block and off-rank entries in two lists, truncates their concatenation and deals the survivors
+      // back to the two lists in the order the sort left them: a stable partition of the row by class before the
+      // truncation, and another one after it.
+      int nd = len;
+      const bool f_row = !bad && cf_i < 0 && cf_i != -3;
+      const bool trunc = MODE != 0 && f_row && (trunc_tol > 0.0 || (max_elmts > 0 && max_elmts < len));
+      const bool dist_row = MODE != 0 && split >= 0 && f_row && len > 0;
+      if (trunc || dist_row)
       {
          if (lane == 0)
          {
-            int d1 = len;
-            if (trunc_tol > 0.0)
+            auto partition_row = [&](int cnt)
             {
-               double row_nrm = 0.0;
-               for (int k = 0; k < len; k++) { row_nrm = fmax(row_nrm, fabs(pa[k])); }
-               const double drop = trunc_tol * row_nrm;
-               double row_sum = 0.0, scale = 0.0;
-               int w = 0;
-               for (int k = 0; k < len; k++)
+               int *tj = stack;
+               double *ta = reinterpret_cast<double *>(stack + capR);
+               int w = 0, ng = 0;
+               for (int k = 0; k < cnt; k++)
                {
-                  row_sum += pa[k];
-                  if (!(fabs(pa[k]) < drop)) { scale += pa[k]; pa[w] = pa[k]; pj[w] = pj[k]; w++; }
+                  if (pj[k] >= split) { tj[ng] = pj[k]; ta[ng] = pa[k]; ng++; }
+                  else { pj[w] = pj[k]; pa[w] = pa[k]; w++; }
                }
-               d1 = w;
-               if (scale != 0. && scale != row_sum)
-               {
-                  scale = row_sum / scale;
-                  for (int k = 0; k < d1; k++) { pa[k] *= scale; }
-               }
-            }
-            if (max_elmts > 0 && max_elmts < d1)
+               for (int q = 0; q < ng; q++) { pj[w + q] = tj[q]; pa[w + q] = ta[q]; }
+               return w;
+            };
+            int d1 = len, ndl = len;
+            if (dist_row) { ndl = partition_row(len); }
+            if (trunc)
             {
-               double row_sum = 0.0;
-               for (int k = 0; k < d1; k++) { row_sum += pa[k]; }
-               qsort2_abs_dev(pj, pa, d1, max_elmts, stack);
-               double scale = 0.0;
-               for (int k = 0; k < max_elmts; k++) { scale += pa[k]; }
-               d1 = max_elmts;
-               if (scale != 0. && scale != row_sum)
+               if (trunc_tol > 0.0)
                {
-                  scale = row_sum / scale;
-                  for (int k = 0; k < d1; k++) { pa[k] *= scale; }
+                  double row_nrm = 0.0;
+                  for (int k = 0; k < len; k++) { row_nrm = fmax(row_nrm, fabs(pa[k])); }
+                  const double drop = trunc_tol * row_nrm;
+                  double row_sum = 0.0, scale = 0.0;
+                  int w = 0;
+                  for (int k = 0; k < len; k++)
+                  {
+                     row_sum += pa[k];
+                     if (!(fabs(pa[k]) < drop)) { scale += pa[k]; pa[w] = pa[k]; pj[w] = pj[k]; w++; }
+                  }
+                  d1 = w;
+                  if (scale != 0. && scale != row_sum)
+                  {
+                     scale = row_sum / scale;
+                     for (int k = 0; k < d1; k++) { pa[k] *= scale; }
+                  }
                }
+               if (max_elmts > 0 && max_elmts < d1)
+               {
+                  double row_sum = 0.0;
+                  for (int k = 0; k < d1; k++) { row_sum += pa[k]; }
+                  qsort2_abs_dev(pj, pa, d1, max_elmts, stack);
+                  double scale = 0.0;
+                  for (int k = 0; k < max_elmts; k++) { scale += pa[k]; }
+                  d1 = max_elmts;
+                  if (scale != 0. && scale != row_sum)
+                  {
+                     scale = row_sum / scale;
+                     for (int k = 0; k < d1; k++) { pa[k] *= scale; }
+                  }
+               }
+               if (dist_row) { ndl = partition_row(d1); }
             }
-            stack[0] = d1;
+            stack[0] = d1; stack[1] = ndl;
          }
          __syncthreads();
-         len = stack[0];
+         len = stack[0]; nd = stack[1];
          __syncthreads();
       }
 
@@ -369,7 +396,7 @@ void extpi_rows_kernel(int n, const int *__restrict__ Ai, const int *__restrict_
       else
       {
          const size_t o = MODE == 1 ? (size_t) out_off[i] : (size_t) i * (size_t) stride;
-         if (MODE == 2 && lane == 0) { rowlen[i] = len; }
+         if (MODE == 2 && lane == 0) { rowlen[i] = len; if (rowlen_d) { rowlen_d[i] = nd; } }
          for (int k = lane; k < len; k += 64) { Pj[o + k] = pj[k]; Pa[o + k] = pa[k]; }
       }
       __syncthreads();
@@ -387,30 +414,65 @@ __global__ void compact_rows_kernel(int n, int stride, const int *__restrict__ P
 
 static int pow2_ge(int v) { int p = 16; while (p < v) { p <<= 1; } return p; }
 
+void device_split_strided(int n, int stride, int *len, int *nd, const int *sj, const double *sa, int split,
+                          int **Di_out, int **Dj_out, double **Da_out, int *dnnz, int **Oi_out, int **Oj_out, double **Oa_out, int *onnz,
+                          hipStream_t s);
+
 // A (n x n, diagonal first), S (pattern), CF marker and fine -> coarse numbering on the device.  Returns false when a row's
 // interpolatory set does not fit LDS (the caller then uses the host loop).  The result arrays are device allocations.
+// split >= 0: a distributed level on the extended numbering (dist_setup_kernels.hip): rows 0 .. n-1 are built, the arrays
+// cover the ghost points as well, coarse numbers >= split are off-rank; the operator comes back as two blocks
+// (Pi/Pj/Pa: columns < split; Oi/Oj/Oa: the others, minus split).
 bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const int *Si, const int *Sj, const int *CF,
                   const int *f2c, double trunc_tol, int max_elmts, int first_rung, int **Pi_out, int **Pj_out, double **Pa_out,
-                  int *nnz_out, hipStream_t s)
+                  int *nnz_out, hipStream_t s, int split, int **Oi_out, int **Oj_out, double **Oa_out, int *onnz_out)
 {
    if (max_elmts <= 0 && trunc_tol > 0.0) { return false; }     // lengths would depend on the weights: not built here
+   const bool dist = split >= 0;
+   if (dist && n <= 0)
+   {
+      int *Pi = nullptr, *Oi = nullptr;
+      HIP_CHECK(hipMalloc((void **) &Pi, sizeof(int) * 2)); HIP_CHECK(hipMemsetAsync(Pi, 0, sizeof(int) * 2, s));
+      HIP_CHECK(hipMalloc((void **) &Oi, sizeof(int) * 2)); HIP_CHECK(hipMemsetAsync(Oi, 0, sizeof(int) * 2, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      *Pi_out = Pi; *Pj_out = nullptr; *Pa_out = nullptr; *nnz_out = 0;
+      *Oi_out = Oi; *Oj_out = nullptr; *Oa_out = nullptr; *onnz_out = 0;
+      return true;
+   }
    auto lds = [](int capM, int capR) { return (size_t) 8 * capM + 8 * capR + 8 * 64 + 4 * capM + 4 * capR + 4 * (4 * capR + 8) + 4 * 64 * 5 + 64; };
    const size_t budget = 150 * 1024;
    (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
    (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
    (void) hipFuncSetAttribute((const void *) extpi_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) budget);
-   int *d_flag = nullptr, *rowlen = nullptr;
+   int *d_flag = nullptr, *rowlen = nullptr, *rowlen_d = nullptr;
    HIP_CHECK(hipMalloc((void **) &d_flag, sizeof(int)));
    HIP_CHECK(hipMalloc((void **) &rowlen, sizeof(int) * ((size_t) n + 1)));
+   if (dist) { HIP_CHECK(hipMalloc((void **) &rowlen_d, sizeof(int) * ((size_t) n + 1))); }
    const int waves = std::min(n, handle().num_cus * 32);
-   const bool fixed = max_elmts > 0;          // rows have at most max_elmts entries: one pass into strided storage
+   // rows have at most max_elmts entries: one pass into strided storage (a distributed level always works that way, with
+   // room for a whole table's worth of entries per row when the rows are not cut)
+   const bool fixed = max_elmts > 0 || dist;
    int *sj = nullptr;
    double *sa = nullptr;
-   if (fixed)
+   int stride = max_elmts;
+   auto alloc_strided = [&](int st)
    {
-      HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * (size_t) n * (size_t) max_elmts));
-      HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * (size_t) n * (size_t) max_elmts));
-   }
+      if (sj) { HIP_CHECK(hipFree(sj)); sj = nullptr; }
+      if (sa) { HIP_CHECK(hipFree(sa)); sa = nullptr; }
+      stride = st;
+      if (hipMalloc((void **) &sj, sizeof(int) * (size_t) n * (size_t) st) != hipSuccess) { sj = nullptr; (void) hipGetLastError(); return false; }
+      if (hipMalloc((void **) &sa, sizeof(double) * (size_t) n * (size_t) st) != hipSuccess) { sa = nullptr; (void) hipGetLastError(); return false; }
+      return true;
+   };
+   auto give_up = [&]()
+   {
+      HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(rowlen));
+      if (rowlen_d) { HIP_CHECK(hipFree(rowlen_d)); }
+      if (sj) { HIP_CHECK(hipFree(sj)); }
+      if (sa) { HIP_CHECK(hipFree(sa)); }
+      return false;
+   };
+   if (fixed && max_elmts > 0 && !alloc_strided(max_elmts)) { return give_up(); }
    // Tables sized by what rows of such operators need, smallest first: the kernel lives on the number of rows in flight
    // (tables for 64 entries: 23 waves a CU; for 256: 7), and the interpolatory sets of the benchmark hierarchy stay below
    // 64 points on every level although the rows of A grow to 134 entries.  An overflowing row sends everyone to the next
@@ -429,19 +491,25 @@ bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const i
       HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), s));
       if (fixed)
       {
+         if (max_elmts <= 0 && !alloc_strided(capR)) { return give_up(); }
          hipLaunchKernelGGL((extpi_rows_kernel<2>), dim3(waves), dim3(64), lds(capM, capR), s, n, Ai, Aj, Aa, Si, Sj, CF, f2c, trunc_tol,
-                            max_elmts, capM, capR, (const int *) nullptr, max_elmts, rowlen, sj, sa, d_flag);
+                            max_elmts, capM, capR, (const int *) nullptr, stride, rowlen, sj, sa, d_flag, split, rowlen_d);
       }
       else
       {
          hipLaunchKernelGGL((extpi_rows_kernel<0>), dim3(waves), dim3(64), lds(capM, capR), s, n, Ai, Aj, Aa, Si, Sj, CF, f2c, trunc_tol,
-                            max_elmts, capM, capR, (const int *) nullptr, 0, rowlen, (int *) nullptr, (double *) nullptr, d_flag);
+                            max_elmts, capM, capR, (const int *) nullptr, 0, rowlen, (int *) nullptr, (double *) nullptr, d_flag, -1, (int *) nullptr);
       }
       HIP_CHECK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
       HIP_CHECK(hipStreamSynchronize(s));
    }
-   auto give_up = [&]() { HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(rowlen)); if (sj) { HIP_CHECK(hipFree(sj)); } if (sa) { HIP_CHECK(hipFree(sa)); } return false; };
    if (h_flag) { return give_up(); }
+   if (dist)
+   {
+      device_split_strided(n, stride, rowlen, rowlen_d, sj, sa, split, Pi_out, Pj_out, Pa_out, nnz_out, Oi_out, Oj_out, Oa_out, onnz_out, s);
+      (void) give_up();       // frees the work arrays
+      return true;
+   }
    // row pointers: exclusive scan of the lengths, in place
    launch_scan_exclusive(rowlen, n, s);
    int nnz = 0;
@@ -461,7 +529,7 @@ bool device_extpi(int n, const int *Ai, const int *Aj, const double *Aa, const i
    {
       HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), s));
       hipLaunchKernelGGL((extpi_rows_kernel<1>), dim3(waves), dim3(64), lds(capM, capR), s, n, Ai, Aj, Aa, Si, Sj, CF, f2c, trunc_tol,
-                         max_elmts, capM, capR, Pi, 0, (int *) nullptr, Pj, Pa, d_flag);
+                         max_elmts, capM, capR, Pi, 0, (int *) nullptr, Pj, Pa, d_flag, -1, (int *) nullptr);
    }
    HIP_CHECK(hipStreamSynchronize(s));
    HIP_CHECK(hipFree(d_flag));

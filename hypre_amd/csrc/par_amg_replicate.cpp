@@ -55,7 +55,10 @@ std::vector<T> allgather_var(const hypre_amd_CommOps *o, const T *mine, int n, s
 hypre_ParCSRMatrix *replicate_matrix(hypre_ParCSRMatrix *M)
 {
    const hypre_amd_CommOps *o = comm_ops(M->comm);
-   hypre_CSRMatrix *D = M->diag, *O = M->offd;
+   // a level the setup worked on in device memory: host copies for the gather
+   hypre_CSRMatrix *D = M->diag, *O = M->offd, *Dh = nullptr, *Oh = nullptr;
+   if (D->memory_location == HYPRE_MEMORY_DEVICE) { Dh = hypre_CSRMatrixClone_v2(D, 1, HYPRE_MEMORY_HOST); D = Dh; }
+   if (O->memory_location == HYPRE_MEMORY_DEVICE) { Oh = hypre_CSRMatrixClone_v2(O, 1, HYPRE_MEMORY_HOST); O = Oh; }
    const HYPRE_Int nloc = D->num_rows;
    std::vector<int> rowlen((size_t) std::max(nloc, 1));
    std::vector<int> cols;
@@ -71,6 +74,8 @@ hypre_ParCSRMatrix *replicate_matrix(hypre_ParCSRMatrix *M)
       }
       rowlen[(size_t) i] = (D->i[i + 1] - D->i[i]) + (O->num_cols > 0 ? O->i[i + 1] - O->i[i] : 0);
    }
+   if (Dh) { hypre_CSRMatrixDestroy(Dh); }
+   if (Oh) { hypre_CSRMatrixDestroy(Oh); }
    std::vector<int> all_len = allgather_var<int>(o, rowlen.data(), nloc);
    std::vector<int> all_col = allgather_var<int>(o, cols.data(), (int) cols.size());
    std::vector<double> all_val = allgather_var<double>(o, vals.data(), (int) vals.size());
@@ -204,7 +209,10 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
       t->U_array[l] = self_vec(n, HYPRE_MEMORY_HOST);
       if (d->l1_norms[g])
       {
-         std::vector<double> all = allgather_var<double>(o, d->l1_norms[g]->data, d->l1_norms[g]->size);
+         std::vector<double> mine((size_t) std::max(d->l1_norms[g]->size, 1));
+         hypre_Memcpy(mine.data(), d->l1_norms[g]->data, sizeof(double) * (size_t) d->l1_norms[g]->size, HYPRE_MEMORY_HOST,
+                      d->l1_norms[g]->memory_location);
+         std::vector<double> all = allgather_var<double>(o, mine.data(), d->l1_norms[g]->size);
          t->l1_norms[l] = hypre_SeqVectorCreate((HYPRE_Int) all.size());
          hypre_SeqVectorInitialize_v2(t->l1_norms[l], HYPRE_MEMORY_HOST);
          memcpy(t->l1_norms[l]->data, all.data(), sizeof(double) * all.size());

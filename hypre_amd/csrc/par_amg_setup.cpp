@@ -281,6 +281,14 @@ extern "C" HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on)
 static int  g_device_coarsen_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_COARSEN"); return e ? atoi(e) : 1; }();
 static int  g_device_coarsen_count = 0;
 static bool g_level_on_device = false;       // set by the setup loop for the level it is working on
+// distributed levels (several ranks) on the device as well: on = 0 keeps them on the host (OpenMP loops)
+static int  g_device_dist_on = [] { const char *e = getenv("HYPRE_AMD_SETUP_DEVICE_DIST"); return e ? atoi(e) : 1; }();
+extern "C" HYPRE_Int hypre_amd_SetSetupDeviceDist(HYPRE_Int on)
+{
+   const int was = g_device_dist_on;
+   if (on >= 0) { g_device_dist_on = on; }
+   return was;
+}
 extern "C" HYPRE_Int hypre_amd_SetSetupDeviceCoarsen(HYPRE_Int on)
 {
    if (on >= 0) { g_device_coarsen_on = on; }
@@ -309,6 +317,18 @@ static HYPRE_Int *device_marker_of(const HYPRE_Int *host, HYPRE_Int n)
    t[host] = dd;
    return dd;
 }
+namespace hamd {
+hypre_CSRMatrix *setup_device_twin_of(hypre_CSRMatrix *host, int with_data) { return device_twin_of(host, with_data); }
+hypre_CSRMatrix *setup_wrap_device_csr(HYPRE_Int nr, HYPRE_Int ncl, HYPRE_Int nnz, int *i, int *j, double *a) { return wrap_device_csr(nr, ncl, nnz, i, j, a); }
+void setup_register_device_marker(const HYPRE_Int *host, HYPRE_Int *dev)
+{
+   auto &mk = device_markers();
+   auto it = mk.find(host);
+   if (it != mk.end()) { hypre_Free(it->second, HYPRE_MEMORY_DEVICE); }
+   mk[host] = dev;
+}
+HYPRE_Int *setup_device_marker_of(const HYPRE_Int *host, HYPRE_Int n) { return device_marker_of(host, n); }
+}  // namespace hamd
 // a matrix of the setup goes away: so must the twins registered under its blocks' addresses (the next matrix allocated
 // there would inherit them)
 static void destroy_with_twins(hypre_ParCSRMatrix *M)
@@ -358,6 +378,11 @@ HYPRE_Int hypre_BoomerAMGCreateS(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_
    hypre_CSRMatrix *Ad = A->diag, *Ao = A->offd;
    const HYPRE_Int n = Ad->num_rows;
    const HYPRE_Int nco = Ao->num_cols;
+   if (g_level_on_device && num_functions <= 1 && comm_size(A->comm) > 1)
+   {
+      // a distributed level of a device-targeted setup: both blocks, one pattern over [local | ghost] columns
+      return dist_device_create_S(A, theta, max_row_sum, S_ptr);
+   }
    if (g_level_on_device && num_functions <= 1 && nco == 0 && Ao->num_nonzeros == 0)
    {
       // this level of a device-targeted setup: one thread per row, the loops below statement for statement; S stays there
@@ -474,6 +499,18 @@ HYPRE_Int hypre_BoomerAMGCoarsenPMIS(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *
    {
       // S was made on the device (a single-rank level of a device-targeted setup): the sweeps below, one thread per
       // row; the markers come back for the host's bookkeeping and stay on the device for the interpolation
+      if (nprocs > 1 && (CF_init == 0 || CF_init == 2))
+      {
+         // distributed level: the sweeps on the extended graph, the host routine's exchanges (setup_kernels.hip)
+         if (*CF_marker_ptr == nullptr)
+         {
+            *CF_marker_ptr = hypre_IntArrayCreate(n);
+            hypre_IntArrayInitialize_v2(*CF_marker_ptr, HYPRE_MEMORY_HOST);
+         }
+         dist_device_pmis(S, A, CF_init, (*CF_marker_ptr)->data);
+         g_device_coarsen_count++;
+         return hypre_error_flag;
+      }
       if (nprocs > 1 || nco > 0 || (CF_init != 0 && CF_init != 2))
       {
          hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGCoarsenPMIS: device strength matrix outside the single-rank PMIS path");
@@ -1009,6 +1046,14 @@ HYPRE_Int hypre_BoomerAMGBuildExtPIInterp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_m
       const hypre_amd_CommOps *o = comm_ops(comm);
       std::vector<HYPRE_BigInt> ends((size_t) o->size);
       o->allgather(o->ctx, &num_cpts_global[1], ends.data(), sizeof(HYPRE_BigInt));
+      if (g_level_on_device && !sys && S->diag->memory_location == HYPRE_MEMORY_DEVICE)
+      {
+         // P_ptr comes back empty (error flag clear) when some rank's rows did not fit the kernel's tables: the caller
+         // repeats the level's interpolation with the host routine
+         dist_device_extpi_interp(A, CF_marker, S, num_cpts_global, ends.back(), trunc_factor, max_elmts, g_device_interp_on - 1, P_ptr);
+         if (*P_ptr) { g_device_interp_count++; }
+         return hypre_error_flag;
+      }
       return dist_build_extpi_interp(A, CF_marker, S, num_cpts_global, ends.back(), sys ? dof_func : nullptr, trunc_factor, max_elmts, P_ptr);
    }
    hypre_CSRMatrix *Ad = A->diag;
@@ -1401,7 +1446,16 @@ HYPRE_Int hypre_BoomerAMGBuildCoarseOperatorKT(hypre_ParCSRMatrix *RT, hypre_Par
                                                hypre_ParCSRMatrix **RAP_ptr)
 {
    MPI_Comm comm = A->comm;
-   if (comm_size(comm) > 1) { return dist_build_coarse_operator(RT, A, P, keepTranspose, RAP_ptr); }
+   if (comm_size(comm) > 1)
+   {
+      if (g_level_on_device && RT == P && P->diag->memory_location == HYPRE_MEMORY_DEVICE)
+      {
+         dist_device_coarse_operator(RT, A, P, keepTranspose, RAP_ptr);       // empty result, clear flag: the host routine takes over
+         if (*RAP_ptr) { g_device_rap_count++; }
+         return hypre_error_flag;
+      }
+      return dist_build_coarse_operator(RT, A, P, keepTranspose, RAP_ptr);
+   }
    if (device_galerkin_product(RT, A, P, keepTranspose, RAP_ptr)) { return hypre_error_flag; }
    if (A->diag->memory_location != HYPRE_MEMORY_HOST)
    {
@@ -1766,6 +1820,31 @@ static hypre_ParVector *new_vec(MPI_Comm comm, HYPRE_BigInt gsize, HYPRE_BigInt 
    return v;
 }
 
+namespace {
+// The flags that route the builders to the device, the twins and the markers belong to ONE run of the setup: set when it
+// starts, cleared on every way out (a standalone call of hypre_BoomerAMGBuildExtPIInterp or ..CoarseOperatorKT afterwards
+// works where its operands are, as the reference's do).
+struct SetupScope
+{
+   int saved_threads;
+   explicit SetupScope(bool device) : saved_threads(omp_get_max_threads())
+   {
+      g_setup_targets_device = device;
+      g_level_on_device = false;
+      g_interp_host_once = false;
+      drop_device_twins();
+   }
+   ~SetupScope()
+   {
+      g_setup_targets_device = false;
+      g_level_on_device = false;
+      g_interp_host_once = false;
+      drop_device_twins();
+      omp_set_num_threads(saved_threads);
+   }
+};
+}  // namespace
+
 HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_ParVector *f, hypre_ParVector *u)
 {
    (void) f; (void) u;
@@ -1780,8 +1859,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_BoomerAMGSetup: hierarchy requested in device memory but no HIP device is available");
       return hypre_error_flag;
    }
-   g_setup_targets_device = (target == HYPRE_MEMORY_DEVICE);
-   drop_device_twins();
+   SetupScope scope(target == HYPRE_MEMORY_DEVICE);
    const int max_levels = d->max_levels;
    d->A = A;
    d->A_array = (hypre_ParCSRMatrix **) calloc((size_t) max_levels, sizeof(void *));
@@ -1806,11 +1884,18 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    std::vector<hypre_ParCSRMatrix *> hostA((size_t) max_levels, nullptr);
    const bool A_on_device = A->diag->memory_location == HYPRE_MEMORY_DEVICE;
    const bool single_rank = comm_size(comm) == 1;
+   const int num_ranks = comm_size(comm);
    auto level_runs_on_device = [&](hypre_ParCSRMatrix *M, HYPRE_Int ct)
    {
-      return target == HYPRE_MEMORY_DEVICE && g_device_coarsen_on && g_device_interp_on && g_device_rap_on && single_rank &&
-             d->num_functions <= 1 && (ct == 8 || ct == 9) && d->interp_type == 6 && M->offd->num_cols == 0 &&
-             M->offd->num_nonzeros == 0 && M->diag->num_rows >= g_device_rap_min_rows && M->diag->num_nonzeros > 0;
+      if (!(target == HYPRE_MEMORY_DEVICE && g_device_coarsen_on && g_device_interp_on && g_device_rap_on &&
+            d->num_functions <= 1 && (ct == 8 || ct == 9) && d->interp_type == 6)) { return false; }
+      if (single_rank)
+      {
+         return M->offd->num_cols == 0 && M->offd->num_nonzeros == 0 && M->diag->num_rows >= g_device_rap_min_rows && M->diag->num_nonzeros > 0;
+      }
+      // several ranks (par_amg_setup_dist.cpp, the device half): every rank has to take the same road, so the test is on
+      // the level's global size; a rank with few rows, or none, goes along
+      return g_device_dist_on && M->global_num_rows / num_ranks >= (HYPRE_BigInt) g_device_rap_min_rows;
    };
    const bool A_stays = A_on_device && level_runs_on_device(A, d->coarsen_type);
    hostA[0] = (A_on_device && !A_stays) ? hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST) : A;
@@ -1819,9 +1904,9 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    auto fetch_level = [&](int l)
    {
       hypre_ParCSRMatrix *M = hostA[(size_t) l];
-      if (!M || M->diag->memory_location != HYPRE_MEMORY_DEVICE) { return; }
+      if (!M || (M->diag->memory_location != HYPRE_MEMORY_DEVICE && M->offd->memory_location != HYPRE_MEMORY_DEVICE)) { return; }
       if (l == 0 && M == A) { hostA[0] = hypre_ParCSRMatrixClone_v2(A, 1, HYPRE_MEMORY_HOST); own_host_A0 = true; }
-      else { make_host_resident(M->diag); }
+      else { make_host_resident(M->diag); make_host_resident(M->offd); }
    };
    if (d->num_functions > 1 && pv->filter_functions)
    {
@@ -1940,8 +2025,15 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
             // the device kernel declined (a row beyond its tables) and the level lives on the device: host copies, host loop
             fetch_level(level);
             Al = hostA[(size_t) level];
-            make_host_resident(S->diag);
-            g_interp_host_once = true;
+            if (single_rank) { make_host_resident(S->diag); g_interp_host_once = true; }
+            else
+            {
+               // (every rank is here: the verdict was agreed on)  the strength matrix again, as the host routine's two blocks
+               destroy_with_twins(S);
+               S = nullptr;
+               g_level_on_device = false;
+               hypre_BoomerAMGCreateS(Al, d->strong_threshold, d->max_row_sum, d->num_functions, dofs, &S);
+            }
             hypre_BoomerAMGBuildExtPIInterp(Al, CF, S, cpts, d->num_functions, dofs, 0, d->trunc_factor, d->P_max_elmts, &P);
          }
       }
@@ -1961,10 +2053,16 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       const double t_r0 = omp_get_wtime();
       hypre_ParCSRMatrix *AH = nullptr;
       hypre_BoomerAMGBuildCoarseOperatorKT(P, Al, P, 1, &AH);
-      if (!AH && !hypre_error_flag && Al->diag->memory_location == HYPRE_MEMORY_DEVICE)
+      if (!AH && !hypre_error_flag && (Al->diag->memory_location == HYPRE_MEMORY_DEVICE || (!single_rank && g_level_on_device)))
       {
          fetch_level(level);
          Al = hostA[(size_t) level];
+         if (!single_rank)
+         {
+            // (agreed on by every rank)  the host routine reads the interpolation operator's two blocks as well
+            make_host_resident(P->diag); make_host_resident(P->offd);
+            g_level_on_device = false;
+         }
          hypre_BoomerAMGBuildCoarseOperatorKT(P, Al, P, 1, &AH);
       }
       if (getenv("HYPRE_AMD_SETUP_TIMING") && comm_rank(comm) == 0)
@@ -2035,14 +2133,33 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          {
             if (l1) { hypre_Free(l1, l1_on_device ? HYPRE_MEMORY_DEVICE : HYPRE_MEMORY_HOST); l1 = nullptr; }
             hypre_ParCSRMatrix *M = hostA[(size_t) j];
-            if (M->diag->memory_location == HYPRE_MEMORY_DEVICE && gs_threads <= 1 && M->offd->num_cols == 0)
+            if (M->diag->memory_location == HYPRE_MEMORY_DEVICE && gs_threads <= 1 &&
+                (M->offd->num_cols == 0 || M->offd->memory_location == HYPRE_MEMORY_DEVICE))
             {
                // a level that never left the device: one thread per row, the host routine's sums in the host's order
-               const HYPRE_Int n = M->diag->num_rows;
+               const HYPRE_Int n = M->diag->num_rows, nco = M->offd->num_cols;
                l1 = hypre_TAlloc(HYPRE_Real, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
                l1_on_device = true;
                const HYPRE_Int *dcf = cfm ? device_marker_of(cfm, n) : nullptr;
-               if (!device_l1_norms(n, M->diag->i, M->diag->j, M->diag->data, option, dcf, l1, stream())) { hypre_error_in_arg(1); }
+               bool fine;
+               if (nco == 0) { fine = device_l1_norms(n, M->diag->i, M->diag->j, M->diag->data, option, dcf, l1, stream()); }
+               else
+               {
+                  // ghost columns: their markers come from the owners (CF-ordered relaxation only)
+                  HYPRE_Int *dcfo = nullptr;
+                  if (cfm)
+                  {
+                     std::vector<HYPRE_Int> cfo((size_t) nco);
+                     if (!M->comm_pkg) { hypre_MatvecCommPkgCreate(M); }
+                     halo_forward<HYPRE_Int>(M->comm_pkg, cfm, cfo.data());
+                     dcfo = hypre_TAlloc(HYPRE_Int, (size_t) nco, HYPRE_MEMORY_DEVICE);
+                     hypre_TMemcpy(dcfo, cfo.data(), HYPRE_Int, (size_t) nco, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+                  }
+                  fine = device_l1_norms_blocks(n, M->diag->i, M->diag->j, M->diag->data, M->offd->i, M->offd->j, M->offd->data, option, dcf,
+                                                dcfo, l1, stream());
+                  if (dcfo) { hypre_Free(dcfo, HYPRE_MEMORY_DEVICE); }
+               }
+               if (!fine) { hypre_error_in_arg(1); }
                return;
             }
             fetch_level(j);
@@ -2145,7 +2262,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          auto place = [&](hypre_ParCSRMatrix *M)
          {
             place_on_device(M->diag);
-            hypre_CSRMatrixMigrate(M->offd, HYPRE_MEMORY_DEVICE);
+            place_on_device(M->offd);
             if (M->diagT) { place_on_device(M->diagT); }
             if (M->offdT) { hypre_CSRMatrixMigrate(M->offdT, HYPRE_MEMORY_DEVICE); }
          };
@@ -2194,9 +2311,7 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    {
       for (int l = 0; l < num_levels - 1; l++) { hypre_amd_ParCSRMatrixKeepTranspose(d->P_array[l]); }
    }
-   drop_device_twins();
    if (own_host_A0) { hypre_ParCSRMatrixDestroy(hostA[0]); }
-   omp_set_num_threads(saved_omp_threads);
    return hypre_error_flag;
 }
 

@@ -144,6 +144,65 @@ HYPRE_Int bsearch_big(const HYPRE_BigInt *list, HYPRE_BigInt v, HYPRE_Int n)
    return (p != list + n && *p == v) ? (HYPRE_Int) (p - list) : -1;
 }
 
+// New off-rank nodes of the extended+i interpolation (aux_interp.c:351-560): the columns of ghost F rows (of the
+// fetched rows Aext and Sop) that are neither local nor ghosts of A become `found` (ascending); every off-rank column
+// of those rows is re-encoded as -(k) - 1 with k its position among A's ghosts, or nco + its position in `found`.
+void ghost_row_numbering(const HYPRE_BigInt *col_map_offd, HYPRE_Int nco, HYPRE_BigInt col_1, HYPRE_BigInt col_n,
+                         const std::vector<HYPRE_Int> &CF_offd, ExtCSR &Aext, ExtCSR &Sop, std::vector<HYPRE_BigInt> &found)
+{
+   for (HYPRE_Int i = 0; i < nco; i++)
+   {
+      if (CF_offd[(size_t) i] < 0)
+      {
+         for (HYPRE_Int k = Aext.i[(size_t) i]; k < Aext.i[(size_t) i + 1]; k++)
+         {
+            const HYPRE_BigInt g = Aext.j[(size_t) k];
+            if (g < col_1 || g >= col_n)
+            {
+               const HYPRE_Int f = bsearch_big(col_map_offd, g, nco);
+               if (f == -1) { found.push_back(g); } else { Aext.j[(size_t) k] = (HYPRE_BigInt) (-f - 1); }
+            }
+         }
+         for (HYPRE_Int k = Sop.i[(size_t) i]; k < Sop.i[(size_t) i + 1]; k++)
+         {
+            const HYPRE_BigInt g = Sop.j[(size_t) k];
+            if (g < col_1 || g >= col_n)
+            {
+               const HYPRE_Int f = bsearch_big(col_map_offd, g, nco);
+               if (f == -1) { found.push_back(g); } else { Sop.j[(size_t) k] = (HYPRE_BigInt) (-f - 1); }
+            }
+         }
+      }
+   }
+   std::sort(found.begin(), found.end());
+   found.erase(std::unique(found.begin(), found.end()), found.end());
+   const HYPRE_Int newoff = (HYPRE_Int) found.size();
+   for (HYPRE_Int i = 0; i < nco; i++)
+   {
+      if (CF_offd[(size_t) i] < 0)
+      {
+         for (HYPRE_Int k = Sop.i[(size_t) i]; k < Sop.i[(size_t) i + 1]; k++)
+         {
+            const HYPRE_BigInt g = Sop.j[(size_t) k];
+            if (g > -1 && (g < col_1 || g >= col_n))
+            {
+               const HYPRE_Int loc = bsearch_big(found.data(), g, newoff);
+               if (loc > -1) { Sop.j[(size_t) k] = (HYPRE_BigInt) (-(loc + nco) - 1); }
+            }
+         }
+         for (HYPRE_Int k = Aext.i[(size_t) i]; k < Aext.i[(size_t) i + 1]; k++)
+         {
+            const HYPRE_BigInt g = Aext.j[(size_t) k];
+            if (g > -1 && (g < col_1 || g >= col_n))
+            {
+               const HYPRE_Int loc = bsearch_big(found.data(), g, newoff);
+               if (loc > -1) { Aext.j[(size_t) k] = (HYPRE_BigInt) (-(loc + nco) - 1); }
+            }
+         }
+      }
+   }
+}
+
 }  // namespace
 
 namespace hamd {
@@ -179,59 +238,9 @@ HYPRE_Int dist_build_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, h
    halo_fwd<HYPRE_Int>(pkg, CF_marker, CF_offd.data(), 11);
    ExtCSR Aext = extract_ext(A, pkg, true, 2, CF_marker, CF_offd.data());
    ExtCSR Sop  = extract_ext(S, pkg, false, 1, CF_marker, CF_offd.data());
-   // new off-rank nodes (aux_interp.c:351-560): columns of ghost F rows that are neither local nor ghosts of A
    std::vector<HYPRE_BigInt> found;
-   for (HYPRE_Int i = 0; i < nco; i++)
-   {
-      if (CF_offd[(size_t) i] < 0)
-      {
-         for (HYPRE_Int k = Aext.i[(size_t) i]; k < Aext.i[(size_t) i + 1]; k++)
-         {
-            const HYPRE_BigInt g = Aext.j[(size_t) k];
-            if (g < col_1 || g >= col_n)
-            {
-               const HYPRE_Int f = bsearch_big(A->col_map_offd, g, nco);
-               if (f == -1) { found.push_back(g); } else { Aext.j[(size_t) k] = (HYPRE_BigInt) (-f - 1); }
-            }
-         }
-         for (HYPRE_Int k = Sop.i[(size_t) i]; k < Sop.i[(size_t) i + 1]; k++)
-         {
-            const HYPRE_BigInt g = Sop.j[(size_t) k];
-            if (g < col_1 || g >= col_n)
-            {
-               const HYPRE_Int f = bsearch_big(A->col_map_offd, g, nco);
-               if (f == -1) { found.push_back(g); } else { Sop.j[(size_t) k] = (HYPRE_BigInt) (-f - 1); }
-            }
-         }
-      }
-   }
-   std::sort(found.begin(), found.end());
-   found.erase(std::unique(found.begin(), found.end()), found.end());
+   ghost_row_numbering(A->col_map_offd, nco, col_1, col_n, CF_offd, Aext, Sop, found);
    const HYPRE_Int newoff = (HYPRE_Int) found.size();
-   for (HYPRE_Int i = 0; i < nco; i++)
-   {
-      if (CF_offd[(size_t) i] < 0)
-      {
-         for (HYPRE_Int k = Sop.i[(size_t) i]; k < Sop.i[(size_t) i + 1]; k++)
-         {
-            const HYPRE_BigInt g = Sop.j[(size_t) k];
-            if (g > -1 && (g < col_1 || g >= col_n))
-            {
-               const HYPRE_Int loc = bsearch_big(found.data(), g, newoff);
-               if (loc > -1) { Sop.j[(size_t) k] = (HYPRE_BigInt) (-(loc + nco) - 1); }
-            }
-         }
-         for (HYPRE_Int k = Aext.i[(size_t) i]; k < Aext.i[(size_t) i + 1]; k++)
-         {
-            const HYPRE_BigInt g = Aext.j[(size_t) k];
-            if (g > -1 && (g < col_1 || g >= col_n))
-            {
-               const HYPRE_Int loc = bsearch_big(found.data(), g, newoff);
-               if (loc > -1) { Aext.j[(size_t) k] = (HYPRE_BigInt) (-(loc + nco) - 1); }
-            }
-         }
-      }
-   }
    const HYPRE_Int full_off = nco + newoff;
    // package for the new nodes only (collective: every rank builds one, possibly empty)
    hypre_ParCSRCommPkg ext_pkg;
@@ -695,6 +704,487 @@ HYPRE_Int dist_build_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix 
          memcpy(C->offd->data + oo, t_coa[(size_t) t].data(), sizeof(HYPRE_Real) * t_coa[(size_t) t].size());
       }
    }
+   if (ncoRAP)
+   {
+      C->col_map_offd = hypre_TAlloc(HYPRE_BigInt, ncoRAP, HYPRE_MEMORY_HOST);
+      memcpy(C->col_map_offd, cmapRAP.data(), sizeof(HYPRE_BigInt) * (size_t) ncoRAP);
+   }
+   if (keepTranspose) { RT->diagT = Rd; RT->offdT = Ro; }
+   else { hypre_CSRMatrixDestroy(Rd); if (Ro) { hypre_CSRMatrixDestroy(Ro); } }
+   hypre_CSRMatrixSetRownnz(C->offd);
+   hypre_ParCSRMatrixSetNumNonzeros(C);
+   hypre_ParCSRMatrixSetDNumNonzeros(C);
+   hypre_MatvecCommPkgCreate(C);
+   *RAP_ptr = C;
+   return hypre_error_flag;
+}
+
+
+// ===========================================================================
+// The same steps for a level that lives in DEVICE memory: the single-rank kernels on the extended numbering
+// [local points | ghost points] (dist_setup_kernels.hip).  What travels between ranks is what the host routines above
+// exchange — boundary-sized row sets, extracted on the device, exchanged and renumbered on the host, appended on the
+// device as rows n .. of the extended matrices.  The results equal the host routines' array for array.
+// Reference: par_coarsen_device.c:30, par_lr_interp_device.c:1001, par_csr_triplemat.c:938-960 (other formulations).
+// ===========================================================================
+namespace {
+
+template <class T>
+T *upload(const T *h, size_t n)
+{
+   T *d = nullptr;
+   HIP_CHECK(hipMalloc((void **) &d, sizeof(T) * std::max<size_t>(n, 1)));
+   if (n)
+   {
+      HIP_CHECK(hipMemcpyAsync(d, h, sizeof(T) * n, hipMemcpyHostToDevice, stream()));
+      HIP_CHECK(hipStreamSynchronize(stream()));
+   }
+   return d;
+}
+template <class T>
+void fetch(T *h, const T *d, size_t n)
+{
+   if (!n) { return; }
+   HIP_CHECK(hipMemcpyAsync(h, d, sizeof(T) * n, hipMemcpyDeviceToHost, stream()));
+   HIP_CHECK(hipStreamSynchronize(stream()));
+}
+void dfree(void *p) { if (p) { HIP_CHECK(hipFree(p)); } }
+
+// a host CSR (rows of ghost points, extended column numbers) on the device
+struct DevCSR
+{
+   int *i = nullptr, *j = nullptr;
+   double *a = nullptr;
+   void put(const std::vector<HYPRE_Int> &hi, const std::vector<HYPRE_Int> &hj, const std::vector<HYPRE_Real> *ha)
+   {
+      i = upload(hi.data(), hi.size());
+      j = upload(hj.data(), hj.size());
+      if (ha) { a = upload(ha->data(), ha->size()); }
+   }
+   ~DevCSR() { dfree(i); dfree(j); dfree(a); }
+};
+
+const int *send_elmts_on_device(hypre_ParCSRCommPkg *pkg)
+{
+   const HYPRE_Int tot = pkg->send_map_starts[pkg->num_sends];
+   if (!pkg->device_send_map_elmts && tot)
+   {
+      pkg->device_send_map_elmts = hypre_TAlloc(HYPRE_Int, tot, HYPRE_MEMORY_DEVICE);
+      hypre_TMemcpy(pkg->device_send_map_elmts, pkg->send_map_elmts, HYPRE_Int, tot, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   }
+   return pkg->device_send_map_elmts;
+}
+
+}  // namespace
+
+bool all_ranks_agree(MPI_Comm comm, bool mine)
+{
+   return global_sum(comm, mine ? 0.0 : 1.0) == 0.0;
+}
+
+HYPRE_Int dist_device_create_S(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_Real max_row_sum, hypre_ParCSRMatrix **S_ptr)
+{
+   hypre_CSRMatrix *dD = setup_device_twin_of(A->diag, 1), *dO = setup_device_twin_of(A->offd, 1);
+   const HYPRE_Int n = A->diag->num_rows, nco = A->offd->num_cols;
+   int *Si = nullptr, *Sj = nullptr, snnz = 0;
+   device_strength_blocks(n, dD->i, dD->j, dD->data, nco ? dO->i : nullptr, dO->j, dO->data, theta, max_row_sum, &Si, &Sj, &snnz, stream());
+   hypre_ParCSRMatrix *S = hypre_ParCSRMatrixCreate(A->comm, A->global_num_rows, A->global_num_rows, A->row_starts, A->row_starts, 0, snnz, 0);
+   hypre_CSRMatrixDestroy(S->diag);
+   S->diag = setup_wrap_device_csr(n, n + nco, snnz, Si, Sj, nullptr);      // one pattern over the extended numbering
+   hypre_CSRMatrixInitialize_v2(S->offd, 0, HYPRE_MEMORY_HOST);
+   *S_ptr = S;
+   return hypre_error_flag;
+}
+
+HYPRE_Int dist_device_pmis(hypre_ParCSRMatrix *S, hypre_ParCSRMatrix *A, HYPRE_Int CF_init, HYPRE_Int *CF_host)
+{
+   MPI_Comm comm = A->comm;
+   HYPRE_Int my_id;
+   hypre_MPI_Comm_rank(comm, &my_id);
+   if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+   hypre_ParCSRCommPkg *pkg = A->comm_pkg;
+   const HYPRE_Int n = A->diag->num_rows, nco = A->offd->num_cols;
+   const HYPRE_Int tot = pkg->send_map_starts[pkg->num_sends];
+   const int *d_elmts = send_elmts_on_device(pkg);
+   // previous slot of the send list that names the same point (a point on an edge or a corner goes to several neighbours)
+   std::vector<int> prev((size_t) std::max(tot, 1), -1);
+   {
+      std::vector<std::pair<int, int>> order((size_t) tot);
+      for (HYPRE_Int k = 0; k < tot; k++) { order[(size_t) k] = {pkg->send_map_elmts[k], k}; }
+      std::sort(order.begin(), order.end());
+      for (HYPRE_Int q = 1; q < tot; q++) { if (order[(size_t) q].first == order[(size_t) q - 1].first) { prev[(size_t) order[(size_t) q].second] = order[(size_t) q - 1].second; } }
+   }
+   int *d_prev = upload(prev.data(), (size_t) tot);
+   HYPRE_Int *dCF = hypre_TAlloc(HYPRE_Int, (size_t) std::max(n + nco, 1), HYPRE_MEMORY_DEVICE);
+   hypre_CSRMatrix *Sd = S->diag;
+   device_pmis_dist(n, nco, Sd->i, Sd->j, Sd->num_nonzeros, 2747u + (CF_init == 2 ? 0u : (unsigned) my_id),
+                    CF_init == 2 ? (unsigned long long) S->first_row_index : 0ull, pkg, d_elmts, d_prev, comm, dCF, stream());
+   fetch(CF_host, dCF, (size_t) n);
+   dfree(d_prev);
+   setup_register_device_marker(CF_host, dCF);
+   return hypre_error_flag;
+}
+
+HYPRE_Int dist_device_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, hypre_ParCSRMatrix *S,
+                                   HYPRE_BigInt *num_cpts_global, HYPRE_BigInt total_global_cpts, HYPRE_Real trunc_factor,
+                                   HYPRE_Int max_elmts, HYPRE_Int first_rung, hypre_ParCSRMatrix **P_ptr)
+{
+   *P_ptr = nullptr;
+   MPI_Comm comm = A->comm;
+   hipStream_t st = stream();
+   if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+   hypre_ParCSRCommPkg *pkg = A->comm_pkg;
+   hypre_CSRMatrix *dD = setup_device_twin_of(A->diag, 1), *dO = setup_device_twin_of(A->offd, 1), *Sx = S->diag;
+   const HYPRE_Int n = A->diag->num_rows, nco = A->offd->num_cols;
+   const HYPRE_BigInt col_1 = A->first_row_index, col_n = col_1 + n;
+   const HYPRE_BigInt my_first_cpt = num_cpts_global[0];
+   const HYPRE_Int ncP = (HYPRE_Int) (num_cpts_global[1] - num_cpts_global[0]);
+   const HYPRE_Int tot = pkg->send_map_starts[pkg->num_sends];
+   const int *d_elmts = send_elmts_on_device(pkg);
+   HYPRE_Int *dCF = setup_device_marker_of(CF_marker, n);          // left by the device coarsening (or uploaded now)
+
+   // ---- markers of the ghost points, the rows of A and S the neighbours hold for them
+   std::vector<HYPRE_Int> CF_offd((size_t) std::max(nco, 1));
+   halo_fwd<HYPRE_Int>(pkg, CF_marker, CF_offd.data(), 11);
+   long long *d_cmap = upload((const long long *) A->col_map_offd, (size_t) nco);
+   int *dCFx = nullptr;                                            // markers over [local | ghosts of A]
+   HIP_CHECK(hipMalloc((void **) &dCFx, sizeof(int) * (size_t) std::max(n + nco, 1)));
+   if (n) { HIP_CHECK(hipMemcpyAsync(dCFx, dCF, sizeof(int) * (size_t) n, hipMemcpyDeviceToDevice, st)); }
+   if (nco) { HIP_CHECK(hipMemcpyAsync(dCFx + n, CF_offd.data(), sizeof(int) * (size_t) nco, hipMemcpyHostToDevice, st)); }
+   HIP_CHECK(hipStreamSynchronize(st));
+   ExtCSR Aext, Sop;
+   {
+      ExtCSR rows;
+      device_extract_rows(2, tot, d_elmts, dD->i, dD->j, dD->data, nco ? dO->i : nullptr, dO->j, dO->data, (long long) A->first_col_diag,
+                          d_cmap, dCF, rows.i, rows.j, rows.a, st);
+      if (rows.j.empty()) { rows.j.push_back(0); rows.a.push_back(0.0); }
+      Aext = exchange_rows(pkg, rows, true, true);
+   }
+   {
+      ExtCSR rows;
+      device_extract_S_rows(tot, d_elmts, n, Sx->i, Sx->j, (long long) A->first_col_diag, d_cmap, dCFx, rows.i, rows.j, st);
+      if (rows.j.empty()) { rows.j.push_back(0); }
+      Sop = exchange_rows(pkg, rows, true, false);
+   }
+   dfree(d_cmap); dfree(dCFx);
+   std::vector<HYPRE_BigInt> found;
+   ghost_row_numbering(A->col_map_offd, nco, col_1, col_n, CF_offd, Aext, Sop, found);
+   const HYPRE_Int newoff = (HYPRE_Int) found.size(), full_off = nco + newoff;
+   hypre_ParCSRCommPkg ext_pkg;
+   memset(&ext_pkg, 0, sizeof(ext_pkg));
+   ext_pkg.comm = comm;
+   hypre_ParCSRCommPkgCreate_core(comm, found.empty() ? nullptr : found.data(), A->first_col_diag, A->col_starts,
+                                  A->diag->num_cols, newoff, &ext_pkg.num_recvs, &ext_pkg.recv_procs,
+                                  &ext_pkg.recv_vec_starts, &ext_pkg.num_sends, &ext_pkg.send_procs,
+                                  &ext_pkg.send_map_starts, &ext_pkg.send_map_elmts);
+   CF_offd.resize((size_t) std::max(full_off, 1));
+   halo_fwd<HYPRE_Int>(&ext_pkg, CF_marker, CF_offd.data() + nco, 11);
+
+   // ---- coarse numbers: local ones on the device; the ghosts' global ones through the two packages
+   int *dF2Cx = nullptr;                                          // over [local | ghosts | new nodes]
+   HIP_CHECK(hipMalloc((void **) &dF2Cx, sizeof(int) * (size_t) std::max(n + full_off, 1)));
+   device_coarse_numbering(n, dCF, dF2Cx, st);
+   std::vector<HYPRE_BigInt> f2c_offd((size_t) std::max(full_off, 1), -1);
+   auto coarse_ids_out = [&](hypre_ParCSRCommPkg *pk, const int *d_idx, HYPRE_BigInt *ghost)
+   {
+      const HYPRE_Int t = pk->send_map_starts[pk->num_sends];
+      std::vector<HYPRE_Int> loc((size_t) std::max(t, 1));
+      std::vector<HYPRE_BigInt> buf((size_t) std::max(t, 1));
+      if (t)
+      {
+         int *d_out = nullptr;
+         HIP_CHECK(hipMalloc((void **) &d_out, sizeof(int) * (size_t) t));
+         launch_gather_int(dF2Cx, d_idx, d_out, (size_t) t, st);
+         fetch(loc.data(), d_out, (size_t) t);
+         dfree(d_out);
+      }
+      for (HYPRE_Int k = 0; k < t; k++) { buf[(size_t) k] = (HYPRE_BigInt) loc[(size_t) k] + my_first_cpt; }
+      hypre_ParCSRCommHandle *h = hypre_ParCSRCommHandleCreate(21, pk, buf.data(), ghost);
+      hypre_ParCSRCommHandleDestroy(h);
+   };
+   coarse_ids_out(pkg, d_elmts, f2c_offd.data());
+   {
+      const HYPRE_Int t = ext_pkg.send_map_starts[ext_pkg.num_sends];
+      int *d_idx = upload(ext_pkg.send_map_elmts, (size_t) t);
+      coarse_ids_out(&ext_pkg, d_idx, f2c_offd.data() + nco);
+      dfree(d_idx);
+   }
+
+   // ---- extended matrices: the ghost F points' rows behind the local ones.  A fetched row of A holds only the entries the
+   // weights can use (sign opposite to its diagonal: the owner filtered them) and no diagonal: a stand-in of the right
+   // sign goes in front, where the kernel expects a row's diagonal
+   std::vector<HYPRE_Int> gi((size_t) full_off + 1, 0), gj, si((size_t) full_off + 1, 0), sj;
+   std::vector<HYPRE_Real> ga;
+   auto ext_id = [&](HYPRE_BigInt g) { return g >= 0 ? (HYPRE_Int) (g - col_1) : n + (HYPRE_Int) (-g - 1); };
+   for (HYPRE_Int k = 0; k < nco; k++)
+   {
+      if (CF_offd[(size_t) k] < 0)
+      {
+         const HYPRE_Int b = Aext.i[(size_t) k], e = Aext.i[(size_t) k + 1];
+         gj.push_back(n + k);
+         ga.push_back(b < e && Aext.a[(size_t) b] > 0 ? -1.0 : 1.0);
+         for (HYPRE_Int q = b; q < e; q++) { gj.push_back(ext_id(Aext.j[(size_t) q])); ga.push_back(Aext.a[(size_t) q]); }
+         for (HYPRE_Int q = Sop.i[(size_t) k]; q < Sop.i[(size_t) k + 1]; q++) { sj.push_back(ext_id(Sop.j[(size_t) q])); }
+      }
+      gi[(size_t) k + 1] = (HYPRE_Int) gj.size();
+      si[(size_t) k + 1] = (HYPRE_Int) sj.size();
+   }
+   for (HYPRE_Int k = nco; k < full_off; k++) { gi[(size_t) k + 1] = gi[(size_t) k]; si[(size_t) k + 1] = si[(size_t) k]; }
+   bool ok = true;
+   int *Pdi = nullptr, *Pdj = nullptr, *Poi = nullptr, *Poj = nullptr, dnnz = 0, onnz = 0;
+   double *Pda = nullptr, *Poa = nullptr;
+   {
+      DevCSR G, GS;
+      G.put(gi, gj, &ga);
+      GS.put(si, sj, nullptr);
+      int *Ei = nullptr, *Ej = nullptr, *SEi = nullptr, *SEj = nullptr, ennz = 0, sennz = 0;
+      double *Ea = nullptr;
+      device_extend_csr(n, dD->i, dD->j, dD->data, nco ? dO->i : nullptr, dO->j, dO->data, n, full_off, G.i, G.j, G.a, &Ei, &Ej, &Ea, &ennz, st);
+      device_extend_csr(n, Sx->i, Sx->j, nullptr, nullptr, nullptr, nullptr, 0, full_off, GS.i, GS.j, nullptr, &SEi, &SEj, nullptr, &sennz, st);
+      // markers and coarse numbers of the ghost points: an off-rank C point's column is ncP + its ghost number
+      int *dCFf = nullptr;
+      HIP_CHECK(hipMalloc((void **) &dCFf, sizeof(int) * (size_t) std::max(n + full_off, 1)));
+      std::vector<int> f2c_g((size_t) std::max(full_off, 1));
+      for (HYPRE_Int k = 0; k < full_off; k++) { f2c_g[(size_t) k] = CF_offd[(size_t) k] >= 0 ? ncP + k : -1; }
+      if (n) { HIP_CHECK(hipMemcpyAsync(dCFf, dCF, sizeof(int) * (size_t) n, hipMemcpyDeviceToDevice, st)); }
+      if (full_off)
+      {
+         HIP_CHECK(hipMemcpyAsync(dCFf + n, CF_offd.data(), sizeof(int) * (size_t) full_off, hipMemcpyHostToDevice, st));
+         HIP_CHECK(hipMemcpyAsync(dF2Cx + n, f2c_g.data(), sizeof(int) * (size_t) full_off, hipMemcpyHostToDevice, st));
+      }
+      HIP_CHECK(hipStreamSynchronize(st));
+      ok = device_extpi(n, Ei, Ej, Ea, SEi, SEj, dCFf, dF2Cx, trunc_factor, max_elmts, first_rung, &Pdi, &Pdj, &Pda, &dnnz, st,
+                        ncP, &Poi, &Poj, &Poa, &onnz);
+      dfree(Ei); dfree(Ej); dfree(Ea); dfree(SEi); dfree(SEj); dfree(dCFf);
+   }
+   dfree(dF2Cx);
+   auto free_ext_pkg = [&]()
+   {
+      hypre_Free(ext_pkg.recv_procs, HYPRE_MEMORY_HOST); hypre_Free(ext_pkg.recv_vec_starts, HYPRE_MEMORY_HOST);
+      hypre_Free(ext_pkg.send_procs, HYPRE_MEMORY_HOST); hypre_Free(ext_pkg.send_map_starts, HYPRE_MEMORY_HOST);
+      hypre_Free(ext_pkg.send_map_elmts, HYPRE_MEMORY_HOST);
+   };
+   if (!all_ranks_agree(comm, ok))
+   {
+      if (ok) { dfree(Pdi); dfree(Pdj); dfree(Pda); dfree(Poi); dfree(Poj); dfree(Poa); }
+      free_ext_pkg();
+      return hypre_error_flag;
+   }
+
+   // ---- column map of the off-rank block (aux_interp.c:777-900): the ghosts in use, ascending coarse number
+   std::vector<HYPRE_BigInt> cmap;
+   {
+      int *d_used = nullptr;
+      HIP_CHECK(hipMalloc((void **) &d_used, sizeof(int) * (size_t) std::max(full_off, 1)));
+      HIP_CHECK(hipMemsetAsync(d_used, 0, sizeof(int) * (size_t) std::max(full_off, 1), st));
+      launch_mark_used(Poj, (size_t) onnz, d_used, st);
+      std::vector<int> used((size_t) std::max(full_off, 1), 0);
+      fetch(used.data(), d_used, (size_t) full_off);
+      for (HYPRE_Int g = 0; g < full_off; g++) { if (used[(size_t) g]) { cmap.push_back(f2c_offd[(size_t) g]); } }
+      std::sort(cmap.begin(), cmap.end());
+      cmap.erase(std::unique(cmap.begin(), cmap.end()), cmap.end());
+      std::vector<int> renum((size_t) std::max(full_off, 1), 0);
+      for (HYPRE_Int g = 0; g < full_off; g++)
+      {
+         if (used[(size_t) g]) { renum[(size_t) g] = (int) (std::lower_bound(cmap.begin(), cmap.end(), f2c_offd[(size_t) g]) - cmap.begin()); }
+      }
+      HIP_CHECK(hipMemcpyAsync(d_used, renum.data(), sizeof(int) * (size_t) full_off, hipMemcpyHostToDevice, st));
+      launch_renumber(Poj, (size_t) onnz, 0, d_used, st);
+      HIP_CHECK(hipStreamSynchronize(st));
+      dfree(d_used);
+   }
+   HYPRE_BigInt cs[2] = {num_cpts_global[0], num_cpts_global[1]};
+   hypre_ParCSRMatrix *P = hypre_ParCSRMatrixCreate(comm, A->global_num_rows, total_global_cpts, A->col_starts, cs,
+                                                    (HYPRE_Int) cmap.size(), dnnz, onnz);
+   hypre_CSRMatrixDestroy(P->diag); hypre_CSRMatrixDestroy(P->offd);
+   P->diag = setup_wrap_device_csr(n, ncP, dnnz, Pdi, Pdj, Pda);
+   P->offd = setup_wrap_device_csr(n, (HYPRE_Int) cmap.size(), onnz, Poi, Poj, Poa);
+   if (!cmap.empty())
+   {
+      P->col_map_offd = hypre_TAlloc(HYPRE_BigInt, cmap.size(), HYPRE_MEMORY_HOST);
+      memcpy(P->col_map_offd, cmap.data(), sizeof(HYPRE_BigInt) * cmap.size());
+   }
+   hypre_CSRMatrixSetRownnz(P->offd);
+   hypre_MatvecCommPkgCreate(P);
+   free_ext_pkg();
+   *P_ptr = P;
+   return hypre_error_flag;
+}
+
+HYPRE_Int dist_device_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix *A, hypre_ParCSRMatrix *P,
+                                      HYPRE_Int keepTranspose, hypre_ParCSRMatrix **RAP_ptr)
+{
+   *RAP_ptr = nullptr;
+   MPI_Comm comm = A->comm;
+   hipStream_t st = stream();
+   if (!A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+   if (!RT->comm_pkg) { hypre_MatvecCommPkgCreate(RT); }
+   hypre_ParCSRCommPkg *pkgA = A->comm_pkg, *pkgRT = RT->comm_pkg;
+   hypre_CSRMatrix *dD = setup_device_twin_of(A->diag, 1), *dO = setup_device_twin_of(A->offd, 1);
+   hypre_CSRMatrix *Pd = setup_device_twin_of(P->diag, 1), *Po = setup_device_twin_of(P->offd, 1);
+   const HYPRE_Int n = A->diag->num_rows, ncoA = A->offd->num_cols;
+   const HYPRE_Int ncP = P->diag->num_cols, ncoP = P->offd->num_cols, ncoRT = RT->offd->num_cols, ncRT = RT->diag->num_cols;
+   const HYPRE_BigInt first_c = P->first_col_diag, last_c = first_c + ncP - 1;
+   hypre_CSRMatrix *Rd = nullptr, *Ro = nullptr;
+   hypre_CSRMatrixTranspose(Pd, &Rd, 1);
+   if (ncoRT) { hypre_CSRMatrixTranspose(Po, &Ro, 1); }
+
+   // ---- P_ext: the rows of P of A's ghost columns, local coarse columns first, off-rank ones behind
+   ExtCSR Ps;
+   {
+      const HYPRE_Int totA = pkgA->send_map_starts[pkgA->num_sends];
+      long long *d_cmapP = upload((const long long *) P->col_map_offd, (size_t) ncoP);
+      ExtCSR rows;
+      device_extract_rows(0, totA, send_elmts_on_device(pkgA), Pd->i, Pd->j, Pd->data, ncoP ? Po->i : nullptr, Po->j, Po->data,
+                          (long long) first_c, d_cmapP, nullptr, rows.i, rows.j, rows.a, st);
+      dfree(d_cmapP);
+      if (rows.j.empty()) { rows.j.push_back(0); rows.a.push_back(0.0); }
+      Ps = exchange_rows(pkgA, rows, true, true);
+   }
+   std::vector<HYPRE_Int> Pedi((size_t) ncoA + 1, 0), Peoi((size_t) ncoA + 1, 0), Pedj, Peoj;
+   std::vector<HYPRE_Real> Peda, Peoa;
+   std::vector<HYPRE_BigInt> Pe_big;
+   for (HYPRE_Int i = 0; i < ncoA; i++)
+   {
+      for (HYPRE_Int k = Ps.i[(size_t) i]; k < Ps.i[(size_t) i + 1]; k++)
+      {
+         const HYPRE_BigInt g = Ps.j[(size_t) k];
+         if (g < first_c || g > last_c) { Pe_big.push_back(g); Peoa.push_back(Ps.a[(size_t) k]); }
+         else { Pedj.push_back((HYPRE_Int) (g - first_c)); Peda.push_back(Ps.a[(size_t) k]); }
+      }
+      Pedi[(size_t) i + 1] = (HYPRE_Int) Pedj.size();
+      Peoi[(size_t) i + 1] = (HYPRE_Int) Pe_big.size();
+   }
+   std::vector<HYPRE_BigInt> cmapPext(Pe_big);
+   for (HYPRE_Int k = 0; k < ncoP; k++) { cmapPext.push_back(P->col_map_offd[k]); }
+   std::sort(cmapPext.begin(), cmapPext.end());
+   cmapPext.erase(std::unique(cmapPext.begin(), cmapPext.end()), cmapPext.end());
+   const HYPRE_Int ncoPext = (HYPRE_Int) cmapPext.size();
+   Peoj.resize(Pe_big.size());
+   for (size_t k = 0; k < Pe_big.size(); k++) { Peoj[k] = bsearch_big(cmapPext.data(), Pe_big[k], ncoPext); }
+   std::vector<int> mapP2Pext((size_t) std::max(ncoP, 1));
+   for (HYPRE_Int k = 0; k < ncoP; k++) { mapP2Pext[(size_t) k] = bsearch_big(cmapPext.data(), P->col_map_offd[k], ncoPext); }
+
+   // ---- the extended interpolation operator: rows of the local points [P_diag | ncP + P_offd in P_ext's numbering], then
+   // the ghost points' rows
+   int *Xi = nullptr, *Xj = nullptr, xnnz = 0;
+   double *Xa = nullptr;
+   {
+      std::vector<HYPRE_Int> gi((size_t) ncoA + 1, 0), gj;
+      std::vector<HYPRE_Real> ga;
+      for (HYPRE_Int i = 0; i < ncoA; i++)
+      {
+         for (HYPRE_Int k = Pedi[(size_t) i]; k < Pedi[(size_t) i + 1]; k++) { gj.push_back(Pedj[(size_t) k]); ga.push_back(Peda[(size_t) k]); }
+         for (HYPRE_Int k = Peoi[(size_t) i]; k < Peoi[(size_t) i + 1]; k++) { gj.push_back(ncP + Peoj[(size_t) k]); ga.push_back(Peoa[(size_t) k]); }
+         gi[(size_t) i + 1] = (HYPRE_Int) gj.size();
+      }
+      DevCSR G;
+      G.put(gi, gj, &ga);
+      int *d_map = upload(mapP2Pext.data(), (size_t) ncoP), *oj = nullptr;
+      const HYPRE_Int onz = Po->num_nonzeros;
+      HIP_CHECK(hipMalloc((void **) &oj, sizeof(int) * (size_t) std::max(onz, 1)));
+      if (onz) { HIP_CHECK(hipMemcpyAsync(oj, Po->j, sizeof(int) * (size_t) onz, hipMemcpyDeviceToDevice, st)); }
+      launch_renumber(oj, (size_t) onz, 0, d_map, st);
+      device_extend_csr(n, Pd->i, Pd->j, Pd->data, ncoP ? Po->i : nullptr, oj, Po->data, ncP, ncoA, G.i, G.j, G.a, &Xi, &Xj, &Xa, &xnnz, st);
+      dfree(d_map); dfree(oj);
+   }
+   const int maxP = device_max_row_nnz(Xi, n + ncoA, st);
+   auto give_up = [&]()
+   {
+      dfree(Xi); dfree(Xj); dfree(Xa);
+      hypre_CSRMatrixDestroy(Rd);
+      if (Ro) { hypre_CSRMatrixDestroy(Ro); }
+      return hypre_error_flag;
+   };
+
+   // ---- the rows of the product that belong to the neighbours (one per ghost coarse column of P), sent home
+   ExtCSR Rint;
+   {
+      int *Ii = nullptr, *Ij = nullptr, innz = 0;
+      double *Ia = nullptr;
+      const bool ok = device_rap_dist(true, ncoRT, 0, ncP + ncoPext, maxP, 0, Ro ? Ro->i : nullptr, Ro ? Ro->j : nullptr, Ro ? Ro->data : nullptr,
+                                      dD->i, dD->j, dD->data, ncoA ? dO->i : nullptr, dO->j, dO->data, n, n, Xi, Xj, Xa,
+                                      nullptr, nullptr, nullptr, nullptr, nullptr, ncP, &Ii, &Ij, &Ia, &innz, nullptr, nullptr, nullptr, nullptr, st);
+      if (!all_ranks_agree(comm, ok))
+      {
+         if (ok) { dfree(Ii); dfree(Ij); dfree(Ia); }
+         return give_up();
+      }
+      Rint.i.assign((size_t) ncoRT + 1, 0);
+      std::vector<int> hj((size_t) std::max(innz, 1));
+      Rint.a.resize((size_t) std::max(innz, 1));
+      fetch(Rint.i.data(), Ii, (size_t) ncoRT + 1);
+      fetch(hj.data(), Ij, (size_t) innz);
+      fetch(Rint.a.data(), Ia, (size_t) innz);
+      dfree(Ii); dfree(Ij); dfree(Ia);
+      Rint.j.resize((size_t) std::max(innz, 1), 0);
+      for (HYPRE_Int k = 0; k < innz; k++)
+      {
+         const int c = hj[(size_t) k];
+         Rint.j[(size_t) k] = c < ncP ? (HYPRE_BigInt) c + first_c : cmapPext[(size_t) (c - ncP)];
+      }
+      if (innz == 0) { Rint.j.assign(1, 0); Rint.a.assign(1, 0.0); }
+      else { Rint.j.resize((size_t) innz); Rint.a.resize((size_t) innz); }
+   }
+   ExtCSR Rext = exchange_rows(pkgRT, Rint, false, true);
+   const HYPRE_Int nsendRT = pkgRT->send_map_starts[pkgRT->num_sends];
+
+   // ---- column map of the off-rank block of the product
+   std::vector<HYPRE_BigInt> cmapRAP;
+   for (size_t k = 0; k < Rext.j.size(); k++) { if (Rext.j[k] < first_c || Rext.j[k] > last_c) { cmapRAP.push_back(Rext.j[k]); } }
+   for (HYPRE_Int k = 0; k < ncoPext; k++) { cmapRAP.push_back(cmapPext[(size_t) k]); }
+   std::sort(cmapRAP.begin(), cmapRAP.end());
+   cmapRAP.erase(std::unique(cmapRAP.begin(), cmapRAP.end()), cmapRAP.end());
+   const HYPRE_Int ncoRAP = (HYPRE_Int) cmapRAP.size();
+   std::vector<int> mapPext2RAP((size_t) std::max(ncoPext, 1));
+   for (HYPRE_Int k = 0; k < ncoPext; k++) { mapPext2RAP[(size_t) k] = bsearch_big(cmapRAP.data(), cmapPext[(size_t) k], ncoRAP); }
+   // what the neighbours computed for this rank's rows: the received rows in the extended coarse numbering, and per local
+   // coarse row the received rows that feed it, in package order
+   std::vector<HYPRE_Int> xj(Rext.j.size());
+   for (size_t k = 0; k < Rext.j.size(); k++)
+   {
+      const HYPRE_BigInt g = Rext.j[k];
+      xj[k] = (g < first_c || g > last_c) ? ncP + bsearch_big(cmapRAP.data(), g, ncoRAP) : (HYPRE_Int) (g - first_c);
+   }
+   std::vector<HYPRE_Int> Fi((size_t) ncRT + 1, 0), Fj((size_t) std::max(nsendRT, 1));
+   for (HYPRE_Int s = 0; s < nsendRT; s++) { Fi[(size_t) pkgRT->send_map_elmts[s] + 1]++; }
+   for (HYPRE_Int ic = 0; ic < ncRT; ic++) { Fi[(size_t) ic + 1] += Fi[(size_t) ic]; }
+   int max_seed = 0;
+   {
+      std::vector<HYPRE_Int> pos(Fi.begin(), Fi.end() - 1), seed((size_t) std::max(ncRT, 1), 0);
+      for (HYPRE_Int s = 0; s < nsendRT; s++)
+      {
+         const HYPRE_Int ic = pkgRT->send_map_elmts[s];
+         Fj[(size_t) pos[(size_t) ic]++] = s;
+         seed[(size_t) ic] += Rext.i[(size_t) s + 1] - Rext.i[(size_t) s];
+         max_seed = std::max(max_seed, (int) seed[(size_t) ic]);
+      }
+   }
+   int *Cdi = nullptr, *Cdj = nullptr, *Coi = nullptr, *Coj = nullptr, cdnnz = 0, connz = 0;
+   double *Cda = nullptr, *Coa = nullptr;
+   bool ok;
+   {
+      DevCSR X;
+      X.put(Rext.i, xj, &Rext.a);
+      int *dFi = upload(Fi.data(), Fi.size()), *dFj = upload(Fj.data(), (size_t) nsendRT);
+      int *d_map = upload(mapPext2RAP.data(), (size_t) ncoPext);
+      launch_renumber(Xj, (size_t) xnnz, ncP, d_map, st);            // P_ext's numbering of the ghost coarse points -> the product's
+      ok = device_rap_dist(false, ncRT, ncRT == ncP ? 1 : 0, ncP + ncoRAP, maxP, max_seed, Rd->i, Rd->j, Rd->data,
+                           dD->i, dD->j, dD->data, ncoA ? dO->i : nullptr, dO->j, dO->data, n, n, Xi, Xj, Xa,
+                           nsendRT ? dFi : nullptr, dFj, X.i, X.j, X.a, ncP, &Cdi, &Cdj, &Cda, &cdnnz, &Coi, &Coj, &Coa, &connz, st);
+      dfree(dFi); dfree(dFj); dfree(d_map);
+   }
+   if (!all_ranks_agree(comm, ok))
+   {
+      if (ok) { dfree(Cdi); dfree(Cdj); dfree(Cda); dfree(Coi); dfree(Coj); dfree(Coa); }
+      return give_up();
+   }
+   dfree(Xi); dfree(Xj); dfree(Xa);
+   hypre_ParCSRMatrix *C = hypre_ParCSRMatrixCreate(comm, RT->global_num_cols, P->global_num_cols, RT->col_starts,
+                                                    P->col_starts, ncoRAP, cdnnz, connz);
+   hypre_CSRMatrixDestroy(C->diag); hypre_CSRMatrixDestroy(C->offd);
+   C->diag = setup_wrap_device_csr(ncRT, ncP, cdnnz, Cdi, Cdj, Cda);
+   C->offd = setup_wrap_device_csr(ncRT, ncoRAP, connz, Coi, Coj, Coa);
    if (ncoRAP)
    {
       C->col_map_offd = hypre_TAlloc(HYPRE_BigInt, ncoRAP, HYPRE_MEMORY_HOST);

@@ -56,6 +56,51 @@ void strength_kernel(int n, const int *__restrict__ Ai, const int *__restrict__ 
    if (!FILL) { cnt[i] = c; }
 }
 
+// A rank's two blocks (par_strength.c:75-530 with ghost columns): the row is "diag entries, then offd entries" for the
+// scale, the row sum and the strong couplings alike; a strong ghost column g is stored as n + g (extended numbering)
+template <bool FILL>
+__global__ __launch_bounds__(TB)
+void strength_blocks_kernel(int n, const int *__restrict__ Di, const int *__restrict__ Dj, const double *__restrict__ Da,
+                            const int *__restrict__ Oi, const int *__restrict__ Oj, const double *__restrict__ Oa,
+                            double theta, double max_row_sum, int *__restrict__ cnt, const int *__restrict__ Si, int *__restrict__ Sj)
+{
+   const int i = blockIdx.x * TB + threadIdx.x;
+   if (i >= n) { return; }
+   const int b = Di[i], e = Di[i + 1], ob = Oi ? Oi[i] : 0, oe = Oi ? Oi[i + 1] : 0;
+   if (e <= b) { if (!FILL) { cnt[i] = 0; } return; }
+   const double diag = Da[b];
+   double row_scale = 0.0, row_sum = diag;
+   if (diag < 0)
+   {
+      for (int k = b + 1; k < e; k++) { const double a = Da[k]; row_scale = fmax(row_scale, a); row_sum += a; }
+      for (int k = ob; k < oe; k++) { const double a = Oa[k]; row_scale = fmax(row_scale, a); row_sum += a; }
+   }
+   else
+   {
+      for (int k = b + 1; k < e; k++) { const double a = Da[k]; row_scale = fmin(row_scale, a); row_sum += a; }
+      for (int k = ob; k < oe; k++) { const double a = Oa[k]; row_scale = fmin(row_scale, a); row_sum += a; }
+   }
+   const bool all_weak = (fabs(row_sum) > fabs(diag) * max_row_sum) && (max_row_sum < 1.0);
+   const double bar = theta * row_scale;
+   int c = 0, p = FILL ? Si[i] : 0;
+   if (!all_weak)
+   {
+      for (int k = b + 1; k < e; k++)
+      {
+         const double a = Da[k];
+         const bool strong = diag < 0 ? !(a <= bar) : !(a >= bar);
+         if (strong) { if (FILL) { Sj[p++] = Dj[k]; } else { c++; } }
+      }
+      for (int k = ob; k < oe; k++)
+      {
+         const double a = Oa[k];
+         const bool strong = diag < 0 ? !(a <= bar) : !(a >= bar);
+         if (strong) { if (FILL) { Sj[p++] = n + Oj[k]; } else { c++; } }
+      }
+   }
+   if (!FILL) { cnt[i] = c; }
+}
+
 // ---- PMIS ----------------------------------------------------------------------------------------------------------
 constexpr int C_PT = 1, F_PT = -1, SF_PT = -3;
 
@@ -161,6 +206,54 @@ void pmis_retire_kernel(int n, double *__restrict__ measure, const int *__restri
    }
 }
 
+// ---- PMIS across ranks (par_coarsen.c:2101-2810 with ghost points) --------------------------------------------------------
+// ghost points carry the owner's measure; decided ghosts leave the graph like local points
+__global__ __launch_bounds__(TB)
+void pmis_retire_ghost_kernel(int nco, double *__restrict__ measure_g, const int *__restrict__ CF_g)
+{
+   const int i = blockIdx.x * TB + threadIdx.x;
+   if (i < nco && CF_g[i] != 0) { measure_g[i] = 0.0; }
+}
+__global__ __launch_bounds__(TB)
+void add_counts_kernel(int tot, const int *__restrict__ elmts, const int *__restrict__ buf, int *__restrict__ cnt)
+{
+   const int k = blockIdx.x * TB + threadIdx.x;
+   if (k < tot && buf[k]) { atomicAdd(&cnt[elmts[k]], buf[k]); }
+}
+__global__ __launch_bounds__(TB)
+void gather_double_kernel(int tot, const double *__restrict__ x, const int *__restrict__ elmts, double *__restrict__ out)
+{
+   const int k = blockIdx.x * TB + threadIdx.x;
+   if (k < tot) { out[k] = x[elmts[k]]; }
+}
+__global__ __launch_bounds__(TB)
+void gather_marker_kernel(int tot, const int *__restrict__ x, const int *__restrict__ elmts, int *__restrict__ out)
+{
+   const int k = blockIdx.x * TB + threadIdx.x;
+   if (k < tot) { out[k] = x[elmts[k]]; }
+}
+// What the neighbours decided about this rank's boundary points (par_coarsen.c:2485-2500): the host walks the send list
+//    for k: if (!recv[k] && CF[elmt] > 0) CF[elmt] = 0; else recv[k] = CF[elmt];
+// IN ORDER, and a point listed for several neighbours is knocked out from the first slot on that says so — the slots
+// before it still report the old marker.  out[k] = what slot k reports; prev[k] = the previous slot of the same point.
+__global__ __launch_bounds__(TB)
+void pmis_verdict_kernel(int tot, const int *__restrict__ elmts, const int *__restrict__ prev, const int *__restrict__ recv,
+                         const int *__restrict__ CF, int *__restrict__ out)
+{
+   const int k = blockIdx.x * TB + threadIdx.x;
+   if (k >= tot) { return; }
+   const int orig = CF[elmts[k]];
+   bool knocked = false;
+   if (orig > 0) { for (int q = k; q >= 0; q = prev[q]) { if (recv[q] == 0) { knocked = true; break; } } }
+   out[k] = knocked ? 0 : orig;
+}
+__global__ __launch_bounds__(TB)
+void pmis_apply_verdict_kernel(int tot, const int *__restrict__ elmts, const int *__restrict__ out, int *__restrict__ CF)
+{
+   const int k = blockIdx.x * TB + threadIdx.x;
+   if (k < tot && out[k] == 0 && CF[elmts[k]] > 0) { CF[elmts[k]] = 0; }
+}
+
 // ---- coarse numbering: f2c[i] = number of C points before i, or -1 ---------------------------------------------------
 __global__ __launch_bounds__(TB)
 void cpt_flag_kernel(int n, const int *__restrict__ CF, int *__restrict__ flag)
@@ -257,6 +350,92 @@ int device_pmis(int n, const int *Si, const int *Sj, int snnz, unsigned seed, un
    }
    HIP_CHECK(hipFree(measure));
    HIP_CHECK(hipFree(cnt));
+   return sweeps;
+}
+
+// S of a rank's two blocks, as ONE pattern over the extended numbering (local columns, then n + ghost column)
+void device_strength_blocks(int n, const int *Di, const int *Dj, const double *Da, const int *Oi, const int *Oj, const double *Oa,
+                            double theta, double max_row_sum, int **Si_out, int **Sj_out, int *nnz_out, hipStream_t s)
+{
+   int *Si = nullptr, *Sj = nullptr;
+   HIP_CHECK(hipMalloc((void **) &Si, sizeof(int) * ((size_t) n + 1)));
+   HIP_CHECK(hipMemsetAsync(Si, 0, sizeof(int) * ((size_t) n + 1), s));
+   if (n > 0) { hipLaunchKernelGGL((strength_blocks_kernel<false>), dim3(grid_for((size_t) n)), dim3(TB), 0, s, n, Di, Dj, Da, Oi, Oj, Oa, theta, max_row_sum, Si, nullptr, nullptr); }
+   launch_scan_exclusive(Si, n, s);
+   int nnz = 0;
+   HIP_CHECK(hipMemcpyAsync(&nnz, Si + n, sizeof(int), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipMalloc((void **) &Sj, sizeof(int) * (size_t) std::max(nnz, 1)));
+   if (n > 0) { hipLaunchKernelGGL((strength_blocks_kernel<true>), dim3(grid_for((size_t) n)), dim3(TB), 0, s, n, Di, Dj, Da, Oi, Oj, Oa, theta, max_row_sum, nullptr, Si, Sj); }
+   *Si_out = Si; *Sj_out = Sj; *nnz_out = nnz;
+}
+
+// PMIS of a distributed level on the extended graph (n rows; columns below n local, n + g ghost g of the package).
+// CF has n + nco entries: the local markers, then the ghosts' (current when the routine returns).  d_elmts / d_prev: the
+// package's send list and, per slot, the previous slot naming the same point (-1: none), both on the device.
+// Every exchange is the host routine's (par_coarsen.c:2101-2810): column counts of ghost columns to their owners, the
+// measures out to the ghosts, and per sweep ghost verdicts in / markers out / settled markers out; the sweep count is
+// agreed on through one all-reduce per sweep.  Returns the number of sweeps.
+int device_pmis_dist(int n, int nco, const int *Si, const int *Sj, int snnz, unsigned seed, unsigned long long skip,
+                     hypre_ParCSRCommPkg *pkg, const int *d_elmts, const int *d_prev, MPI_Comm comm, int *CF, hipStream_t s)
+{
+   const int tot = pkg ? pkg->send_map_starts[pkg->num_sends] : 0;
+   const int next = n + nco;
+   double *measure = nullptr, *dbuf = nullptr;
+   int *cnt = nullptr, *ibuf = nullptr, *obuf = nullptr;
+   HIP_CHECK(hipMalloc((void **) &measure, sizeof(double) * (size_t) std::max(next, 1)));
+   HIP_CHECK(hipMalloc((void **) &cnt, sizeof(int) * ((size_t) next + 1)));
+   HIP_CHECK(hipMalloc((void **) &dbuf, sizeof(double) * (size_t) std::max(tot, 1)));
+   HIP_CHECK(hipMalloc((void **) &ibuf, sizeof(int) * (size_t) std::max(tot, 1)));
+   HIP_CHECK(hipMalloc((void **) &obuf, sizeof(int) * (size_t) std::max(tot, 1)));
+   HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * ((size_t) next + 1), s));
+   HIP_CHECK(hipMemsetAsync(measure, 0, sizeof(double) * (size_t) std::max(next, 1), s));
+   HIP_CHECK(hipMemsetAsync(CF, 0, sizeof(int) * (size_t) std::max(next, 1), s));
+   auto exchange = [&](int job, void *send, void *recv)
+   {
+      if (!pkg) { return; }
+      hypre_ParCSRCommHandle *h = hypre_ParCSRCommHandleCreate_v2(job, pkg, HYPRE_MEMORY_DEVICE, send, HYPRE_MEMORY_DEVICE, recv);
+      hypre_ParCSRCommHandleDestroy(h);
+   };
+   if (snnz > 0) { hipLaunchKernelGGL(column_count_kernel, dim3(grid_for((size_t) snnz)), dim3(TB), 0, s, Sj, (size_t) snnz, cnt); }
+   // what the neighbours' rows add to this rank's points
+   exchange(12, cnt + n, ibuf);
+   if (tot > 0) { hipLaunchKernelGGL(add_counts_kernel, dim3(grid_for((size_t) tot)), dim3(TB), 0, s, tot, d_elmts, ibuf, cnt); }
+   const int g = grid_for((size_t) std::max(n, 1)), gx = grid_for((size_t) std::max(next, 1)), gg = grid_for((size_t) std::max(nco, 1));
+   const int gt = grid_for((size_t) std::max(tot, 1));
+   if (n > 0) { hipLaunchKernelGGL(pmis_init_kernel, dim3(g), dim3(TB), 0, s, n, Si, cnt, seed, skip, measure, CF); }
+   if (tot > 0) { hipLaunchKernelGGL(gather_double_kernel, dim3(gt), dim3(TB), 0, s, tot, measure, d_elmts, dbuf); }
+   exchange(1, dbuf, measure + n);
+   int *left = cnt + next, sweeps = 0;
+   auto undecided = [&]()
+   {
+      HIP_CHECK(hipMemsetAsync(left, 0, sizeof(int), s));
+      if (n > 0) { hipLaunchKernelGGL(pmis_retire_kernel, dim3(g), dim3(TB), 0, s, n, measure, CF, left); }
+      if (nco > 0) { hipLaunchKernelGGL(pmis_retire_ghost_kernel, dim3(gg), dim3(TB), 0, s, nco, measure + n, CF + n); }
+      int h_left = 0;
+      HIP_CHECK(hipMemcpyAsync(&h_left, left, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      return (long long) llround(global_sum(comm, (double) h_left));
+   };
+   while (undecided() > 0)
+   {
+      hipLaunchKernelGGL(pmis_candidates_kernel, dim3(gx), dim3(TB), 0, s, next, measure, CF);
+      if (n > 0) { hipLaunchKernelGGL(pmis_knockout_kernel, dim3(g), dim3(TB), 0, s, n, Si, Sj, measure, CF); }
+      exchange(12, CF + n, ibuf);
+      if (tot > 0)
+      {
+         hipLaunchKernelGGL(pmis_verdict_kernel, dim3(gt), dim3(TB), 0, s, tot, d_elmts, d_prev, ibuf, CF, obuf);
+         hipLaunchKernelGGL(pmis_apply_verdict_kernel, dim3(gt), dim3(TB), 0, s, tot, d_elmts, obuf, CF);
+      }
+      exchange(11, obuf, CF + n);
+      if (n > 0) { hipLaunchKernelGGL(pmis_settle_kernel, dim3(g), dim3(TB), 0, s, n, Si, Sj, measure, CF); }
+      if (tot > 0) { hipLaunchKernelGGL(gather_marker_kernel, dim3(gt), dim3(TB), 0, s, tot, CF, d_elmts, obuf); }
+      exchange(11, obuf, CF + n);
+      sweeps++;
+      if (sweeps > 10000) { break; }
+   }
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(measure)); HIP_CHECK(hipFree(cnt)); HIP_CHECK(hipFree(dbuf)); HIP_CHECK(hipFree(ibuf)); HIP_CHECK(hipFree(obuf));
    return sweeps;
 }
 

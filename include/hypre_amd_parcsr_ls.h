@@ -266,6 +266,13 @@ HYPRE_Int hypre_amd_SetSetupDeviceInterp(HYPRE_Int on);
  * number of levels coarsened on the device since the previous call.  The reference's device routines:
  * parcsr_ls/par_strength_device.c, parcsr_ls/par_coarsen_device.c:30. */
 HYPRE_Int hypre_amd_SetSetupDeviceCoarsen(HYPRE_Int on);
+/* Levels of a DISTRIBUTED hierarchy (several ranks, one per GPU) are set up on the device as well when the three switches
+ * above are on and a level has at least min_rows rows per rank on average: the single-rank kernels run on the extended
+ * numbering [local points | ghost points], fed with the rows the host routines exchange (A_ext, S_ext, P_ext, the product
+ * rows computed for the neighbours, the PMIS halo rounds); results equal the host routines' array for array.  on = 0 keeps
+ * distributed levels on the host (OpenMP loops); negative: unchanged.  Returns the previous setting.  The reference's device
+ * routines: par_coarsen_device.c:30, par_lr_interp_device.c:1001, parcsr_mv/par_csr_triplemat.c:938-960. */
+HYPRE_Int hypre_amd_SetSetupDeviceDist(HYPRE_Int on);
 /* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows, default 100000; 0: off) is recorded once as a
  * HIP graph and replayed: its kernels are a few microseconds each behind launches that cost as much.  No reference
  * counterpart (the reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded

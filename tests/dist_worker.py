@@ -41,7 +41,91 @@ def main():
     dist.destroy_process_group()
 
 
+def _blocks(B, m):
+    """arrays of one rank's share of a ParCSR matrix, stored transposes included"""
+    out = list(B.csr_to_arrays(m.diag)) + list(B.csr_to_arrays(m.offd))
+    nco = m.offd.contents.num_cols
+    out.append(np.array([m.col_map_offd[k] for k in range(nco)], dtype=np.int64))
+    for t in (m.diagT, m.offdT):
+        if t:
+            out += list(B.csr_to_arrays(t))
+    return out
+
+
+def compare_setup(case, L, B, ij, O, dist, comm, rank, world):
+    """HYPRE_BoomerAMGSetup twice on the same distributed problem, hierarchy in device memory: the distributed levels worked
+    on by the host routines (OpenMP loops) and by the device kernels.  Every array of every level of this rank's share must
+    be identical: operators (both blocks, ghost column maps), interpolation operators and their stored transposes, C/F
+    markers, smoother diagonals."""
+    opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
+    hier, counts = [], []
+    for on in (0, 1):
+        L.hypre_amd_SetSetupDeviceDist(on)
+        L.hypre_amd_SetSetupDeviceRAP(1, int(case.get("min_rows", 50)))
+        L.hypre_amd_SetSetupDeviceInterp(1 + int(case.get("rung", 0)))
+        L.hypre_amd_SetSetupDeviceCoarsen(1)
+        A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
+        if on and case.get("matrix_on_device"):
+            L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+        s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+        L.HYPRE_BoomerAMGSetup(s, A, None, None)
+        B.check()
+        counts.append((L.hypre_amd_SetSetupDeviceCoarsen(-1), L.hypre_amd_SetSetupDeviceInterp(-1), L.hypre_amd_SetSetupDeviceRAP(-1, -1)))
+        nl = L.hypre_amd_BoomerAMGGetNumLevels(s)
+        lv = []
+        for l in range(nl):
+            Al = C.cast(L.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix)).contents
+            lv.append(("A%d" % l, _blocks(B, Al)))
+            if l < nl - 1:
+                Pl = C.cast(L.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix)).contents
+                lv.append(("P%d" % l, _blocks(B, Pl)))
+            cfp = L.hypre_amd_BoomerAMGGetCFMarker(s, l)
+            if cfp:
+                ia = C.cast(cfp, C.POINTER(B.IntArray)).contents
+                lv.append(("cf%d" % l, [B.fetch(ia.data, ia.size, np.int32, ia.memory_location)]))
+            lp = L.hypre_amd_BoomerAMGGetL1Norms(s, l)
+            if lp:
+                v = C.cast(lp, C.POINTER(B.Vector)).contents
+                lv.append(("l1_%d" % l, [B.fetch(v.data, v.size, np.float64, v.memory_location)]))
+        hier.append(lv)
+        L.HYPRE_BoomerAMGDestroy(s)
+        B.check()
+        L.hypre_ParCSRMatrixDestroy(A)
+        B.check()
+    L.hypre_amd_SetSetupDeviceDist(1)
+    L.hypre_amd_SetSetupDeviceRAP(1, 20000)
+    L.hypre_amd_SetSetupDeviceInterp(1)
+    L.hypre_amd_SetSetupDeviceCoarsen(1)
+    mismatch = None
+    if len(hier[0]) != len(hier[1]):
+        mismatch = "hierarchies of %d and %d pieces" % (len(hier[0]), len(hier[1]))
+    else:
+        for (n0, a0), (n1, a1) in zip(hier[0], hier[1]):
+            if n0 != n1 or len(a0) != len(a1):
+                mismatch = "%s / %s: %d and %d arrays" % (n0, n1, len(a0), len(a1))
+                break
+            for k, (x, y) in enumerate(zip(a0, a1)):
+                if x.shape != y.shape or not np.array_equal(x, y):
+                    where = int(np.flatnonzero(x != y)[0]) if x.shape == y.shape else -1
+                    mismatch = "rank %d, %s array %d (shapes %s %s, first difference at %d)" % (rank, n0, k, x.shape, y.shape, where)
+                    break
+            if mismatch:
+                break
+    mine = dict(mismatch=mismatch, host_counts=counts[0], device_counts=counts[1], pieces=len(hier[1]),
+                sizes=[int(a[1][0].shape[0]) - 1 for a in hier[1] if a[0].startswith("A")])
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0)
+    if rank == 0:
+        bad = [p["mismatch"] for p in parts if p["mismatch"]]
+        out = {"name": case.get("name"), "setup_equal": not bad, "mismatch": bad[:3],
+               "host_counts": [list(p["host_counts"]) for p in parts], "device_counts": [list(p["device_counts"]) for p in parts],
+               "local_sizes": [p["sizes"] for p in parts]}
+        print("RESULT " + json.dumps(out), flush=True)
+
+
 def run_case(case, L, B, ij, O, dist, comm, rank, world):
+    if case.get("compare_setup"):
+        return compare_setup(case, L, B, ij, O, dist, comm, rank, world)
     opt = ij.IJOptions(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in case["options"].items()})
     for name in ("fromfile", "rhsfromfile"):          # the reference's input files live beside the goldens
         if getattr(opt, name):
@@ -54,8 +138,18 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
     mixed = bool(case.get("mixed", 0))
     if mixed:
         L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    if "min_rows" in case:
+        # distributed levels of at least that many rows per rank are set up by the device kernels (default 20000)
+        L.hypre_amd_SetSetupDeviceRAP(1, int(case["min_rows"]))
+        if case.get("matrix_on_device"):
+            L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
     B.check()
+    device_levels = L.hypre_amd_SetSetupDeviceCoarsen(-1)
+    if "min_rows" in case:
+        L.hypre_amd_SetSetupDeviceRAP(1, 20000)
+        if case.get("matrix_on_device"):
+            L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_HOST)
     g, o = C.c_double(), C.c_double()
     L.hypre_amd_BoomerAMGGetComplexities(s, C.byref(g), C.byref(o))
 
@@ -144,7 +238,7 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
             L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
         B.check()
-        mine.update(replicated_level=int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)))
+        mine.update(replicated_level=int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)), device_levels=int(device_levels))
         mine.update(dev_its=its.value, dev_rel=rel.value, dev_x=B.parvec_to_numpy(dx), xt=xt,
                     dev_y=B.parvec_to_numpy(dy), dev_z=B.parvec_to_numpy(dz), dev_dot=dot, zt_repeat=zt_repeat,
                     mv_x=Xm, mv_y=mv_y, mv_z=mv_z)
@@ -182,7 +276,7 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             yd = np.concatenate([p["dev_y"] for p in parts])
             zd = np.concatenate([p["dev_z"] for p in parts])
             xd = np.concatenate([p["dev_x"] for p in parts])
-            out.update(replicated_level=parts[0]["replicated_level"])
+            out.update(replicated_level=parts[0]["replicated_level"], device_levels=min(p["device_levels"] for p in parts))
             # multivector products, column by column, against the oracle
             Xg = np.concatenate([p["mv_x"] for p in parts]); Yg = np.concatenate([p["mv_y"] for p in parts])
             Zg = np.concatenate([p["mv_z"] for p in parts])

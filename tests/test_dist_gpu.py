@@ -151,6 +151,122 @@ def test_baseline_multi_rank_configs_on_device(name):
     assert (out["replicated_level"] == -1) == ("no_tail" in name)
 
 
+# The distributed SETUP on the device (par_amg_setup_dist.cpp, the device half: the single-rank kernels on the extended
+# numbering [local points | ghost points]) against the host routines of the same library, which the reference's 2-8-rank
+# regression files pin: every array of every level identical on every rank.  Levels of at least min_rows rows per rank go to
+# the device (default 20000: the test lowers it so that three or four levels of these small problems do).  Rank counts:
+# the GPU box admits six processes on its card at once — the test runner, the launcher and FOUR ranks — so the 2 x 2 x 2
+# boxes of the eight-GPU configurations cannot share it; 2 x 2 x 1 gives the 27-point operator faces and an edge (three
+# neighbours), 1 x 2 x 2 and 4 x 1 x 1 the other orientations.  (Eight ranks run through the same routines on the host
+# transport in tests/test_dist_golden.py; the eight-GPU run is the driver's.)
+SETUP_CASES = {
+    "c3_7pt_2ranks": (2, dict(n=[40, 20, 20], P=[2, 1, 1], relax_type=18, coarsen_type=8), {}),
+    "c3_7pt_4ranks": (4, dict(n=[40, 40, 20], P=[2, 2, 1], relax_type=18, coarsen_type=8), {}),
+    "c3_7pt_4ranks_matrix_on_device": (4, dict(n=[36, 36, 18], P=[2, 2, 1], relax_type=18, coarsen_type=8), {"matrix_on_device": 1}),
+    "c3_7pt_4ranks_1x1x4": (4, dict(n=[20, 20, 48], P=[1, 1, 4], relax_type=18, coarsen_type=8), {"rung": 2}),
+    "c3_7pt_4ranks_4x1x1": (4, dict(n=[64, 14, 14], P=[4, 1, 1], relax_type=18, coarsen_type=8), {}),
+    "c4_27pt_2ranks_relax11": (2, dict(n=[32, 16, 16], P=[2, 1, 1], problem="27pt", relax_type=11, coarsen_type=8), {}),
+    "c4_27pt_4ranks_relax12": (4, dict(n=[28, 28, 14], P=[2, 2, 1], problem="27pt", relax_type=12, coarsen_type=8), {}),
+    "c4_27pt_4ranks_1x2x2_relax11": (4, dict(n=[14, 26, 26], P=[1, 2, 2], problem="27pt", relax_type=11, coarsen_type=8), {}),
+    "c5_difconv_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], problem="difconv", c=[1.0, 1.0, 0.001], a=[0.0, 0.0, 0.0],
+                                  relax_type=18, coarsen_type=8), {}),
+    "c5_difconv_convection_2ranks": (2, dict(n=[24, 24, 24], P=[1, 1, 2], problem="difconv", c=[1.0, 0.01, 1.0], a=[3.0, 2.0, 1.0],
+                                             relax_type=18, coarsen_type=8), {}),
+    "pmis1_trunc_4ranks": (4, dict(n=[28, 28, 14], P=[2, 2, 1], problem="27pt", relax_type=18, coarsen_type=9, P_max_elmts=6,
+                                   trunc_factor=0.1), {}),
+    "no_pmax_2ranks": (2, dict(n=[32, 16, 16], P=[2, 1, 1], relax_type=18, coarsen_type=8, P_max_elmts=0), {}),
+    "pmax2_3ranks": (3, dict(n=[45, 16, 16], P=[3, 1, 1], relax_type=7, coarsen_type=8, P_max_elmts=2), {}),
+    "cf_relax_l1_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, relax_order=1, coarsen_type=8), {}),
+    "l1_gs_3ranks": (3, dict(n=[42, 18, 18], P=[3, 1, 1], relax_type=8, coarsen_type=8), {}),
+    "strong_threshold_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, coarsen_type=8, strong_threshold=0.6, max_row_sum=0.8), {}),
+}
+_setup = {}
+
+
+def _setup_result(name):
+    nranks = SETUP_CASES[name][0]
+    if nranks not in _setup:
+        from conftest import free_port
+        names = [k for k, v in SETUP_CASES.items() if v[0] == nranks]
+        spec = {"batch": [dict({"name": k, "options": SETUP_CASES[k][1], "device": 1, "compare_setup": 1}, **SETUP_CASES[k][2])
+                          for k in names], "transport": "staged"}
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
+               json.dumps(spec)]
+        env = dict(os.environ, OMP_NUM_THREADS="1", HYPRE_AMD_TEST_WATCHDOG="900")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+        res = {}
+        for line in r.stdout.splitlines():
+            if line.startswith("RESULT "):
+                d = json.loads(line[len("RESULT "):])
+                res[d["name"]] = d
+        _setup[nranks] = (r.returncode, res, _tail(r))
+    rc, res, tail = _setup[nranks]
+    assert name in res, "no result for %s (worker exit code %d)\n%s" % (name, rc, tail)
+    return res[name]
+
+
+@pytest.mark.parametrize("name", sorted(SETUP_CASES))
+def test_distributed_device_setup_is_the_host_setup(name):
+    out = _setup_result(name)
+    assert out["setup_equal"], out["mismatch"]
+    # the host run coarsened nothing on the device, the device run at least two levels on every rank, interpolation and
+    # Galerkin product included
+    assert all(c[0] == 0 for c in out["host_counts"]), out["host_counts"]
+    assert all(min(c) >= 2 for c in out["device_counts"]), out["device_counts"]
+
+
+# ... and the solve phase on hierarchies the device built (communication packages, row lists of the ghost blocks, stored
+# transposes made there): the BASELINE configurations again, AMG and AMG-PCG against the oracle on the exported hierarchy
+DEVICE_BUILT_CASES = {
+    "c3_pcg_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, coarsen_type=8, solver=1), {"min_rows": 40}),
+    "c3_amg_4ranks_no_tail": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, coarsen_type=8), {"min_rows": 40, "replicate": 0}),
+    "c3_amg_4ranks_matrix_on_device": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, coarsen_type=8),
+                                       {"min_rows": 40, "matrix_on_device": 1}),
+    "c4_pcg_relax11_4ranks": (4, dict(n=[24, 24, 12], P=[2, 2, 1], problem="27pt", relax_type=11, coarsen_type=8, solver=1), {"min_rows": 40}),
+    "c4_amg_relax12_4ranks_no_tail": (4, dict(n=[12, 24, 24], P=[1, 2, 2], problem="27pt", relax_type=12, coarsen_type=8),
+                                      {"min_rows": 40, "replicate": 0}),
+    "c5_pcg_mixed_4ranks": (4, dict(n=[24, 24, 24], P=[2, 2, 1], problem="difconv", c=[1.0, 1.0, 0.001], a=[0.0, 0.0, 0.0],
+                                    relax_type=18, coarsen_type=8, solver=1), {"min_rows": 40, "mixed": 1}),
+    "c3_amg_3ranks": (3, dict(n=[36, 20, 20], P=[3, 1, 1], relax_type=18, coarsen_type=8), {"min_rows": 40}),
+}
+_built = {}
+
+
+def _built_result(name):
+    nranks = DEVICE_BUILT_CASES[name][0]
+    if nranks not in _built:
+        from conftest import free_port
+        names = [k for k, v in DEVICE_BUILT_CASES.items() if v[0] == nranks]
+        spec = {"batch": [dict({"name": k, "options": DEVICE_BUILT_CASES[k][1], "device": 1}, **DEVICE_BUILT_CASES[k][2])
+                          for k in names], "transport": "staged"}
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(HERE, "dist_worker.py"),
+               json.dumps(spec)]
+        env = dict(os.environ, OMP_NUM_THREADS="1", HYPRE_AMD_TEST_WATCHDOG="900")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+        res = {}
+        for line in r.stdout.splitlines():
+            if line.startswith("RESULT "):
+                d = json.loads(line[len("RESULT "):])
+                res[d["name"]] = d
+        _built[nranks] = (r.returncode, res, _tail(r))
+    rc, res, tail = _built[nranks]
+    assert name in res, "no result for %s (worker exit code %d)\n%s" % (name, rc, tail)
+    return res[name]
+
+
+@pytest.mark.parametrize("name", sorted(DEVICE_BUILT_CASES))
+def test_solves_on_device_built_distributed_hierarchies(name):
+    out = _built_result(name)
+    assert out["device_levels"] >= 2
+    assert out["matvec_err"] < 1e-13 and out["matvecT_err"] < 1e-13 and out["dot_err"] < 1e-12
+    assert out["dev_iterations"] == out["iterations"] and out["iterations"] > 3
+    assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
+    assert out["x_err"] < 1e-9
+    assert (out["replicated_level"] == -1) == ("no_tail" in name)
+
+
 def test_replicated_tail_is_used_and_optional():
     """Jacobi-type V-cycles on several ranks run their small levels on a replicated copy (one all-reduce instead of
     four halo exchanges per level); switched off, the same solve goes through the distributed levels.  Both
