@@ -159,11 +159,10 @@ def main():
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
     if args.mixed:
         L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
-    # one rank: the matrix is handed to the setup in device memory, as the reference's driver does with -exec device
-    # (ij.c migrates the IJ matrix first), and the whole setup runs there; several ranks: the distributed setup is a
-    # host code and takes the host matrix
-    if world == 1:
-        L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+    # the matrix is handed to the setup in device memory, as the reference's driver does with -exec device (ij.c migrates
+    # the IJ matrix first), and the whole setup runs there — on several ranks too (the distributed levels run the
+    # single-rank kernels on the extended numbering; HYPRE_AMD_SETUP_DEVICE_DIST=0 keeps them on the host)
+    L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
     L.hypre_SyncComputeStream()
     t1 = time.time()
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
@@ -283,13 +282,36 @@ def main():
         pass
 
     # ---- CPU baseline: the oracle's V-cycle on the same hierarchy, host cores ------------
+    # N = 1: the hierarchy just timed.  N > 1 (rank 0 only, the others wait at the fence below): the per-GPU block of the
+    # job — the n^3 problem of one rank — set up as a single-rank hierarchy on rank 0's GPU, its cycle checked against
+    # and timed with the oracle; the job is N such blocks (weak scaling), so DOF/s is the comparable figure.
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle as O
-        amg = O.amg_from_solvers([s], mixed_precision=args.mixed)
-        f = np.ones(nloc)
-        ur = np.zeros(nloc)
+        if world == 1:
+            s1, A1, n_cpu, b1, u1 = s, A, nloc, b, u
+        else:
+            opt1 = ij.IJOptions(n=(n1, n1, n1), P=(1, 1, 1), coarsen_type=8, interp_type=6, P_max_elmts=4,
+                                relax_type=args.relax, num_sweeps=1, problem=args.problem)
+            if args.relax_up > -1:
+                opt1.relax_down, opt1.relax_up = args.relax, args.relax_up
+            if args.problem == "difconv":
+                opt1.c, opt1.a = (1.0, 1.0, 0.001), (0.0, 0.0, 0.0)
+            A1 = ij.build_matrix(opt1)
+            s1 = ij.create_amg(opt1, memory_location=B.HYPRE_MEMORY_DEVICE)
+            if args.mixed:
+                L.hypre_amd_BoomerAMGSetMixedPrecision(s1, 1)
+            L.hypre_ParCSRMatrixMigrate(A1, B.HYPRE_MEMORY_DEVICE)
+            L.HYPRE_BoomerAMGSetup(s1, A1, None, None)
+            B.check()
+            n_cpu = n1 ** 3
+            b1, u1 = B.parvec_from_numpy(np.ones(n_cpu)), B.parvec_from_numpy(np.zeros(n_cpu))
+            L.HYPRE_BoomerAMGSetTol(s1, 0.0)
+            L.HYPRE_BoomerAMGSetMaxIter(s1, 1)
+        amg = O.amg_from_solvers([s1], mixed_precision=args.mixed)
+        f = np.ones(n_cpu)
+        ur = np.zeros(n_cpu)
 
         def cpu_cycles(threads, cycles):
             O.set_num_threads(threads)
@@ -309,21 +331,29 @@ def main():
         cpu_s = samples[len(samples) // 2]
         O.set_num_threads(1)
         O.drop_transposes()
-        step()                                       # u = one cycle from zero again (the PCG run above reused u)
-        fence()
-        ug = B.parvec_to_numpy(u)
+        L.hypre_ParVectorSetZeros(u1)                # one cycle from zero again (the PCG run above reused u)
+        L.HYPRE_BoomerAMGSolve(s1, A1, b1, u1)
+        L.hypre_SyncComputeStream()
+        B.check()
+        ug = B.parvec_to_numpy(u1)
         parity = float(np.max(np.abs(ug - ur)) / np.max(np.abs(ur)))
-        cpu = {"value": nglob / cpu_s, "unit": "DOF/s", "cores": cores, "kind": "port",
-               "sample": "median of %d samples of %d full V(1,1) cycles of the same %d^3 hierarchy (oracle/oracle.c, "
+        which = "the same %d^3 hierarchy" % n1 if world == 1 else \
+            "the per-GPU block of the job (%d^3, set up as a single-rank hierarchy on rank 0; the job is %d such blocks)" % (n1, world)
+        cpu = {"value": n_cpu / cpu_s, "unit": "DOF/s", "cores": cores, "kind": "port",
+               "sample": "median of %d samples of %d full V(1,1) cycles of %s (oracle/oracle.c, "
                          "OpenMP row loops, %d threads, not pinned: OMP_PROC_BIND=%s, the host share is a CFS quota)"
-                         % (len(samples), 2 * args.cpu_cycles if cores > 1 else args.cpu_cycles, n1, cores,
+                         % (len(samples), 2 * args.cpu_cycles if cores > 1 else args.cpu_cycles, which, cores,
                             os.environ.get("OMP_PROC_BIND", "unset")),
-               "samples_DOF_per_s": [nglob / t for t in samples],
-               "single_thread_value": nglob / cpu_1,
+               "samples_DOF_per_s": [n_cpu / t for t in samples],
+               "single_thread_value": n_cpu / cpu_1,
                # the reference itself cannot run on the GPU box; what it did in the survey's container (8 cores), and the
                # port timed beside it there (tools/cpu_baseline_check.py -> profiles/r02_cpu_port_vs_reference_*.json)
                "reference_cpu_survey_container": REFERENCE_CPU_SURVEY,
                "gpu_vs_cpu_cycle_rel_max_diff": parity}
+        if world > 1:
+            L.HYPRE_BoomerAMGDestroy(s1)
+            L.hypre_ParCSRMatrixDestroy(A1)
+            B.check()
 
     # parity gate: a fast cycle whose result differs from the oracle's is not a result
     parity_failed = bool(cpu is not None and not (cpu["gpu_vs_cpu_cycle_rel_max_diff"] <= PARITY_TOL))

@@ -22,6 +22,12 @@ struct AmgPrivate
    // between its home vector and this one instead of copying back.
    std::vector<double *> u_alt;     // [num_levels], device
    std::vector<int>      u_alt_len;
+   // diagonal of a level's operator for the sweeps that have no smoother-diagonal vector (relax 0, 17, Jacobi without l1):
+   // one buffer per level, owned by this solver, so that a recorded coarse-tail graph never points into scratch that
+   // another solver's larger level may reallocate
+   std::vector<double *> diag_buf;  // [num_levels], device, allocated at the first cycle that needs it
+   std::vector<int>      diag_len;
+   double *level_diag(int level, int n);
 
    // mixed precision: fp64 residual and correction of the outer solve loop (a cycle on fp32-rounded operators applied
    // to a non-zero iterate must work on the error equation, or the iteration converges to the rounded system's solution)

@@ -120,7 +120,21 @@ struct SpmvPlan
    int             xs_tiles = 0;       // tiles with a piece list
    int             xs_max_units = 0;   // longest staged copy of any tile, in 2-column units
    int             xs_launch_units = 0;  // what a launch stages at most (tiles above it gather): sizes the launch's LDS
+   // Staleness watch.  The x-staged kernel never reads the column array and the mixed-precision kernels never read the
+   // fp64 values: a plan that outlived its matrix (the caller freed it with its own hypre_CSRMatrixDestroy and a new
+   // matrix of the same shape landed on the same addresses) would give a wrong product silently.  So the plan keeps a
+   // fingerprint per tile (two entries of the column array), every launch compares it — and Ai[first row] against the
+   // tile table, and one fp32 value against its fp64 original — for 12 bytes per 20 KB tile, and a mismatch raises
+   // the flag: a word of pinned host memory the host reads without synchronising (get_plan drops a flagged plan and
+   // raises HYPRE_ERROR_GENERIC; a synchronous public product then repeats itself with a fresh plan).
+   int            *d_tile_fp = nullptr;  // [num_tiles]
+   int            *h_stale = nullptr;    // pinned, mapped
+   int            *d_stale = nullptr;    // the same word as the device sees it
 };
+void bump_plan_generation();
+unsigned long long plan_generation();    // bumped whenever a plan (or a colour plan) is freed: recorded graphs watch it
+bool plan_is_stale(const hypre_CSRMatrix *A);   // the plan of A, if one exists, was flagged by a kernel
+void launch_build_fp(const HYPRE_Int *Aj, int nnz, int num_tiles, int *fp, hipStream_t s);
 SpmvPlan *get_plan(hypre_CSRMatrix *A);
 hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A);   // device CSR of {a_ij : j < i}, cached in A's plan
 void      drop_plan(hypre_CSRMatrix *A);
@@ -159,6 +173,8 @@ struct SpmvArgs
    int                  gather_t;    // x gathers paired with consecutive entries per wave (columns transposed through LDS)
    int                  xcd_map;     // tile -> XCD placement: 0 dispatch order, C > 0 chunks of C tiles, < 0 contiguous eighths
    const int           *tile_perm;   // workgroup -> tile table (overrides xcd_map), or null
+   const int           *tile_fp;     // per-tile fingerprint of the column array the plan was built from, or null
+   int                 *stale;       // raised (system scope) by a tile whose fingerprint / row pointer / fp32 value disagrees
    const int           *rowmap;      // epilogue row indirection (multicolour sweeps: row r of the matrix is row rowmap[r] of
                                      // the vectors b, d, x, y, marker), or null
    int                  variant;     // 0: x gathered through the cache; 2: x staged through LDS from the plan's chunk lists

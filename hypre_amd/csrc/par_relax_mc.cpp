@@ -176,7 +176,7 @@ void drop_mc_plan(const hypre_CSRMatrix *A)
 {
    auto &t = mc_table();
    auto it = t.find(A);
-   if (it != t.end()) { free_mc(it->second); t.erase(it); }
+   if (it != t.end()) { free_mc(it->second); t.erase(it); bump_plan_generation(); }
 }
 }  // namespace hamd
 

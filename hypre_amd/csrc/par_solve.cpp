@@ -41,11 +41,25 @@ void AmgPrivate::release_device()
    graph_level = -1;
    for (double *p : u_alt) { if (p) { hypre_Free(p, HYPRE_MEMORY_DEVICE); } }
    u_alt.clear(); u_alt_len.clear();
+   for (double *p : diag_buf) { if (p) { hypre_Free(p, HYPRE_MEMORY_DEVICE); } }
+   diag_buf.clear(); diag_len.clear();
    if (d_coarse_lu) { hypre_Free(d_coarse_lu, HYPRE_MEMORY_DEVICE); d_coarse_lu = nullptr; }
    if (d_coarse_rhs) { hypre_Free(d_coarse_rhs, HYPRE_MEMORY_DEVICE); d_coarse_rhs = nullptr; }
    coarse_n = 0;
    if (mp_r) { hypre_ParVectorDestroy(mp_r); mp_r = nullptr; }
    if (mp_e) { hypre_ParVectorDestroy(mp_e); mp_e = nullptr; }
+}
+
+double *AmgPrivate::level_diag(int level, int n)
+{
+   if ((int) diag_buf.size() <= level) { diag_buf.resize((size_t) level + 1, nullptr); diag_len.resize((size_t) level + 1, 0); }
+   if (diag_len[(size_t) level] < n || !diag_buf[(size_t) level])
+   {
+      if (diag_buf[(size_t) level]) { hypre_Free(diag_buf[(size_t) level], HYPRE_MEMORY_DEVICE); drop_graph(); graph_state = 0; }
+      diag_buf[(size_t) level] = hypre_TAlloc(double, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
+      diag_len[(size_t) level] = n;
+   }
+   return diag_buf[(size_t) level];
 }
 
 // ---------------------------------------------------------------------------
@@ -463,7 +477,9 @@ unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, h
       mix((unsigned long long) (uintptr_t) F[l]->local_vector->data); mix((unsigned long long) (uintptr_t) U[l]->local_vector->data);
       mix((unsigned long long) (uintptr_t) (d->l1_norms[l] ? d->l1_norms[l]->data : nullptr));
       mix((unsigned long long) (uintptr_t) (l < (int) pv->u_alt.size() ? pv->u_alt[(size_t) l] : nullptr));
+      mix((unsigned long long) (uintptr_t) (l < (int) pv->diag_buf.size() ? pv->diag_buf[(size_t) l] : nullptr));
    }
+   mix(plan_generation());            // a plan dropped or rebuilt anywhere (the recorded kernels point into plans' tables)
    SpmvArgs a{};
    spmv_default_flags(a);
    mix((unsigned long long) a.variant); mix((unsigned long long) a.gather_t); mix((unsigned long long) a.xcd_map);
@@ -625,7 +641,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
             const double *dg = l1;
             if (relax_type == 0 || !dg)
             {
-               double *dd = diag_scratch((size_t) std::max(n, 1));
+               double *dd = pv->level_diag(level, n);
                launch_diag_first(A[level]->diag->i, A[level]->diag->data, dd, n, s);
                dg = dd;
             }
@@ -673,7 +689,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
             // the F points; one plain Jacobi sweep on the coarsest level, which has no C/F splitting
             static const int fcf[3] = {-1, 1, -1};
             const int npass = (level == L - 1) ? 1 : 3;
-            double *dd = diag_scratch((size_t) std::max(n, 1));
+            double *dd = pv->level_diag(level, n);
             launch_diag_first(A[level]->diag->i, A[level]->diag->data, dd, n, s);
             for (int pss = 0; pss < npass; pss++)
             {

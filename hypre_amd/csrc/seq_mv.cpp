@@ -133,9 +133,41 @@ static std::unordered_map<const hypre_CSRMatrix *, SpmvPlan *> &plan_table()
    return t;
 }
 
+static unsigned long long g_plan_generation = 1;
+unsigned long long plan_generation() { return g_plan_generation; }
+void bump_plan_generation() { g_plan_generation++; }
+
+// words of pinned, device-visible host memory for the plans' staleness flags, handed out from pages of 1024
+namespace {
+struct StaleSlots
+{
+   std::vector<int *> pages;
+   std::vector<int *> free_list;
+   int used_in_last = 1024;
+   int *take()
+   {
+      if (!free_list.empty()) { int *p = free_list.back(); free_list.pop_back(); *p = 0; return p; }
+      if (used_in_last >= 1024)
+      {
+         int *page = nullptr;
+         if (hipHostMalloc((void **) &page, sizeof(int) * 1024, hipHostMallocMapped) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+         memset(page, 0, sizeof(int) * 1024);
+         pages.push_back(page);
+         used_in_last = 0;
+      }
+      return pages.back() + used_in_last++;
+   }
+   void give(int *p) { if (p) { free_list.push_back(p); } }
+};
+StaleSlots &stale_slots() { static StaleSlots s; return s; }
+}  // namespace
+
 static void free_plan(SpmvPlan *p)
 {
    if (!p) { return; }
+   g_plan_generation++;
+   if (p->d_tile_fp) { HIP_CHECK(hipFree(p->d_tile_fp)); }
+   stale_slots().give(p->h_stale);
    if (p->d_tile_row) { HIP_CHECK(hipFree(p->d_tile_row)); }
    if (p->d_tile_k) { HIP_CHECK(hipFree(p->d_tile_k)); }
    if (p->d_tile_perm) { HIP_CHECK(hipFree(p->d_tile_perm)); }
@@ -171,10 +203,19 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
    if (it != t.end())
    {
       SpmvPlan *p = it->second;
-      if (p->i == A->i && p->j == A->j && p->a == A->data && p->nnz == A->num_nonzeros &&
+      const bool flagged = p->h_stale && __atomic_load_n(p->h_stale, __ATOMIC_RELAXED) != 0;
+      if (!flagged && p->i == A->i && p->j == A->j && p->a == A->data && p->nnz == A->num_nonzeros &&
           p->num_rows == A->num_rows && p->num_cols == A->num_cols)
       {
          return p;
+      }
+      if (flagged)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "a kernel found its SpMV plan out of date (the matrix at this address is not the one the plan "
+                                                "was built for, or its values changed without hypre_amd_CSRMatrixInvalidatePlan): the products "
+                                                "since then are wrong; the plan is rebuilt");
+         drop_gs_schedule(A);
+         drop_mc_plan(A);
       }
       free_plan(p);
       t.erase(it);
@@ -196,6 +237,19 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
          p->prod_elems = SPMV_TILE + ((p->max_row_nnz + 3) & ~3) + 8;
          launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
          p->max_tile_rows = device_max_row_nnz(p->d_tile_row, p->num_tiles, s);     // max over tiles of tile_row[b+1] - tile_row[b]
+         // staleness watch (see SpmvPlan)
+         p->h_stale = stale_slots().take();
+         if (p->h_stale && hipHostGetDevicePointer((void **) &p->d_stale, p->h_stale, 0) != hipSuccess) { (void) hipGetLastError(); p->d_stale = nullptr; }
+         if (!p->d_stale)
+         {
+            // no pinned word to be had: the kernels still need somewhere to write (nobody reads it)
+            static int *sink = nullptr;
+            if (!sink) { HIP_CHECK(hipMalloc((void **) &sink, sizeof(int))); HIP_CHECK(hipMemsetAsync(sink, 0, sizeof(int), s)); }
+            p->d_stale = sink;
+            stale_slots().give(p->h_stale); p->h_stale = nullptr;
+         }
+         HIP_CHECK(hipMalloc((void **) &p->d_tile_fp, sizeof(int) * (size_t) p->num_tiles));
+         launch_build_fp(A->j, A->num_nonzeros, p->num_tiles, p->d_tile_fp, s);
          build_band_placement(p, A, s);
          if (spmv_variant().variant == 2)
          {
@@ -251,6 +305,13 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
    }
    t[A] = p;
    return p;
+}
+
+bool plan_is_stale(const hypre_CSRMatrix *A)
+{
+   auto &t = plan_table();
+   auto it = t.find(A);
+   return it != t.end() && it->second->h_stale && __atomic_load_n(it->second->h_stale, __ATOMIC_RELAXED) != 0;
 }
 
 // fp32 copy of a device matrix's values (mixed precision), converted once and cached in the plan
@@ -772,6 +833,21 @@ HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypr
       }
       spmv_device_core(alpha, M, xd + (size_t) v * x->vecstride, beta, b->data + (size_t) v * b->vecstride,
                        y->data + (size_t) v * y->vecstride, HYPRE_SPMV_FILL_WHOLE);
+   }
+   if (handle().sync_compute && !(x->data == y->data))
+   {
+      // synchronous public product: a plan the kernels found out of date is rebuilt (get_plan raises the error) and the
+      // product repeated, so that what the caller reads is right.  (Without the end-of-call synchronisation the flag is
+      // seen by the next call that asks for the plan.)
+      HIP_CHECK(hipStreamSynchronize(stream()));
+      if (plan_is_stale(M))
+      {
+         for (HYPRE_Int v = 0; v < x->num_vectors; v++)
+         {
+            spmv_device_core(alpha, M, xd + (size_t) v * x->vecstride, beta, b->data + (size_t) v * b->vecstride,
+                             y->data + (size_t) v * y->vecstride, HYPRE_SPMV_FILL_WHOLE);
+         }
+      }
    }
    if (x_tmp) { HIP_CHECK(hipStreamSynchronize(stream())); hypre_SeqVectorDestroy(x_tmp); }
    maybe_sync();

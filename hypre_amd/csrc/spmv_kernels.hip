@@ -567,8 +567,24 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    const int r0 = tile_row[tile], r1 = tile_row[tile + 1];
    const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
    const int xc = xs_cnt[tile];                // (covered units << 8) | pieces
-   asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aa32) : "memory");
+   // staleness watch (SpmvPlan): two entries of the column array this kernel otherwise never reads, against the
+   // fingerprint the plan took of them; in mixed precision one fp64 value against its fp32 copy.  Wave-uniform
+   // addresses: they ride in the scalar batch above.
+   // (unconditional loads: the launch always hands over a fingerprint table and a flag word — a test on a pointer here
+   // puts a scalar round trip of its own in front of the batch)
+   const int qs0 = min(ka + 5, p.last_quad), qs1 = min(ka + 1029, p.last_quad);
+   const int fp_plan = p.tile_fp[tile];
+   const int fc0 = p.Aj[qs0], fc1 = p.Aj[qs1];
+   double fv64 = 0.0;
+   float  fv32 = 0.0f;
+   if (F32) { fv64 = p.Aa[qs0]; fv32 = p.Aa32[qs0]; }
+   asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aa32), "s"(p.Aj), "s"(p.tile_fp) : "memory");
    if (r1 <= r0) { return; }
+   {
+      bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1);
+      if (F32) { off = off || ((float) fv64 != fv32); }
+      if (off && tid == 0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+   }
 #if !XS_EARLY_STREAM
    if (F32)
    {
@@ -640,6 +656,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    // lanes past the tile's rows repeat its last pointer into the last slot
 #pragma unroll
    for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
+   if (tid == 0 && rpv[0] != k0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // the tile table is not this matrix's
    __syncthreads();
 
    // "gathers": eight LDS reads per lane.  Entries of the window that belong to a neighbouring tile carry that tile's
@@ -983,6 +1000,21 @@ __global__ void max_row_nnz_kernel(const int *__restrict__ Ai, int num_rows, int
    if ((threadIdx.x & 63) == 0) { atomicMax(out, m); }
 }
 
+// per tile: two entries of the column array (the positions spmv_xs_kernel samples), mixed
+__global__ void build_fp_kernel(const HYPRE_Int *__restrict__ Aj, int last_quad, int num_tiles, int *__restrict__ fp)
+{
+   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+   if (t >= num_tiles) { return; }
+   const int ka = t * SPMV_TILE;
+   const int c0 = Aj[min(ka + 5, last_quad)], c1 = Aj[min(ka + 1029, last_quad)];
+   fp[t] = (int) ((unsigned) c0 * 2654435761u + (unsigned) c1);
+}
+void launch_build_fp(const HYPRE_Int *Aj, int nnz, int num_tiles, int *fp, hipStream_t s)
+{
+   if (num_tiles <= 0) { return; }
+   hipLaunchKernelGGL(build_fp_kernel, dim3((num_tiles + 255) / 256), dim3(256), 0, s, Aj, (nnz > 0 ? nnz - 1 : 0) & ~3, num_tiles, fp);
+}
+
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
                         int *d_tile_k, hipStream_t s)
 {
@@ -1117,6 +1149,8 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    a.last_quad = (plan->nnz > 0 ? (int) (plan->nnz - 1) : 0) & ~3;
    a.x_last = plan->num_cols > 0 ? plan->num_cols - 1 : 0;
    a.tile_perm = plan->d_tile_perm;
+   a.tile_fp = plan->d_tile_fp;
+   a.stale = plan->d_stale;
    if (handle().fp32_values && !a.Aa32 && plan->nnz > 0)
    {
       // mixed precision: matrix values stream as fp32 (converted once per matrix), vectors and

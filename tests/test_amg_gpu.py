@@ -686,3 +686,60 @@ def test_device_setup_on_an_unstructured_matrix(gpu_lib, tmp_path, relax_type):
             assert np.array_equal(a, b)
     assert solves[0][0] == solves[1][0] < 0.5
     assert np.array_equal(solves[0][1], solves[1][1])
+
+
+def test_graphs_of_two_hierarchies_keep_their_own_diagonal_buffers(gpu_lib, oracle):
+    """Weighted Jacobi (relax 0) divides by a diagonal the sweep extracts into a work buffer.  That buffer used to be one
+    process-wide, grow-only scratch: a second, larger hierarchy reallocated it under the first one's recorded coarse-tail
+    graph.  Now every solver owns a buffer per level: cycles of a small and of a large hierarchy, interleaved, with both
+    graphs recorded, each give the oracle's result."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    sets = []
+    for n in ((24, 24, 24), (44, 43, 42)):
+        opt, A, s = _setup(lib, n=n, coarsen_type=8, relax_type=0, relax_wt=0.7)
+        lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+        lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+        lib.hypre_amd_BoomerAMGSetGraphThreshold(s, 1000000)        # every level below the finest belongs to the tail
+        sets.append((n[0] * n[1] * n[2], A, s, oracle.amg_from_solvers([s])))
+    lev, nodes = C.c_int(), C.c_int()
+    for k in range(5):
+        for nn, A, s, amg in sets:                       # small, large, small, large ...
+            f = rand_vector(nn, 3 + k)
+            du, df = B.parvec_from_numpy(np.zeros(nn)), B.parvec_from_numpy(f)
+            lib.hypre_ParVectorSetZeros(du)
+            lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+            B.check()
+            ur = np.zeros(nn)
+            amg.solve(f, ur, tol=0.0, max_iter=1, u_all_zeros=True)
+            assert np.max(np.abs(B.parvec_to_numpy(du) - ur)) <= 1e-11 * np.max(np.abs(ur)), (nn, k)
+    for nn, A, s, amg in sets:
+        lib.hypre_amd_BoomerAMGGetGraphInfo(s, C.byref(lev), C.byref(nodes))
+        assert lev.value >= 1 and nodes.value > 5
+        lib.HYPRE_BoomerAMGDestroy(s)
+    B.check()
+
+
+def test_values_changed_under_a_mixed_precision_hierarchy_are_noticed(gpu_lib):
+    """Mixed precision streams an fp32 copy of the matrix values cached in the plan.  Values changed in place without
+    hypre_amd_CSRMatrixInvalidatePlan leave that copy behind; every tile compares one fp64 value with its fp32 copy, so
+    the next solve raises HYPRE_ERROR_GENERIC instead of silently preconditioning with the old operator."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    opt, A, s = _setup(lib, n=(30, 30, 30), coarsen_type=8, relax_type=18)
+    lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 2)
+    n = 27000
+    du, df = B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(np.ones(n))
+    lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+    lib.HYPRE_ClearAllErrors()                            # (max_iter reached: expected)
+    d = A.contents.diag.contents
+    vals = B.fetch(d.data, d.num_nonzeros, np.float64, d.memory_location) * 3.0
+    lib.hypre_Memcpy(C.cast(d.data, C.c_void_p), vals.ctypes.data_as(C.c_void_p), vals.nbytes, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+    lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+    lib.hypre_SyncComputeStream()
+    lib.HYPRE_BoomerAMGSolve(s, A, df, du)                # (the flag is read when the plan is next asked for)
+    assert lib.HYPRE_GetError() & 1           # HYPRE_ERROR_GENERIC: "a kernel found its SpMV plan out of date"
+    lib.HYPRE_BoomerAMGDestroy(s)
+    lib.HYPRE_ClearAllErrors()

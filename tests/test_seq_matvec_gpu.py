@@ -292,3 +292,61 @@ def test_comm_pkg_update_vec_starts(gpu_lib):
     assert [pkg.send_map_starts[i] for i in range(3)] == [0, 2, 5]
     assert [pkg.recv_vec_starts[i] for i in range(3)] == [0, 3, 4]
     assert [pkg.send_map_elmts[i] for i in range(5)] == list(elmts)
+
+
+def _overwrite(lib, dA, A):
+    """the device arrays of dA now hold A (same shape, same entry count): what a caller does who frees a matrix with
+    hypre's own hypre_CSRMatrixDestroy — which knows nothing of this library's plans — and builds the next one of the
+    same size, which lands on the same addresses"""
+    import ctypes as C
+    from hypre_amd import binding as B
+    s = dA.contents
+    ii = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    jj = np.ascontiguousarray(A.indices, dtype=np.int32)
+    aa = np.ascontiguousarray(A.data, dtype=np.float64)
+    assert len(ii) == s.num_rows + 1 and len(jj) == s.num_nonzeros
+    for dst, src in ((s.i, ii), (s.j, jj), (s.data, aa)):
+        lib.hypre_Memcpy(C.cast(dst, C.c_void_p), src.ctypes.data_as(C.c_void_p), src.nbytes, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+
+
+@pytest.mark.parametrize("how", ["columns", "rows"])
+def test_a_plan_that_outlived_its_matrix_is_found_out(gpu_lib, oracle, how):
+    """The x-staged kernel reads per-entry indices from its plan, not the column array: a plan that survives its matrix
+    (same struct address, same array addresses, same sizes: the identity test of get_plan passes) would multiply by the
+    OLD pattern.  Every tile therefore compares two entries of the column array with the fingerprint the plan took and
+    its first row pointer with the tile table; a mismatch raises a flag in pinned memory, the synchronous public product
+    raises HYPRE_ERROR_GENERIC, rebuilds the plan and repeats itself: the caller reads the right product."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A1 = random_csr(9000, 9000, 6, 40, seed=11)
+    if how == "columns":
+        # same row pointers, other columns
+        perm = np.random.default_rng(5).permutation(9000)
+        A2 = sp.csr_matrix((A1.data * 0.5, perm[A1.indices].astype(np.int32), A1.indptr), shape=A1.shape)
+    else:
+        # other row lengths (the rows in reverse order), same entry count
+        A2 = sp.csr_matrix(A1[::-1, :])
+    x = rand_vector(9000, 3)
+    dA = B.csr_from_scipy(A1)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(9000))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A1 @ x) <= _bound(A1, x, 1.0, 0.0, x))
+    _overwrite(lib, dA, A2)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    with pytest.raises(B.HypreAmdError):
+        B.check()                         # the stale plan was noticed and reported ...
+    lib.HYPRE_ClearAllErrors()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A2 @ x) <= _bound(A2, x, 1.0, 0.0, x))      # ... and the product is A2's
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()                             # the rebuilt plan is A2's: no complaint
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A2 @ x) <= _bound(A2, x, 1.0, 0.0, x))
+    # the announced way (INTEGRATION.md): tell the library, and nothing is raised
+    _overwrite(lib, dA, A1)
+    lib.hypre_amd_CSRMatrixInvalidatePlan(dA)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A1 @ x) <= _bound(A1, x, 1.0, 0.0, x))
+    for o in (dx, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
