@@ -200,19 +200,41 @@ def main():
     fence()
     B.check()
     L.hypre_amd_CommCounters(None, None, 1)
+    L.hypre_amd_ByteCounters(None, None, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    b_csr, b_str = C.c_double(), C.c_double()
+    L.hypre_amd_ByteCounters(C.byref(b_csr), C.byref(b_str), 0)      # this rank's launches of the timed cycles
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if transport == "rccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     B.check()
-    n_exch, n_allr = C.c_longlong(), C.c_longlong()
+    n_exch, n_allr, x_bytes, r_bytes = C.c_longlong(), C.c_longlong(), C.c_longlong(), C.c_longlong()
     L.hypre_amd_CommCounters(C.byref(n_exch), C.byref(n_allr), 0)
+    L.hypre_amd_CommBytes(C.byref(x_bytes), C.byref(r_bytes))
+    # the exchanges of one cycle level by level, from the hierarchy's communication packages (this rank's share): a
+    # distributed level exchanges u twice through A's package (residual, post-smoothing), the coarse correction once
+    # through P's (prolongation) and the restricted residual's off-rank part once through P's in reverse
+    exchange_plan = []
+    if world > 1:
+        nlv = L.hypre_amd_BoomerAMGGetNumLevels(s)
+        rep = int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s))
+        ns, se, nr, re_ = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        for l in range(nlv - 1 if rep < 0 else min(rep, nlv - 1)):
+            Al = C.cast(L.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
+            Pl = C.cast(L.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
+            L.hypre_amd_ParCSRMatrixHaloInfo(Al, C.byref(ns), C.byref(se), C.byref(nr), C.byref(re_))
+            row = {"level": l, "local_rows": int(Al.contents.diag.contents.num_rows), "A_neighbours": ns.value,
+                   "A_send_bytes": 8 * se.value}
+            L.hypre_amd_ParCSRMatrixHaloInfo(Pl, C.byref(ns), C.byref(se), C.byref(nr), C.byref(re_))
+            row.update(P_neighbours=ns.value, P_send_bytes=8 * se.value, PT_send_bytes=8 * re_.value,
+                       exchanges=4, bytes_sent=2 * row["A_send_bytes"] + 8 * se.value + 8 * re_.value)
+            exchange_plan.append(row)
     g_level, g_nodes = C.c_int(), C.c_int()
     L.hypre_amd_BoomerAMGGetGraphInfo(s, C.byref(g_level), C.byref(g_nodes))
     ms_per_step = 1e3 * elapsed / args.steps
@@ -233,7 +255,14 @@ def main():
     spmv_ms = L.hypre_amd_EventTimerStopMs() / reps
     spmv_bytes = nnz * 12 + (nloc + 1) * 4 + nloc * 8 + nloc * 8
     spmv_gbs = spmv_bytes / spmv_ms / 1e6
-    cycle_bytes = L.hypre_amd_BoomerAMGCycleBytes(s)
+    # Bytes of one cycle on this rank (every rank carries the same share: weak scaling): counted by the launch wrappers
+    # over the timed cycles, so the figure follows the smoother, the value width and the levels actually run (two-stage
+    # GS: residual pass + inner passes over the strict lower triangle; fp32 values: 4 instead of 8 bytes per entry).
+    # csr = SURVEY 8(d)'s CSR count, streamed = what the kernels are designed to read (8 + 2 / 4 + 2 bytes per entry of the
+    # x-staged kernel).  The setup's closed formula (l1-Jacobi V(1,1) on CSR) stays beside them as a cross-check.
+    cycle_bytes = b_csr.value / args.steps
+    cycle_streamed = b_str.value / args.steps
+    cycle_formula = L.hypre_amd_BoomerAMGCycleBytes(s)
     B.check()
 
     # ---- the caller of the path: AMG-preconditioned CG to 1e-8 (BASELINE configs solve with it) ----
@@ -265,20 +294,27 @@ def main():
     except Exception as exc:      # noqa: BLE001 - the headline metric above stands on its own
         pcg_info = {"error": str(exc)}
         L.HYPRE_ClearAllErrors()
-    # HBM traffic per launch cannot be read from inside the process; it is taken from the committed
-    # rocprofv3 --pmc pass over this same kernel and matrix (profiles/), when the workload matches.
+    # HBM traffic per launch cannot be read from inside the process (PMC counters need rocprofv3 around it): the figure is
+    # taken from the newest committed --pmc pass over this same kernel and matrix (profiles/, tools/pmc_levels.sh) when
+    # the workload matches, and labelled as what it is: a profile-derived number of an earlier run of this kernel — with
+    # the hash of the kernel source it was taken from, so that a changed kernel shows
     traffic = None
     traffic_src = None
     try:
-        # newest per-level counter summary of the kernel in use (tools/pmc_levels.sh + pmc_levels_summary.py), level 0
-        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r02_levels_xs") and f.endswith("_summary.json"))
+        import hashlib
+        with open(os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip"), "rb") as fh:
+            kernel_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "levels_xs" in f and f.endswith("_summary.json"))
         if pmc_files:
             with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as fh:
-                pmc = json.load(fh)["levels"]["0"]
+                summary = json.load(fh)
+            pmc = summary["levels"]["0"]
             if int(pmc.get("algorithmic_bytes_per_launch", -1)) == int(spmv_bytes) and "hbm_traffic_bytes_per_launch" in pmc:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
-                traffic_src = "profiles/" + pmc_files[-1]
-    except OSError:
+                same = summary.get("kernel_source_sha16") == kernel_sha
+                traffic_src = "profile-derived, not of this run: profiles/%s (%s)" % (
+                    pmc_files[-1], "same kernel source" if same else "taken from an EARLIER version of the kernel source")
+    except (OSError, KeyError, ValueError):
         pass
 
     # ---- CPU baseline: the oracle's V-cycle on the same hierarchy, host cores ------------
@@ -378,6 +414,8 @@ def main():
                        "transport": transport if world > 1 else "none",
                        "replicated_from_level": int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)),
                        "halo_exchanges_per_cycle": n_exch.value / args.steps, "allreduces_per_cycle": n_allr.value / args.steps,
+                       "halo_bytes_sent_per_cycle": x_bytes.value / args.steps, "allreduce_bytes_per_cycle": r_bytes.value / args.steps,
+                       "exchanges_by_level": exchange_plan,
                        "coarse_tail_graph_from_level": g_level.value, "coarse_tail_graph_nodes": g_nodes.value,
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s, "matrix_generation_seconds": matrix_s},
@@ -386,7 +424,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},
             "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
-                       "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS},
+                       "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS,
+                       "streamed_bytes": cycle_streamed, "streamed_GBps": cycle_streamed / ms_per_step / 1e6,
+                       "streamed_frac_of_hbm_peak": cycle_streamed / ms_per_step / 1e6 / HBM_PEAK_GBS,
+                       "per": "GPU (rank 0's launches; every rank carries the same share)",
+                       "counted_by": "the library's launch wrappers over the timed cycles (hypre_amd_ByteCounters)",
+                       "jacobi_csr_formula_bytes": cycle_formula},
             "pcg": pcg_info,
             "cpu_baseline": cpu,
         }

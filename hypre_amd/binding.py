@@ -136,6 +136,7 @@ PROTOTYPES = {
     "hypre_SetSyncCudaCompute": (Int, [Int]),
     "hypre_GetSyncCudaCompute": (Int, [IntP]),
     "hypre_SyncComputeStream": (Int, []),
+    "hypre_amd_ByteCounters": (Int, [C.POINTER(C.c_double), C.POINTER(C.c_double), Int]),
     "hypre_amd_ComputeStream": (C.c_void_p, []),
     "hypre_amd_CommStream": (C.c_void_p, []),
     "hypre_amd_EventTimerStart": (Int, []),
@@ -161,6 +162,8 @@ PROTOTYPES = {
     "hypre_amd_CommSelfTest": (Int, [Int, Int]),
     "hypre_MPI_Barrier": (Int, [Int]),
     "hypre_amd_CommCounters": (Int, [BigIntP, BigIntP, Int]),
+    "hypre_amd_CommBytes": (Int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "hypre_amd_ParCSRMatrixHaloInfo": (Int, [ParCSRp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     # seq_mv
     "hypre_CSRMatrixCreate": (CSRp, [Int, Int, Int]),
     "hypre_CSRMatrixInitialize_v2": (Int, [CSRp, Int, Int]),

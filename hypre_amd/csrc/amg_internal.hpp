@@ -47,6 +47,7 @@ struct AmgPrivate
    hipGraphExec_t graph_exec   = nullptr;
    std::vector<double *> graph_cur;           // where every tail level's iterate lives when the sub-cycle is over
    double         graph_op_count = 0.0;       // what the sub-cycle adds to cycle_op_count
+   double         graph_bytes_csr = 0.0, graph_bytes_stream = 0.0;   // ... and to the byte counters (Handle::bytes_*)
    int            graph_launches = 0;         // kernel nodes of the graph (reported by the benchmark)
    void drop_graph();
 
@@ -67,7 +68,13 @@ struct AmgPrivate
    // their halo exchanges are pure latency.  Setup gathers these operators onto every rank as a
    // single-rank hierarchy; the cycle then gathers the right-hand side of level tail_level with ONE
    // all-reduce, runs the rest of the V-cycle redundantly and locally, and keeps its own slice.
-   int               replicate_rows = 16384;   // global row count at or below which a level is replicated (0: off)
+   // Global row count at or below which a level is replicated (0: off).  What a replicated level costs a rank grows with
+   // the level's GLOBAL size (every rank sweeps all of it), what a distributed one costs is four latency-bound exchanges
+   // (~30 us each over xGMI) whatever its size: with ~90 entries per row the two meet around 100 000 global rows (six
+   // passes of 100 000 x 90 entries at ~5 TB/s = 130 us against 4 x 30 us of exchanges plus the local share), and below
+   // ~25 000 rows a level is launch-bound either way.  At 8 x 256^3 that replicates from level 4 (66 320 rows): 16
+   // exchanges + 1 all-reduce per cycle instead of 20; HYPRE_AMD_REPLICATE_ROWS / ..SetReplicateThreshold change it.
+   int               replicate_rows = [] { const char *e = getenv("HYPRE_AMD_REPLICATE_ROWS"); return e ? atoi(e) : 100000; }();
    hypre_ParAMGData *tail = nullptr;
    int               tail_level = -1;
    double           *d_tail_f = nullptr;      // global right-hand side of level tail_level (device)

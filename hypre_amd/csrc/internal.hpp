@@ -64,8 +64,17 @@ struct Handle
    // mixed precision (set by the cycle from the solver): SpMV-class kernels read fp32 copies
    // of the matrix values
    bool                  fp32_values   = false;
+   // Algorithmic bytes of everything launched since the last reset (hypre_amd_ByteCounters): what SURVEY 8(d) counts —
+   // CSR entries at 4 bytes of index + the value width in use, row pointers, every vector operand once — and, beside it,
+   // what the kernels are designed to stream (the x-staged kernel reads a 16-bit index and no column array).  Filled
+   // by the launch wrappers, so the numbers follow the smoother, the precision and the rank's share actually run;
+   // a replayed graph adds what its recording added.
+   double                bytes_csr     = 0.0;
+   double                bytes_stream  = 0.0;
 };
 Handle &handle();
+inline void account_bytes(double csr, double stream) { Handle &h = handle(); h.bytes_csr += csr; h.bytes_stream += stream; }
+inline void account_bytes(double b) { account_bytes(b, b); }
 const hypre_amd_CommOps *comm_ops(MPI_Comm comm);   // nullptr for an invalid handle
 bool    ensure_device();                 // lazily creates streams; false if no GPU
 int     host_cpu_share();                // cores this process may use: affinity mask cut by a cgroup CPU quota

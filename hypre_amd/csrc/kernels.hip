@@ -431,25 +431,26 @@ static inline int lin_grid(size_t n)
 }
 
 void launch_set(double *y, double v, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(set_kernel, dim3(vec_grid(n)), dim3(256), 0, s, y, v, n); }
+{ account_bytes(8.0 * n); if (n) hipLaunchKernelGGL(set_kernel, dim3(vec_grid(n)), dim3(256), 0, s, y, v, n); }
 void launch_copy(double *y, const double *x, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(copy_kernel, dim3(vec_grid(n)), dim3(256), 0, s, y, x, n); }
+{ account_bytes(16.0 * n); if (n) hipLaunchKernelGGL(copy_kernel, dim3(vec_grid(n)), dim3(256), 0, s, y, x, n); }
 void launch_scale(double *y, double a, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(scale_kernel, dim3(vec_grid(n)), dim3(256), 0, s, y, a, n); }
+{ account_bytes(16.0 * n); if (n) hipLaunchKernelGGL(scale_kernel, dim3(vec_grid(n)), dim3(256), 0, s, y, a, n); }
 void launch_scale_copy(double b, const double *x, double *y, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(scale_copy_kernel, dim3(vec_grid(n)), dim3(256), 0, s, b, x, y, n); }
+{ account_bytes(16.0 * n); if (n) hipLaunchKernelGGL(scale_copy_kernel, dim3(vec_grid(n)), dim3(256), 0, s, b, x, y, n); }
 void launch_axpy(double a, const double *x, double *y, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(axpy_kernel, dim3(vec_grid(n)), dim3(256), 0, s, a, x, y, n); }
+{ account_bytes(24.0 * n); if (n) hipLaunchKernelGGL(axpy_kernel, dim3(vec_grid(n)), dim3(256), 0, s, a, x, y, n); }
 void launch_axpyz(double a, const double *x, double b, const double *y, double *z, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(axpyz_kernel, dim3(vec_grid(n)), dim3(256), 0, s, a, x, b, y, z, n); }
+{ account_bytes(24.0 * n); if (n) hipLaunchKernelGGL(axpyz_kernel, dim3(vec_grid(n)), dim3(256), 0, s, a, x, b, y, z, n); }
 void launch_elmdivpy(const double *x, const double *d, double *y, const int *marker, int mval, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(elmdivpy_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, d, y, marker, mval, n); }
+{ account_bytes((32.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(elmdivpy_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, d, y, marker, mval, n); }
 void launch_scaled_div(double w, const double *f, const double *d, double *u, const int *marker, int mval, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(scaled_div_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, u, marker, mval, n); }
+{ account_bytes((24.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(scaled_div_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, u, marker, mval, n); }
 void launch_diagscale2(const double *diag, const double *x, double beta, double *y, double *z, int computeY, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(diagscale2_kernel, dim3(lin_grid(n)), dim3(256), 0, s, diag, x, beta, y, z, computeY, n); }
+{ account_bytes(40.0 * n); if (n) hipLaunchKernelGGL(diagscale2_kernel, dim3(lin_grid(n)), dim3(256), 0, s, diag, x, beta, y, z, computeY, n); }
 void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipStream_t s)
 {
+   account_bytes(16.0 * n);
    int nb = vec_grid(n);
    if (nb > DOT_BLOCKS) { nb = DOT_BLOCKS; }
    double *partial = reduce_scratch(DOT_BLOCKS + 16) + 16;
@@ -459,6 +460,7 @@ void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipSt
 void launch_pcg_update(double a, double na, const double *p, const double *sv, double *x, double *r, size_t n,
                        double *d_out, hipStream_t s)
 {
+   account_bytes(48.0 * n);
    int nb = vec_grid(n);
    if (nb > DOT_BLOCKS) { nb = DOT_BLOCKS; }
    double *partial = reduce_scratch(DOT_BLOCKS + 16) + 16;
@@ -466,21 +468,21 @@ void launch_pcg_update(double a, double na, const double *p, const double *sv, d
    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, s, partial, nb, d_out);
 }
 void launch_pcg_direction(double beta, const double *sv, double *p, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(pcg_direction_kernel, dim3(vec_grid(n)), dim3(256), 0, s, beta, sv, p, n); }
+{ account_bytes(24.0 * n); if (n) hipLaunchKernelGGL(pcg_direction_kernel, dim3(vec_grid(n)), dim3(256), 0, s, beta, sv, p, n); }
 void launch_count_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int n, int *cnt, hipStream_t s)
 { if (n > 0) hipLaunchKernelGGL(count_lower_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aj, n, cnt); }
 void launch_fill_lower(const HYPRE_Int *Ai, const HYPRE_Int *Aj, const double *Aa, const HYPRE_Int *Li, HYPRE_Int *Lj,
                        double *La, int n, hipStream_t s)
 { if (n > 0) hipLaunchKernelGGL(fill_lower_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aj, Aa, Li, Lj, La, n); }
 void launch_gather(const double *x, const int *idx, double *out, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, out, n); }
+{ account_bytes(20.0 * n); if (n) hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, idx, out, n); }
 void launch_scatter_add(const double *in, const int *idx, double *y, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(scatter_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, idx, y, n); }
+{ account_bytes(28.0 * n); if (n) hipLaunchKernelGGL(scatter_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, in, idx, y, n); }
 void launch_jacobi_update(const double *u_in, const double *r, const double *d, const int *marker, int mval,
                           double *u_out, size_t n, hipStream_t s)
-{ if (n) hipLaunchKernelGGL(jacobi_update_kernel, dim3(lin_grid(n)), dim3(256), 0, s, u_in, r, d, marker, mval, u_out, n); }
+{ account_bytes((32.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(jacobi_update_kernel, dim3(lin_grid(n)), dim3(256), 0, s, u_in, r, d, marker, mval, u_out, n); }
 void launch_diag_first(const int *Ai, const double *Aa, double *d, int n, hipStream_t s)
-{ if (n > 0) hipLaunchKernelGGL(diag_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aa, d, n); }
+{ account_bytes(20.0 * n); if (n > 0) hipLaunchKernelGGL(diag_first_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Ai, Aa, d, n); }
 void launch_coarse_solve(const double *lu, double *x, int n, hipStream_t s)
 { if (n > 0) hipLaunchKernelGGL(coarse_solve_kernel, dim3(1), dim3(64), 0, s, lu, x, n); }
 // A (nrows x ncols, device) -> Ti[ncols + 1], tj[nnz], ta[nnz] (device, allocated by the caller); Aa / ta may be null

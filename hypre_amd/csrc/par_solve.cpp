@@ -563,7 +563,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       }
    }
    bool arrived_down = false, capturing = false;
-   double op_count_at_capture = 0.0;
+   double op_count_at_capture = 0.0, csr_at_capture = 0.0, stream_at_capture = 0.0;
 
    while (not_finished)
    {
@@ -577,11 +577,12 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
             HIP_CHECK(hipGraphLaunch(pv->graph_exec, s));
             for (int l = gl; l < L; l++) { lv[(size_t) l].cur = pv->graph_cur[(size_t) (l - gl)]; zeros[(size_t) l] = 0; lev_counter[(size_t) l] = -1; }
             cycle_op_count += pv->graph_op_count;
+            account_bytes(pv->graph_bytes_csr, pv->graph_bytes_stream);      // what the recorded launches accounted for
             replayed = true;
          }
          else if (pv->graph_state == 1)
          {
-            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; op_count_at_capture = cycle_op_count; }
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; op_count_at_capture = cycle_op_count; csr_at_capture = handle().bytes_csr; stream_at_capture = handle().bytes_stream; }
             else { (void) hipGetLastError(); pv->graph_state = 0; gl = -1; }
          }
       }
@@ -782,6 +783,8 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
                   pv->graph_cur.assign((size_t) (L - gl), nullptr);
                   for (int l = gl; l < L; l++) { pv->graph_cur[(size_t) (l - gl)] = lv[(size_t) l].cur; }
                   pv->graph_op_count = cycle_op_count - op_count_at_capture;
+                  pv->graph_bytes_csr = handle().bytes_csr - csr_at_capture;
+                  pv->graph_bytes_stream = handle().bytes_stream - stream_at_capture;
                   size_t nn = 0;
                   if (hipGraphGetNodes(g, nullptr, &nn) == hipSuccess) { pv->graph_launches = (int) nn; }
                   HIP_CHECK(hipGraphLaunch(ex, s));       // the capture recorded the work, it did not run it

@@ -22,13 +22,35 @@ using namespace hamd;
 
 namespace hamd {
 // traffic counters of this process (reported by the benchmark): neighbour exchanges and all-reduces started
-static long long g_exchanges = 0, g_allreduces = 0;
+static long long g_exchanges = 0, g_allreduces = 0, g_exchange_bytes = 0, g_allreduce_bytes = 0;
 }
 extern "C" HYPRE_Int hypre_amd_CommCounters(HYPRE_BigInt *exchanges, HYPRE_BigInt *allreduces, HYPRE_Int reset)
 {
    if (exchanges) { *exchanges = hamd::g_exchanges; }
    if (allreduces) { *allreduces = hamd::g_allreduces; }
-   if (reset) { hamd::g_exchanges = 0; hamd::g_allreduces = 0; }
+   if (reset) { hamd::g_exchanges = 0; hamd::g_allreduces = 0; hamd::g_exchange_bytes = 0; hamd::g_allreduce_bytes = 0; }
+   return hypre_error_flag;
+}
+// bytes this process SENT in neighbour exchanges / contributed to all-reduces since the last reset of the counters above
+extern "C" HYPRE_Int hypre_amd_CommBytes(HYPRE_BigInt *exchange_bytes, HYPRE_BigInt *allreduce_bytes)
+{
+   if (exchange_bytes) { *exchange_bytes = hamd::g_exchange_bytes; }
+   if (allreduce_bytes) { *allreduce_bytes = hamd::g_allreduce_bytes; }
+   return hypre_error_flag;
+}
+// shape of a matrix's halo exchange (its communication package, built on demand): neighbours this rank sends to /
+// receives from, entries sent / received per exchange
+extern "C" HYPRE_Int hypre_amd_ParCSRMatrixHaloInfo(hypre_ParCSRMatrix *A, HYPRE_Int *num_sends, HYPRE_Int *send_entries,
+                                                    HYPRE_Int *num_recvs, HYPRE_Int *recv_entries)
+{
+   HYPRE_Int np;
+   hypre_MPI_Comm_size(A->comm, &np);
+   if (np > 1 && !A->comm_pkg) { hypre_MatvecCommPkgCreate(A); }
+   hypre_ParCSRCommPkg *pk = A->comm_pkg;
+   if (num_sends) { *num_sends = pk ? pk->num_sends : 0; }
+   if (send_entries) { *send_entries = pk ? pk->send_map_starts[pk->num_sends] : 0; }
+   if (num_recvs) { *num_recvs = pk ? pk->num_recvs : 0; }
+   if (recv_entries) { *recv_entries = pk ? pk->recv_vec_starts[pk->num_recvs] : 0; }
    return hypre_error_flag;
 }
 namespace hamd {
@@ -74,6 +96,7 @@ void dev_allreduce_sum(MPI_Comm comm, double *d_buf, int n)
    const hypre_amd_CommOps *o = comm_ops(comm);
    if (!o || o->size <= 1 || n <= 0) { return; }
    g_allreduces++;
+   g_allreduce_bytes += 8LL * n;
    Handle &hd = handle();
    if (o->device_buffers)
    {
@@ -578,6 +601,7 @@ hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate_v2(HYPRE_Int job, hypre_Par
    std::vector<char> hs, hr;
    const size_t stot = esz * (size_t) sstarts[ns], rtot = esz * (size_t) rstarts[nr];
    const bool stage = dev && !o->device_buffers;
+   hamd::g_exchange_bytes += (long long) stot;
    if (stage)
    {
       // provider cannot take device pointers: bounce through host memory

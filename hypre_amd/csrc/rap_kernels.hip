@@ -573,7 +573,12 @@ bool device_rap(int nc, int ncP, int maxP,
          }
       }
    }
-   const size_t scratch_limit = (size_t) 24 << 30;
+   // the strided scratch of the one-walk form: at most 24 GB and at most half of what the device has free right now
+   // (other hierarchies, other tenants); an allocation that fails all the same sends this product to the two-walk form,
+   // which needs none
+   size_t free_b = 0, total_b = 0;
+   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); free_b = (size_t) 48 << 30; }
+   const size_t scratch_limit = std::min<size_t>((size_t) 24 << 30, free_b / 2);
    for (int attempt = 0; attempt < 6 && !done; attempt++)
    {
       capRA = (std::min(ubA, needRA) + 1) & ~1;
@@ -587,9 +592,16 @@ bool device_rap(int nc, int ncP, int maxP,
       if (single)
       {
          const double ta = omp_get_wtime();
-         HIP_CHECK(hipMalloc((void **) &sj, sizeof(int) * slots));
-         HIP_CHECK(hipMalloc((void **) &sa, sizeof(double) * slots));
+         if (hipMalloc((void **) &sj, sizeof(int) * slots) != hipSuccess) { (void) hipGetLastError(); sj = nullptr; single = false; }
+         if (single && hipMalloc((void **) &sa, sizeof(double) * slots) != hipSuccess)
+         {
+            (void) hipGetLastError();
+            HIP_CHECK(hipFree(sj)); sj = nullptr; sa = nullptr; single = false;
+         }
          t_alloc += omp_get_wtime() - ta;
+      }
+      if (single)
+      {
          hipLaunchKernelGGL((rap_rows_kernel<true>), dim3(waves), dim3(64), lds_bytes(capA, capRA, capP, capO), s, nc, square ? 1 : 0,
                             Ri, Rj, Ra, Ai, Aj, Aa, Pi, Pj, Pa, capA, capRA, capP, capO, rowlen, (const int *) nullptr, sj, sa, d_scr + 1,
                             1, (int *) nullptr);
@@ -620,8 +632,14 @@ bool device_rap(int nc, int ncP, int maxP,
    if (nnz < 0) { return give_up(); }               // more than 2^31 - 1 entries
    int *Ci = rowlen, *Cj = nullptr;
    double *Ca = nullptr;
-   HIP_CHECK(hipMalloc((void **) &Cj, sizeof(int) * (size_t) std::max(nnz, 1)));
-   HIP_CHECK(hipMalloc((void **) &Ca, sizeof(double) * (size_t) std::max(nnz, 1)));
+   if (hipMalloc((void **) &Cj, sizeof(int) * (size_t) std::max(nnz, 1)) != hipSuccess ||
+       hipMalloc((void **) &Ca, sizeof(double) * (size_t) std::max(nnz, 1)) != hipSuccess)
+   {
+      // no room for the product on the device: the host loop takes over
+      (void) hipGetLastError();
+      if (Cj) { HIP_CHECK(hipFree(Cj)); }
+      return give_up();
+   }
    if (single)
    {
       const size_t slots = (size_t) nc * (size_t) capO;

@@ -177,6 +177,16 @@ HYPRE_Int hypre_SyncComputeStream(void)
    if (h.device_ok) { HIP_CHECK(hipStreamSynchronize(h.compute_stream)); }
    return hypre_error_flag;
 }
+// Algorithmic bytes of the launches since the last reset (Handle::bytes_csr / bytes_stream): the CSR count of SURVEY 8(d)
+// and what the kernels are designed to stream.
+HYPRE_Int hypre_amd_ByteCounters(HYPRE_Real *csr_bytes, HYPRE_Real *streamed_bytes, HYPRE_Int reset)
+{
+   Handle &h = handle();
+   if (csr_bytes) { *csr_bytes = h.bytes_csr; }
+   if (streamed_bytes) { *streamed_bytes = h.bytes_stream; }
+   if (reset) { h.bytes_csr = 0.0; h.bytes_stream = 0.0; }
+   return hypre_error_flag;
+}
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 HYPRE_Int hypre_amd_EventTimerStart(void)
 {

@@ -1164,6 +1164,24 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       a.Aa32 = mp->a32;
    }
    if (a.rowmap && op != OP_JACOBI_MAP) { hypre_error_w_msg(HYPRE_ERROR_ARG, "row map given to an operation that does not read it"); return; }
+   {
+      // byte accounting (Handle::bytes_csr / bytes_stream): the matrix pass, the compulsory read of x (every column once,
+      // or every entry's column when the matrix has fewer entries than columns: a colour's rows) and the row operands
+      const double nz = (double) plan->nnz, nr = (double) plan->num_rows, vw = a.Aa32 ? 4.0 : 8.0;
+      const double xcols = 8.0 * std::min((double) plan->num_cols, nz);
+      double rowb = 0.0;
+      switch (op)
+      {
+         case OP_AXPBY:      rowb = 8.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;              // y (+ b)
+         case OP_JACOBI:     rowb = 24.0; break;                                              // f, d, u'   (u is the x gather)
+         case OP_JACOBI_CF:  rowb = 28.0; break;                                              // + marker
+         case OP_JACOBI_MAP: rowb = 28.0 + (a.marker ? 4.0 : 0.0); break;                     // + row map
+         case OP_TSGS:       rowb = 32.0; break;                                              // d, z', u read and write
+      }
+      const double rows_b = 4.0 * (nr + 1.0) + rowb * nr + xcols;
+      const bool staged = plan->tiled && a.variant == 2 && plan->d_lidx != nullptr;
+      account_bytes(nz * (vw + 4.0) + rows_b, nz * (vw + (staged ? 2.0 : 4.0)) + rows_b);
+   }
    switch (op)
    {
       case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, a, s); break;
@@ -1184,6 +1202,7 @@ void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t 
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s)
 {
    if (num_rownnz <= 0) { return; }
+   account_bytes(36.0 * num_rownnz);        // latency-bound ghost-block pass: listed row, its pointers, about one entry, y read and write
    const int grid = (num_rownnz * 8 + SPMV_THREADS - 1) / SPMV_THREADS;
    hipLaunchKernelGGL(spmv_rownnz_kernel, dim3(grid), dim3(SPMV_THREADS), 0, s, args, rownnz, num_rownnz);
 }

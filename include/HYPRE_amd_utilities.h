@@ -110,6 +110,13 @@ HYPRE_Int hypre_amd_SetHostThreads(HYPRE_Int num_threads);
 HYPRE_Int hypre_SetSyncCudaCompute(HYPRE_Int action);
 HYPRE_Int hypre_GetSyncCudaCompute(HYPRE_Int *cuda_compute_stream_sync_ptr);
 HYPRE_Int hypre_SyncComputeStream(void);
+/* Algorithmic bytes of everything the library launched since the last reset, counted by the launch wrappers (so they follow
+ * the smoother, the value width and the rank's share actually run; a replayed HIP graph adds what its recording added):
+ * csr_bytes = the count of SURVEY.md 8(d) — CSR entries at 4 bytes of index + the value width in use, row pointers, every
+ * vector operand once; streamed_bytes = what the kernels are designed to read (the x-staged SpMV streams a 16-bit staged
+ * index per entry and never the column array).  Either pointer may be NULL; reset != 0 clears both.  No reference
+ * counterpart (the reference reports flop-free wall-clock times only). */
+HYPRE_Int hypre_amd_ByteCounters(HYPRE_Real *csr_bytes, HYPRE_Real *streamed_bytes, HYPRE_Int reset);
 /* the HIP stream (hipStream_t as void*) every kernel of the library is
  * launched on; utilities/handle.h hypre_HandleComputeStream */
 void     *hypre_amd_ComputeStream(void);

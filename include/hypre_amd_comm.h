@@ -82,6 +82,8 @@ HYPRE_Int hypre_amd_CommSelfTest(MPI_Comm comm, HYPRE_Int nbytes);
 
 /* neighbour exchanges and all-reduces this process has started since the last reset (benchmark reporting) */
 HYPRE_Int hypre_amd_CommCounters(HYPRE_BigInt *exchanges, HYPRE_BigInt *allreduces, HYPRE_Int reset);
+/* bytes this process sent in those exchanges / contributed to device all-reduces (cleared with the counters above) */
+HYPRE_Int hypre_amd_CommBytes(HYPRE_BigInt *exchange_bytes, HYPRE_BigInt *allreduce_bytes);
 
 HYPRE_Int hypre_MPI_Comm_rank(MPI_Comm comm, HYPRE_Int *rank);
 HYPRE_Int hypre_MPI_Comm_size(MPI_Comm comm, HYPRE_Int *size);

@@ -245,8 +245,6 @@ HYPRE_Int hypre_amd_BoomerAMGSetMemoryLocation(HYPRE_Solver solver, HYPRE_Memory
 /* OpenMP thread count the host setup emulates in its thread-partitioned loops
  * (0 = 1; results of the hybrid smoothers' block partition depend on it) */
 HYPRE_Int hypre_amd_BoomerAMGSetNumThreads(HYPRE_Solver solver, HYPRE_Int num_threads);
-/* store matrix values of every level in fp32 for the SpMV / smoother kernels;
- * residuals on level 0 stay fp64 (mixed-precision configuration) */
 /* Where the Galerkin products of HYPRE_BoomerAMGSetup are formed when the hierarchy's home is device memory and there is
  * one rank: on the device by default (rap_kernels.hip; same columns, order and bits as the host loop), on = 0 keeps the
  * host loop; min_rows: smallest fine level sent to the device (default 20000).  Negative arguments leave a setting
@@ -279,6 +277,11 @@ HYPRE_Int hypre_amd_SetSetupDeviceDist(HYPRE_Int on);
  * graph (-1: none) and its node count. */
 HYPRE_Int hypre_amd_BoomerAMGSetGraphThreshold(HYPRE_Solver solver, HYPRE_Int rows);
 HYPRE_Int hypre_amd_BoomerAMGGetGraphInfo(HYPRE_Solver solver, HYPRE_Int *level, HYPRE_Int *nodes);
+/* Mixed precision (BASELINE config C5): inside the cycle the SpMV-class kernels stream an fp32 copy of every level's matrix
+ * values, diagonal and ghost blocks alike (4 + 2 instead of 8 + 2 bytes per entry); vectors, accumulation, smoother
+ * diagonals, the coarse solve and everything outside the cycle stay fp64, and HYPRE_BoomerAMGSolve applies the cycle to the
+ * fp64 residual equation from a non-zero iterate.  The reference has only the whole-library HYPRE_SINGLE
+ * (utilities/HYPRE_utilities.h:78-89). */
 HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on);
 /* grid / operator complexity of the last setup */
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);

@@ -277,6 +277,10 @@ hypre_CSRMatrix *hypre_amd_CSRMatrixFromArrays(HYPRE_Int num_rows, HYPRE_Int num
 hypre_Vector    *hypre_amd_SeqVectorFromArray(HYPRE_Int size, const HYPRE_Complex *data,
                                               HYPRE_MemoryLocation location);
 HYPRE_Int        hypre_amd_SeqVectorToArray(hypre_Vector *v, HYPRE_Complex *out);
+/* shape of a matrix's halo exchange (its communication package, built on demand — collective): neighbours this rank sends
+ * to / receives from and the entries per exchange (par_csr_communication.h:51-75 send_map_starts / recv_vec_starts) */
+HYPRE_Int        hypre_amd_ParCSRMatrixHaloInfo(hypre_ParCSRMatrix *A, HYPRE_Int *num_sends, HYPRE_Int *send_entries,
+                                                HYPRE_Int *num_recvs, HYPRE_Int *recv_entries);
 HYPRE_Int        hypre_amd_CopyToHost(void *dst_host, const void *src, size_t bytes,
                                       HYPRE_MemoryLocation src_location);
 /* assemble one rank's block from local diag/offd CSR arrays (host pointers) */

@@ -110,6 +110,63 @@ def test_hot_kernels_keep_full_occupancy():
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, r
 
 
+def _xs_kernel_listing(extra_flags):
+    """instructions of spmv_xs_kernel<OP_AXPBY, fp64, no fill> as the build's flags compile it (device code only)"""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.join(ROOT, "hypre_amd", "csrc"), "-x", "hip", "-S", "--cuda-device-only", "-o", out, src] + extra_flags
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = open(out).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4hamd14spmv_xs_kernelILi0ELb0ELb0E") and l.rstrip().endswith(":") is False and ":" in l)
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    return [l.strip() for l in lines[start:end + 1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
+
+
+def _xs_schedule(ins):
+    """where the loads of one tile sit: indices of the first matrix-stream load, of the wait that ends the scalar batch
+    with the tile's piece descriptors, of the first LDS-DMA load of x, of the first barrier; and the waits between them"""
+    first_stream = next(i for i, l in enumerate(ins) if l.startswith("global_load_dwordx4") or l.startswith("global_load_dwordx2"))
+    first_dma = next(i for i, l in enumerate(ins) if l.startswith("global_load_lds_dwordx4"))
+    # the descriptors are the scalar loads at a register offset (tile * 96 ints into the plan's table)
+    import re
+    pat = re.compile(r"s_load_dwordx8 s\[\d+:\d+\], s\[\d+:\d+\], s\d+ offset:")
+    desc = [i for i, l in enumerate(ins[:first_dma]) if pat.match(l)]
+    assert desc, "no descriptor batch found in front of the LDS-DMA loads"
+    batch_wait = next(i for i in range(desc[-1], len(ins)) if ins[i].startswith("s_waitcnt") and "lgkmcnt(0)" in ins[i])
+    first_barrier = next(i for i in range(first_dma, len(ins)) if ins[i].startswith("s_barrier"))
+    return dict(first_stream=first_stream, batch_wait=batch_wait, first_dma=first_dma, first_barrier=first_barrier,
+                vm_waits_before_dma=[l for l in ins[first_stream:first_dma] if l.startswith("s_waitcnt") and "vmcnt" in l],
+                vm_waits_dma_to_barrier=[l for l in ins[first_dma:first_barrier] if l.startswith("s_waitcnt") and "vmcnt" in l],
+                stream_loads_before_batch_wait=sum(1 for l in ins[:batch_wait] if l.startswith(("global_load_dwordx4", "global_load_dwordx2"))),
+                dma_loads=sum(1 for l in ins[first_dma:first_barrier] if l.startswith("global_load_lds_dwordx4")))
+
+
+def test_the_x_staged_kernel_keeps_its_load_schedule():
+    """One trip through the vector-memory pipeline per tile is what spmv_xs_kernel is built on: the
+    (value, index) stream of the tile is requested BEFORE the scalar batch with the tile's bounds and piece descriptors
+    has come back, nothing waits for a vector load until the twelve LDS-DMA loads of the x pieces are out, and exactly one
+    wait for everything stands in front of the first barrier.  The compiler is free to sink loads below the branches
+    that follow them — it did, until an empty asm with a memory clobber fenced the batch — so the build's own compile of the
+    kernel is disassembled here and the order checked; the same check must FAIL for the -DXS_EARLY_STREAM=0 variant
+    (stream loads behind the empty-tile test), or it checks nothing."""
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc")
+    good = _xs_schedule(_xs_kernel_listing([]))
+    assert good["first_stream"] < good["batch_wait"] < good["first_dma"] < good["first_barrier"], good
+    assert good["stream_loads_before_batch_wait"] >= 6, good          # 4 x 16 bytes of values + 2 x 8 bytes of indices per lane
+    assert good["vm_waits_before_dma"] == [], good
+    assert good["dma_loads"] == 12, good
+    assert len(good["vm_waits_dma_to_barrier"]) == 1 and "vmcnt(0)" in good["vm_waits_dma_to_barrier"][0], good
+    late = _xs_schedule(_xs_kernel_listing(["-DXS_EARLY_STREAM=0"]))
+    assert not (late["first_stream"] < late["batch_wait"]), late
+
+
 def test_option_gates_accept_the_built_branch_and_refuse_the_rest(lib):
     """Setters for options whose other branches are not built: the supported value passes, anything else is an
     argument error with a message (never silently ignored)."""

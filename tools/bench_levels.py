@@ -24,7 +24,11 @@ ap.add_argument("--variants", default="0")
 ap.add_argument("--problem", default="laplacian")
 ap.add_argument("--levels", type=int, default=99, help="time the first LEVELS levels only")
 ap.add_argument("--relax", type=int, default=18)
+ap.add_argument("--mixed", action="store_true")
+ap.add_argument("--json", default="", help="write the table (per level and operation: ms, SURVEY 8(d) bytes, GB/s, fraction of 8 TB/s) here")
 args = ap.parse_args()
+table = {"problem": args.problem, "n": args.n, "relax": args.relax, "mixed": bool(args.mixed), "reps": args.reps,
+         "bytes": "SURVEY.md 8(d): CSR entries at 12 bytes, row pointers, every vector operand once", "peak_GBps": 8000.0, "levels": []}
 n, reps = args.n, args.reps
 L = B.load_library()
 opt = ij.IJOptions(n=(n, n, n), coarsen_type=8, interp_type=6, P_max_elmts=4, relax_type=args.relax, num_sweeps=1,
@@ -32,6 +36,9 @@ opt = ij.IJOptions(n=(n, n, n), coarsen_type=8, interp_type=6, P_max_elmts=4, re
 t0 = time.time()
 A = ij.build_matrix(opt)
 s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+if args.mixed:
+    L.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
 L.HYPRE_BoomerAMGSetup(s, A, None, None)
 B.check()
 L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)     # level 0 is the caller's matrix
@@ -69,7 +76,9 @@ def cycle():
 
 for var, wgs in variants:
     L.hypre_amd_SpmvSetVariant(var, wgs)
-    print("variant %d:%d  V-cycle %.4f ms" % (var, wgs, timed(cycle)), flush=True)
+    ms_c = timed(cycle)
+    print("variant %d:%d  V-cycle %.4f ms" % (var, wgs, ms_c), flush=True)
+    table.setdefault("vcycle_ms", {})["%d:%d" % (var, wgs)] = ms_c
 
 for l in range(min(nl, args.levels)):
     Al = C.cast(L.hypre_amd_BoomerAMGGetA(s, l), C.POINTER(B.ParCSRMatrix))
@@ -92,15 +101,33 @@ for l in range(min(nl, args.levels)):
             stt = L.hypre_amd_CSRMatrixPlanStaging(Pq.contents.diagT, C.byref(nt), C.byref(mp))
             line += " | P^T: tiles %d, x-staged %d (%.1f pieces)" % (nt.value, stt, mp.value)
         print(line, flush=True)
+    lev = {"level": l, "rows": nr, "nnz": nnz, "tiles": nt.value, "x_staged_tiles": st, "ops": {}}
+    table["levels"].append(lev)
+
+    def rec(name, var, wgs, ms, by):
+        lev["ops"].setdefault(name, {})["%d:%d" % (var, wgs)] = {"ms": ms, "bytes": by, "GBps": by / ms / 1e6, "frac_of_peak": by / ms / 1e6 / 8000.0}
+
+    z = B.parvec_from_numpy(np.zeros(nr))
     for var, wgs in variants:
         L.hypre_amd_SpmvSetVariant(var, wgs)
         ms_a = timed(lambda: L.hypre_ParCSRMatrixMatvec(1.0, Al, x, 0.0, y))
         by_a = nnz * 12 + (nr + 1) * 4 + nr * 16
+        rec("A x", var, wgs, ms_a, by_a)
         line = "   v%d:%d  A x: %.4f ms %6.0f GB/s" % (var, wgs, ms_a, by_a / ms_a / 1e6)
-        if l1 is not None and l < nl - 1:
-            ms_j = timed(lambda: L.hypre_BoomerAMGRelax(Al, f, None, 18, 0, 1.0, 1.0, l1, x, v, v))
+        if l1 is not None and l < nl - 1 and args.relax in (7, 18):
+            ms_j = timed(lambda: L.hypre_BoomerAMGRelax(Al, f, None, args.relax, 0, 1.0, 1.0, l1, x, v, v))
             by_j = nnz * 12 + (nr + 1) * 4 + nr * 32
+            rec("l1-Jacobi sweep (public entry: + copy back)", var, wgs, ms_j, by_j + nr * 16)
             line += " | l1-Jacobi (+copy back): %.4f ms %6.0f GB/s" % (ms_j, (by_j + nr * 16) / ms_j / 1e6)
+        if l1 is not None and l < nl - 1 and args.relax in (11, 12):
+            # two-stage GS: residual pass over A, then (relax - 10) passes over the strict lower triangle (about half the
+            # entries) with their vector traffic (par_relax_device.c:97-155)
+            inner = args.relax - 10
+            ms_j = timed(lambda: L.hypre_BoomerAMGRelax(Al, f, None, args.relax, 0, 1.0, 1.0, l1, x, v, z))
+            nl_low = (nnz - nr) // 2
+            by_j = (nnz * 12 + (nr + 1) * 4 + nr * 24) + nr * 40 + inner * (nl_low * 12 + (nr + 1) * 4 + nr * 40)
+            rec("two-stage GS sweep (%d inner)" % inner, var, wgs, ms_j, by_j)
+            line += " | two-stage GS(%d): %.4f ms %6.0f GB/s" % (inner, ms_j, by_j / ms_j / 1e6)
         if l < nl - 1:
             Pl = C.cast(L.hypre_amd_BoomerAMGGetP(s, l), C.POINTER(B.ParCSRMatrix))
             pd = Pl.contents.diag.contents
@@ -111,6 +138,12 @@ for l in range(min(nl, args.levels)):
             ms_r = timed(lambda: L.hypre_ParCSRMatrixMatvecT(1.0, Pl, x, 0.0, yc))
             by_p = pd.num_nonzeros * 12 + (nr + 1) * 4 + nc * 8 + nr * 16
             by_r = pd.num_nonzeros * 12 + (nc + 1) * 4 + nr * 8 + nc * 8
+            rec("P x (u += P e)", var, wgs, ms_p, by_p)
+            rec("P^T x", var, wgs, ms_r, by_r)
             line += " | P x: %.4f ms %6.0f GB/s | P^T x: %.4f ms %6.0f GB/s" % (ms_p, by_p / ms_p / 1e6, ms_r, by_r / ms_r / 1e6)
         print(line, flush=True)
 B.check()
+if args.json:
+    import json
+    with open(args.json, "w") as fh:
+        json.dump(table, fh, indent=1)

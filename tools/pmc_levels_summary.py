@@ -75,7 +75,10 @@ for lv, d in levels.items():
         d["wave_time_waiting_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
         d["wave_time_issue_stalled_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
         d["wave_time_issuing_frac"] = c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
-out = {"tag": tag, "command": "bash tools/pmc_levels.sh %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set, "
+import hashlib
+with open(os.path.join("hypre_amd", "csrc", "spmv_kernels.hip"), "rb") as fh:
+    kernel_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+out = {"tag": tag, "kernel_source_sha16": kernel_sha, "command": "bash tools/pmc_levels.sh %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set, "
                               "each over python3 tools/bench_levels_spmv.py 256 3 10)" % tag,
        "matrix": "levels 0-2 of the 256^3 7-pt hierarchy (PMIS, ext+i(4))",
        "note": "SQ_* cycle counters are in units of 4 cycles and sampled; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled "
