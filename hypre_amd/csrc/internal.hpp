@@ -222,6 +222,7 @@ void launch_f64_to_f32(const double *x, float *y, size_t n, hipStream_t s);
 void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows, int ncols, int nnz, int *Ti, int *tj, double *ta,
                       hipStream_t s);     // device CSR transpose, rows of the result in ascending source-row order
 void launch_scan_exclusive(int *data, int n, hipStream_t s);
+void launch_sort_rows(const int *Ai, int *Aj, double *Aa, int n, int keep_first, hipStream_t s);   // columns ascending inside every row
 // one per kernel file: loads its code object (runtime.cpp: ensure_device)
 void preload_cheby_kernels(); void preload_gs_kernels(); void preload_interp_kernels(); void preload_vector_kernels();
 void preload_rap_kernels(); void preload_setup_kernels(); void preload_spmv_kernels();

@@ -531,6 +531,66 @@ void launch_scan_exclusive(int *data, int n, hipStream_t s)
    depth--;
    hipLaunchKernelGGL(scan_blocks_kernel, dim3(nb), dim3(1024), 0, s, data, n, sums[d], nb);
 }
+// Columns of every row in ascending order, the first entry (the diagonal of a square block) left in front.  One wave per
+// row: bitonic network over the row in LDS.  Rows longer than the network (2048 entries) are left as they are.
+// Why: the x-staged SpMV reads a lane's consecutive entries from LDS positions that follow the columns' order; with the
+// first-touch order a Galerkin product leaves, the eight reads of a lane scatter over the staged copy and half of the
+// LDS cycles are bank conflicts (levels 1 - 2 of the benchmark hierarchy: 6 % slower than with sorted rows).
+constexpr int SORT_CAP = 2048;
+__global__ __launch_bounds__(64)
+void sort_rows_kernel(int n, const int *__restrict__ Ai, int *__restrict__ Aj, double *__restrict__ Aa, int keep_first)
+{
+   __shared__ int key[SORT_CAP];
+   __shared__ double val[SORT_CAP];
+   const int lane = threadIdx.x;
+   for (int row = blockIdx.x; row < n; row += gridDim.x)
+   {
+      const int e = Ai[row + 1];
+      int b = Ai[row];
+      if (keep_first && e > b) { b++; }
+      const int len = e - b;
+      if (len <= 1 || len > SORT_CAP) { continue; }
+      // already ascending?  (restriction operators, sorted inputs)
+      bool asc = true;
+      for (int k = lane; k + 1 < len; k += 64) { if (Aj[b + k] > Aj[b + k + 1]) { asc = false; } }
+      if (__ballot(!asc) == 0ull) { continue; }
+      int m = 2;
+      while (m < len) { m <<= 1; }
+      for (int k = lane; k < m; k += 64)
+      {
+         key[k] = k < len ? Aj[b + k] : 0x7fffffff;
+         val[k] = k < len ? Aa[b + k] : 0.0;
+      }
+      __syncthreads();
+      for (int size = 2; size <= m; size <<= 1)
+      {
+         for (int stride = size >> 1; stride > 0; stride >>= 1)
+         {
+            for (int t = lane; t < (m >> 1); t += 64)
+            {
+               const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+               const bool up = (i & size) == 0;
+               const int ki = key[i], kj = key[j];
+               if ((ki > kj) == up)
+               {
+                  key[i] = kj; key[j] = ki;
+                  const double vi = val[i]; val[i] = val[j]; val[j] = vi;
+               }
+            }
+            __syncthreads();
+         }
+      }
+      for (int k = lane; k < len; k += 64) { Aj[b + k] = key[k]; Aa[b + k] = val[k]; }
+      __syncthreads();
+   }
+}
+void launch_sort_rows(const int *Ai, int *Aj, double *Aa, int n, int keep_first, hipStream_t s)
+{
+   if (n <= 0) { return; }
+   const int grid = std::min(n, handle().num_cus * 64);
+   hipLaunchKernelGGL(sort_rows_kernel, dim3(grid), dim3(64), 0, s, n, Ai, Aj, Aa, keep_first);
+}
+
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s)
 { if (n > 0 && nv > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(((size_t) n * nv + 255) / 256), dim3(256), 0, s, in, out, n, nv); }
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s)
