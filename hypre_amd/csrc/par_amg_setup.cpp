@@ -244,6 +244,14 @@ static void place_on_device(hypre_CSRMatrix *M)
    t.erase(it);
    hypre_Free(M->i, HYPRE_MEMORY_HOST); hypre_Free(M->j, HYPRE_MEMORY_HOST); hypre_Free(M->data, HYPRE_MEMORY_HOST);
    M->i = d->i; M->j = d->j; M->data = d->data;
+   if (M->rownnz)
+   {
+      // the list of non-empty rows (ghost blocks carry one) moves with the arrays
+      HYPRE_Int *dr = hypre_TAlloc(HYPRE_Int, (size_t) std::max(M->num_rownnz, 1), HYPRE_MEMORY_DEVICE);
+      hypre_TMemcpy(dr, M->rownnz, HYPRE_Int, (size_t) M->num_rownnz, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+      hypre_Free(M->rownnz, HYPRE_MEMORY_HOST);
+      M->rownnz = dr;
+   }
    M->memory_location = HYPRE_MEMORY_DEVICE;
    d->i = nullptr; d->j = nullptr; d->data = nullptr;
    hypre_CSRMatrixDestroy(d);
@@ -356,6 +364,13 @@ static void make_host_resident(hypre_CSRMatrix *M)
    drop_plan(M);
    device_twins()[M] = wrap_device_csr(nr, M->num_cols, nnz, M->i, M->j, M->data);
    M->i = hi; M->j = hj; M->data = ha;
+   if (M->rownnz)
+   {
+      HYPRE_Int *hr = hypre_TAlloc(HYPRE_Int, (size_t) std::max(M->num_rownnz, 1), HYPRE_MEMORY_HOST);
+      hypre_TMemcpy(hr, M->rownnz, HYPRE_Int, (size_t) M->num_rownnz, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      hypre_Free(M->rownnz, HYPRE_MEMORY_DEVICE);
+      M->rownnz = hr;
+   }
    M->memory_location = HYPRE_MEMORY_HOST;
 }
 

@@ -782,6 +782,22 @@ bool all_ranks_agree(MPI_Comm comm, bool mine)
    return global_sum(comm, mine ? 0.0 : 1.0) == 0.0;
 }
 
+// Test hook: rank `rank` pretends that the device kernel of step `what` (1: interpolation, 2: product rows for the
+// neighbours, 3: product) declined, `count` times — so that the agreed fall-back to the host routines runs in a test.
+static int g_decline_what = 0, g_decline_rank = -1, g_decline_count = 0;
+extern "C" HYPRE_Int hypre_amd_SetupDistTestDecline(HYPRE_Int what, HYPRE_Int rank, HYPRE_Int count)
+{
+   g_decline_what = what; g_decline_rank = rank; g_decline_count = count;
+   return hypre_error_flag;
+}
+static bool test_declines(MPI_Comm comm, int what)
+{
+   HYPRE_Int me;
+   hypre_MPI_Comm_rank(comm, &me);
+   if (g_decline_count > 0 && g_decline_what == what && me == g_decline_rank) { g_decline_count--; return true; }
+   return false;
+}
+
 HYPRE_Int dist_device_create_S(hypre_ParCSRMatrix *A, HYPRE_Real theta, HYPRE_Real max_row_sum, hypre_ParCSRMatrix **S_ptr)
 {
    hypre_CSRMatrix *dD = setup_device_twin_of(A->diag, 1), *dO = setup_device_twin_of(A->offd, 1);
@@ -964,6 +980,7 @@ HYPRE_Int dist_device_extpi_interp(hypre_ParCSRMatrix *A, HYPRE_Int *CF_marker, 
       hypre_Free(ext_pkg.send_procs, HYPRE_MEMORY_HOST); hypre_Free(ext_pkg.send_map_starts, HYPRE_MEMORY_HOST);
       hypre_Free(ext_pkg.send_map_elmts, HYPRE_MEMORY_HOST);
    };
+   if (ok && test_declines(comm, 1)) { dfree(Pdi); dfree(Pdj); dfree(Pda); dfree(Poi); dfree(Poj); dfree(Poa); ok = false; }
    if (!all_ranks_agree(comm, ok))
    {
       if (ok) { dfree(Pdi); dfree(Pdj); dfree(Pda); dfree(Poi); dfree(Poj); dfree(Poa); }
@@ -1105,9 +1122,11 @@ HYPRE_Int dist_device_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix
       const bool ok = device_rap_dist(true, ncoRT, 0, ncP + ncoPext, maxP, 0, Ro ? Ro->i : nullptr, Ro ? Ro->j : nullptr, Ro ? Ro->data : nullptr,
                                       dD->i, dD->j, dD->data, ncoA ? dO->i : nullptr, dO->j, dO->data, n, n, Xi, Xj, Xa,
                                       nullptr, nullptr, nullptr, nullptr, nullptr, ncP, &Ii, &Ij, &Ia, &innz, nullptr, nullptr, nullptr, nullptr, st);
-      if (!all_ranks_agree(comm, ok))
+      bool okk = ok;
+      if (okk && test_declines(comm, 2)) { dfree(Ii); dfree(Ij); dfree(Ia); okk = false; }
+      if (!all_ranks_agree(comm, okk))
       {
-         if (ok) { dfree(Ii); dfree(Ij); dfree(Ia); }
+         if (okk) { dfree(Ii); dfree(Ij); dfree(Ia); }
          return give_up();
       }
       Rint.i.assign((size_t) ncoRT + 1, 0);
@@ -1174,6 +1193,7 @@ HYPRE_Int dist_device_coarse_operator(hypre_ParCSRMatrix *RT, hypre_ParCSRMatrix
                            nsendRT ? dFi : nullptr, dFj, X.i, X.j, X.a, ncP, &Cdi, &Cdj, &Cda, &cdnnz, &Coi, &Coj, &Coa, &connz, st);
       dfree(dFi); dfree(dFj); dfree(d_map);
    }
+   if (ok && test_declines(comm, 3)) { dfree(Cdi); dfree(Cdj); dfree(Cda); dfree(Coi); dfree(Coj); dfree(Coa); ok = false; }
    if (!all_ranks_agree(comm, ok))
    {
       if (ok) { dfree(Cdi); dfree(Cdj); dfree(Cda); dfree(Coi); dfree(Coj); dfree(Coa); }

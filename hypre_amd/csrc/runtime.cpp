@@ -3,6 +3,7 @@
 // utilities/memory.c (hypre_MAlloc/hypre_Free/hypre_Memcpy), utilities/general.c
 // (HYPRE_Initialize, HYPRE_SetMemoryLocation, hypre_SetSyncCudaCompute).
 #include "internal.hpp"
+#include <execinfo.h>
 #include <omp.h>
 #include <sched.h>
 #include <unistd.h>
@@ -257,7 +258,24 @@ void *hypre_CAlloc(size_t count, size_t elt_size, HYPRE_MemoryLocation location)
 void hypre_Free(void *ptr, HYPRE_MemoryLocation location)
 {
    if (!ptr) { return; }
-   if (location == HYPRE_MEMORY_DEVICE) { HIP_CHECK(hipFree(ptr)); }
+   if (location == HYPRE_MEMORY_DEVICE)
+   {
+      const hipError_t e = hipFree(ptr);
+      if (e != hipSuccess)
+      {
+         (void) hipGetLastError();
+         // a host pointer freed as device memory (or a double free): say who asked, once the caller wants to know
+         if (getenv("HYPRE_AMD_DEBUG_FREE"))
+         {
+            void *frames[24];
+            const int nf = backtrace(frames, 24);
+            backtrace_symbols_fd(frames, nf, 2);
+         }
+         char msg[256];
+         snprintf(msg, sizeof(msg), "HIP error %d (%s) in hipFree(%p)", (int) e, hipGetErrorString(e), ptr);
+         hypre_error_handler(__FILE__, __LINE__, HYPRE_ERROR_GENERIC, msg);
+      }
+   }
    else { free(ptr); }
 }
 

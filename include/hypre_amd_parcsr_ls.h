@@ -271,6 +271,11 @@ HYPRE_Int hypre_amd_SetSetupDeviceCoarsen(HYPRE_Int on);
  * distributed levels on the host (OpenMP loops); negative: unchanged.  Returns the previous setting.  The reference's device
  * routines: par_coarsen_device.c:30, par_lr_interp_device.c:1001, parcsr_mv/par_csr_triplemat.c:938-960. */
 HYPRE_Int hypre_amd_SetSetupDeviceDist(HYPRE_Int on);
+/* Test hook of the distributed device setup: rank `rank` pretends, `count` times, that the device kernel of step `what`
+ * (1 interpolation, 2 product rows made for the neighbours, 3 Galerkin product) could not fit a row into its tables.  Every
+ * rank then repeats that step with the host routine — the agreed fall-back, which real problems reach only through rows of
+ * more than a thousand entries. */
+HYPRE_Int hypre_amd_SetupDistTestDecline(HYPRE_Int what, HYPRE_Int rank, HYPRE_Int count);
 /* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows, default 100000; 0: off) is recorded once as a
  * HIP graph and replayed: its kernels are a few microseconds each behind launches that cost as much.  No reference
  * counterpart (the reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded

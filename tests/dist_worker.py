@@ -68,7 +68,11 @@ def compare_setup(case, L, B, ij, O, dist, comm, rank, world):
         if on and case.get("matrix_on_device"):
             L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
         s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+        if on and "decline" in case:
+            # one rank's kernel "declines" a step once: all ranks repeat that step of that level with the host routine
+            L.hypre_amd_SetupDistTestDecline(int(case["decline"][0]), int(case["decline"][1]), 1)
         L.HYPRE_BoomerAMGSetup(s, A, None, None)
+        L.hypre_amd_SetupDistTestDecline(0, -1, 0)
         B.check()
         counts.append((L.hypre_amd_SetSetupDeviceCoarsen(-1), L.hypre_amd_SetSetupDeviceInterp(-1), L.hypre_amd_SetSetupDeviceRAP(-1, -1)))
         nl = L.hypre_amd_BoomerAMGGetNumLevels(s)

@@ -178,6 +178,11 @@ SETUP_CASES = {
     "pmax2_3ranks": (3, dict(n=[45, 16, 16], P=[3, 1, 1], relax_type=7, coarsen_type=8, P_max_elmts=2), {}),
     "cf_relax_l1_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, relax_order=1, coarsen_type=8), {}),
     "l1_gs_3ranks": (3, dict(n=[42, 18, 18], P=[3, 1, 1], relax_type=8, coarsen_type=8), {}),
+    # a rank's device kernel declines a step (tables too small for a row: here on request): every rank repeats the step
+    # with the host routine and the level's remaining steps follow on the host copies
+    "decline_interp_rank1_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, coarsen_type=8), {"decline": [1, 1]}),
+    "decline_product_rows_rank0_4ranks": (4, dict(n=[28, 28, 14], P=[2, 2, 1], problem="27pt", relax_type=11, coarsen_type=8), {"decline": [2, 0]}),
+    "decline_product_rank2_3ranks": (3, dict(n=[45, 16, 16], P=[3, 1, 1], relax_type=18, coarsen_type=8), {"decline": [3, 2]}),
     "strong_threshold_4ranks": (4, dict(n=[32, 32, 16], P=[2, 2, 1], relax_type=18, coarsen_type=8, strong_threshold=0.6, max_row_sum=0.8), {}),
 }
 _setup = {}
@@ -213,7 +218,7 @@ def test_distributed_device_setup_is_the_host_setup(name):
     # the host run coarsened nothing on the device, the device run at least two levels on every rank, interpolation and
     # Galerkin product included
     assert all(c[0] == 0 for c in out["host_counts"]), out["host_counts"]
-    assert all(min(c) >= 2 for c in out["device_counts"]), out["device_counts"]
+    assert all(min(c) >= (1 if "decline" in name else 2) for c in out["device_counts"]), out["device_counts"]
 
 
 # ... and the solve phase on hierarchies the device built (communication packages, row lists of the ghost blocks, stored
