@@ -265,6 +265,21 @@ def main():
     cycle_formula = L.hypre_amd_BoomerAMGCycleBytes(s)
     B.check()
 
+    # ---- what this box's memory sustains: a plain device copy (read + write), next to which box-to-box spread of the
+    # HBM-bound numbers above can be read (compute-bound kernels repeat to 0.5 % between boxes, the big SpMV launches to 4-7 %)
+    nb = 1 << 27                                                       # 1 GiB per vector
+    cx, cy = B.vec_from_numpy(np.zeros(nb)), B.vec_from_numpy(np.zeros(nb))
+    for _ in range(3):
+        L.hypre_SeqVectorCopy(cx, cy)
+    L.hypre_SyncComputeStream()
+    L.hypre_amd_EventTimerStart()
+    for _ in range(10):
+        L.hypre_SeqVectorCopy(cx, cy)
+    copy_gbs = 2.0 * 8.0 * nb / (L.hypre_amd_EventTimerStopMs() / 10) / 1e6
+    L.hypre_SeqVectorDestroy(cx)
+    L.hypre_SeqVectorDestroy(cy)
+    B.check()
+
     # ---- the caller of the path: AMG-preconditioned CG to 1e-8 (BASELINE configs solve with it) ----
     pcg_info = None
     try:
@@ -422,7 +437,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS)",
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms},
+                         "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms,
+                         "device_copy_GBps_this_box": copy_gbs},
             "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
                        "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS,
                        "streamed_bytes": cycle_streamed, "streamed_GBps": cycle_streamed / ms_per_step / 1e6,

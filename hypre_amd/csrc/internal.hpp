@@ -223,6 +223,19 @@ void launch_transpose(const int *Ai, const int *Aj, const double *Aa, int nrows,
                       hipStream_t s);     // device CSR transpose, rows of the result in ascending source-row order
 void launch_scan_exclusive(int *data, int n, hipStream_t s);
 void launch_sort_rows(const int *Ai, int *Aj, double *Aa, int n, int keep_first, hipStream_t s);   // columns ascending inside every row
+// multicolour Gauss-Seidel on the device (mc_kernels.hip, par_relax_mc.cpp)
+void preload_mc_kernels();
+void prepare_mc_plan(hypre_CSRMatrix *A);
+int  device_greedy_coloring(int n, const int *Ai, const int *Aj, const int *Ti, const int *Tj, int *color, int round_budget, hipStream_t s,
+                            int *rounds_out = nullptr);
+void device_color_order(int n, int C, const int *color, int **order_out, std::vector<int> &cstart, hipStream_t s);
+void device_color_matrices(int n, int C, const int *color, const int *order, const std::vector<int> &cstart, const int *Ai, const int *Aj,
+                           const double *Aa, int **ptr_out, int **Cj_out, double **Ca_out, std::vector<int> &slice0, std::vector<int> &slice_nnz,
+                           hipStream_t s);
+void launch_mc_diag(int n, const int *Ai, const double *Aa, double *d, hipStream_t s);
+void launch_mc_small_sweep(int num_colors, int direction, const int *cstart, const int *order, const int *Ai, const int *Aj,
+                           const double *Aa, const float *Aa32, const double *f, const double *d, const int *marker, int marker_val,
+                           double w, double *u, int n, int nnz, hipStream_t s);
 // one per kernel file: loads its code object (runtime.cpp: ensure_device)
 void preload_cheby_kernels(); void preload_gs_kernels(); void preload_interp_kernels(); void preload_vector_kernels();
 void preload_rap_kernels(); void preload_setup_kernels(); void preload_spmv_kernels();

@@ -2335,6 +2335,9 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
          const bool two_stage = last ? (gt[3] == 11 || gt[3] == 12) : (gt[1] == 11 || gt[1] == 12 || gt[2] == 11 || gt[2] == 12);
          hypre_CSRMatrix *Ad = d->A_array[l]->diag;
          if (two_stage && single_rank && Ad->memory_location == HYPRE_MEMORY_DEVICE && Ad->num_nonzeros > 0) { plan_of(strict_lower_of(Ad)); }
+         // multicolour Gauss-Seidel: the colouring and the colour classes (device kernels) belong to the setup as well
+         auto mc = [](HYPRE_Int t) { return t == 21 || t == 22; };
+         if (last ? mc(gt[3]) : (mc(gt[1]) || mc(gt[2]))) { prepare_mc_plan(Ad); }
       }
       hypre_ParVectorMigrate(d->Vtemp, HYPRE_MEMORY_DEVICE);
       hypre_ParVectorMigrate(d->Ztemp, HYPRE_MEMORY_DEVICE);

@@ -9,14 +9,21 @@
 // the oracle's hybrid forward sweep (relax 3) applied to P A P^T with P the colour permutation, relax 22 the backward
 // one (relax 4); tests/test_multicolor_gpu.py.
 //
-// Setup (first sweep on a matrix, cached beside its SpMV plan): greedy first-fit colouring of the pattern of
-// diag + diag^T on the host, then one CSR matrix per colour holding that colour's rows (original column numbering)
-// and the list of their row numbers.  A sweep is one pass of the tiled SpMV kernel per colour with the Jacobi epilogue
-// written IN PLACE through the row list: u[i] += w (f[i] - (A u)[i]) / a_ii for the rows i of the colour.  The whole
-// matrix is streamed once per sweep, as in the fused Jacobi sweep; the price is one launch per colour and the
-// strided vector traffic of the epilogue.
+// Setup (inside HYPRE_BoomerAMGSetup for the levels of a hierarchy smoothed with relax 21 / 22; on the first sweep for a
+// matrix handed to the public entry point; cached beside the SpMV plan), all of it on the device (mc_kernels.hip): greedy
+// first-fit colouring in row order of the pattern of diag + diag^T, then
+//   * large levels: one CSR matrix per colour holding that colour's rows (original column numbering) and the list of
+//     their row numbers; a sweep is one pass of the tiled SpMV kernel per colour with the Jacobi epilogue written IN PLACE
+//     through the row list: u[i] += w (f[i] - (A u)[i]) / a_ii for the rows i of the colour.  The whole matrix is
+//     streamed once per sweep, as in the fused Jacobi sweep; the price is one launch per colour and the strided vector
+//     traffic of the epilogue;
+//   * small levels (at most 1.5 M entries): the rows listed colour by colour, and ONE kernel of one workgroup that sweeps
+//     all colours with a workgroup barrier between them, on the level's own matrix: the coarse levels have 15 - 40
+//     colours of a few hundred rows each, and a launch per colour is 5 us of latency around nothing (346 launches per
+//     cycle at 256^3 before, a third of the cycle).
 #include "amg_internal.hpp"
 #include <algorithm>
+#include <omp.h>
 #include <unordered_map>
 #include <vector>
 
@@ -30,11 +37,17 @@ struct McPlan
    const HYPRE_Complex *key_a = nullptr;
    int n = 0, nnz = 0;
    int num_colors = 0;
-   std::vector<hypre_CSRMatrix *> rows_of;     // [num_colors] device CSR: the rows of one colour
-   std::vector<int *>             rowmap;      // [num_colors] device: original row number of every row of rows_of[c]
+   bool small = false;                         // swept by the one-workgroup kernel: no per-colour matrices
+   std::vector<hypre_CSRMatrix *> rows_of;     // [num_colors] device CSR views: the rows of one colour (large levels)
    std::vector<int>               count;       // rows per colour
+   std::vector<int>               cstart;      // [num_colors + 1] where every colour starts in d_order
+   int    *d_cstart = nullptr;                 // the same on the device
+   int    *d_order = nullptr;                  // [n] the rows colour by colour, ascending inside a colour
+   int    *d_ptr = nullptr, *d_cj = nullptr;   // large levels: the colour-sorted copy of the matrix the views point into
+   double *d_ca = nullptr;
    int    *d_color = nullptr;                  // [n] colour of every row (device; for the tests / oracle)
    double *d_diag = nullptr;                   // [n] first entry of every row (the diagonal), zero replaced by one
+   const int *rowmap(int c) const { return d_order + cstart[(size_t) c]; }
 };
 
 std::unordered_map<const hypre_CSRMatrix *, McPlan *> &mc_table()
@@ -46,44 +59,18 @@ std::unordered_map<const hypre_CSRMatrix *, McPlan *> &mc_table()
 void free_mc(McPlan *m)
 {
    if (!m) { return; }
-   for (hypre_CSRMatrix *c : m->rows_of) { if (c) { hypre_CSRMatrixDestroy(c); } }
-   for (int *r : m->rowmap) { if (r) { hypre_Free(r, HYPRE_MEMORY_DEVICE); } }
+   for (hypre_CSRMatrix *c : m->rows_of) { if (c) { hypre_CSRMatrixDestroy(c); } }        // views: drops their plans only
+   if (m->d_cstart) { HIP_CHECK(hipFree(m->d_cstart)); }
+   if (m->d_order) { HIP_CHECK(hipFree(m->d_order)); }
+   if (m->d_ptr) { HIP_CHECK(hipFree(m->d_ptr)); }
+   if (m->d_cj) { HIP_CHECK(hipFree(m->d_cj)); }
+   if (m->d_ca) { HIP_CHECK(hipFree(m->d_ca)); }
    if (m->d_color) { hypre_Free(m->d_color, HYPRE_MEMORY_DEVICE); }
    if (m->d_diag) { hypre_Free(m->d_diag, HYPRE_MEMORY_DEVICE); }
    delete m;
 }
 
-// Greedy first-fit colouring in row order over the symmetrised pattern: colour[i] = smallest colour no neighbour
-// j (a_ij != 0 or a_ji != 0 stored, j != i) carries yet.
-void greedy_coloring(int n, const int *Ai, const int *Aj, std::vector<int> &color, int &num_colors)
-{
-   // transpose pattern (only needed where the pattern is not symmetric; building it is cheaper than testing)
-   std::vector<int> ti((size_t) n + 1, 0);
-   for (int i = 0; i < n; i++) { for (int k = Ai[i]; k < Ai[i + 1]; k++) { const int j = Aj[k]; if (j >= 0 && j < n && j != i) { ti[(size_t) j + 1]++; } } }
-   for (int i = 0; i < n; i++) { ti[(size_t) i + 1] += ti[(size_t) i]; }
-   std::vector<int> tj((size_t) std::max(ti[(size_t) n], 1)), pos(ti.begin(), ti.end() - 1);
-   for (int i = 0; i < n; i++) { for (int k = Ai[i]; k < Ai[i + 1]; k++) { const int j = Aj[k]; if (j >= 0 && j < n && j != i) { tj[(size_t) pos[(size_t) j]++] = i; } } }
-   color.assign((size_t) std::max(n, 1), -1);
-   std::vector<int> mark;          // mark[c] == i: colour c is taken by a neighbour of row i
-   num_colors = 0;
-   for (int i = 0; i < n; i++)
-   {
-      for (int k = Ai[i]; k < Ai[i + 1]; k++)
-      {
-         const int j = Aj[k];
-         if (j >= 0 && j < n && j != i && color[(size_t) j] >= 0) { mark[(size_t) color[(size_t) j]] = i; }
-      }
-      for (int k = ti[(size_t) i]; k < ti[(size_t) i + 1]; k++)
-      {
-         const int j = tj[(size_t) k];
-         if (color[(size_t) j] >= 0) { mark[(size_t) color[(size_t) j]] = i; }
-      }
-      int c = 0;
-      while (c < num_colors && mark[(size_t) c] == i) { c++; }
-      if (c == num_colors) { num_colors++; mark.push_back(-1); }
-      color[(size_t) i] = c;
-   }
-}
+constexpr int MC_SMALL_NNZ = 200000;           // levels of at most this many entries are swept by one workgroup
 
 McPlan *get_mc(hypre_CSRMatrix *A)
 {
@@ -98,60 +85,56 @@ McPlan *get_mc(hypre_CSRMatrix *A)
    }
    McPlan *m = new McPlan();
    m->key_i = A->i; m->key_j = A->j; m->key_a = A->data; m->n = A->num_rows; m->nnz = A->num_nonzeros;
-   const int n = A->num_rows, nnz = A->num_nonzeros;
-   std::vector<int> hi((size_t) n + 1, 0), hj((size_t) std::max(nnz, 1));
-   std::vector<double> ha((size_t) std::max(nnz, 1));
-   HIP_CHECK(hipStreamSynchronize(stream()));
-   hypre_TMemcpy(hi.data(), A->i, HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_HOST, A->memory_location);
-   if (nnz > 0)
-   {
-      hypre_TMemcpy(hj.data(), A->j, HYPRE_Int, (size_t) nnz, HYPRE_MEMORY_HOST, A->memory_location);
-      hypre_TMemcpy(ha.data(), A->data, HYPRE_Complex, (size_t) nnz, HYPRE_MEMORY_HOST, A->memory_location);
-   }
-   std::vector<int> color;
-   greedy_coloring(n, hi.data(), hj.data(), color, m->num_colors);
-   const int C = m->num_colors;
-   m->count.assign((size_t) C, 0);
-   std::vector<long long> cnnz((size_t) C, 0);
-   for (int i = 0; i < n; i++) { m->count[(size_t) color[(size_t) i]]++; cnnz[(size_t) color[(size_t) i]] += hi[(size_t) i + 1] - hi[(size_t) i]; }
-   m->rows_of.assign((size_t) C, nullptr);
-   m->rowmap.assign((size_t) C, nullptr);
-   std::vector<std::vector<int>> ci((size_t) C), cj((size_t) C), cr((size_t) C);
-   std::vector<std::vector<double>> ca((size_t) C);
-   for (int c = 0; c < C; c++)
-   {
-      ci[(size_t) c].reserve((size_t) m->count[(size_t) c] + 1); ci[(size_t) c].push_back(0);
-      cj[(size_t) c].reserve((size_t) cnnz[(size_t) c]); ca[(size_t) c].reserve((size_t) cnnz[(size_t) c]);
-      cr[(size_t) c].reserve((size_t) m->count[(size_t) c]);
-   }
-   std::vector<double> diag((size_t) std::max(n, 1), 1.0);
-   for (int i = 0; i < n; i++)
-   {
-      const size_t c = (size_t) color[(size_t) i];
-      for (int k = hi[(size_t) i]; k < hi[(size_t) i + 1]; k++) { cj[c].push_back(hj[(size_t) k]); ca[c].push_back(ha[(size_t) k]); }
-      ci[c].push_back((int) cj[c].size());
-      cr[c].push_back(i);
-      if (hi[(size_t) i + 1] > hi[(size_t) i] && ha[(size_t) hi[(size_t) i]] != 0.0) { diag[(size_t) i] = ha[(size_t) hi[(size_t) i]]; }
-   }
-   for (int c = 0; c < C; c++)
-   {
-      const int nr = m->count[(size_t) c], nz = (int) cj[(size_t) c].size();
-      hypre_CSRMatrix *M = hypre_CSRMatrixCreate(nr, A->num_cols, nz);
-      hypre_CSRMatrixInitialize_v2(M, 0, HYPRE_MEMORY_DEVICE);
-      hypre_TMemcpy(M->i, ci[(size_t) c].data(), HYPRE_Int, (size_t) nr + 1, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-      if (nz > 0)
-      {
-         hypre_TMemcpy(M->j, cj[(size_t) c].data(), HYPRE_Int, (size_t) nz, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-         hypre_TMemcpy(M->data, ca[(size_t) c].data(), HYPRE_Complex, (size_t) nz, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-      }
-      m->rows_of[(size_t) c] = M;
-      m->rowmap[(size_t) c] = hypre_TAlloc(int, (size_t) std::max(nr, 1), HYPRE_MEMORY_DEVICE);
-      hypre_TMemcpy(m->rowmap[(size_t) c], cr[(size_t) c].data(), int, (size_t) nr, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
-   }
+   const int n = A->num_rows;
+   hipStream_t s = stream();
+   const bool timing = getenv("HYPRE_AMD_SETUP_TIMING") != nullptr;
+   const double t0 = omp_get_wtime();
+   int rounds = 0;
    m->d_color = hypre_TAlloc(int, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
-   hypre_TMemcpy(m->d_color, color.data(), int, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
    m->d_diag = hypre_TAlloc(double, (size_t) std::max(n, 1), HYPRE_MEMORY_DEVICE);
-   hypre_TMemcpy(m->d_diag, diag.data(), double, (size_t) n, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
+   if (n > 0)
+   {
+      // pattern of A^T (device transpose), then the colouring.  Row order for as long as its dependency chains are those
+      // of a grid (a 256^3 grid: 766 rounds); past 1500 rounds the hashed order takes over (irregular coarse levels, whose
+      // chains run into the thousands: their colour counts are the same either way)
+      hypre_CSRMatrix *AT = nullptr;
+      hypre_CSRMatrixTranspose(A, &AT, 0);
+      static const int budget = [] { const char *e = getenv("HYPRE_AMD_MC_ROUND_BUDGET"); return e ? atoi(e) : 1500; }();
+      m->num_colors = device_greedy_coloring(n, A->i, A->j, AT->i, AT->j, m->d_color, budget, s, &rounds);
+      hypre_CSRMatrixDestroy(AT);
+      launch_mc_diag(n, A->i, A->data, m->d_diag, s);
+   }
+   const int C = m->num_colors;
+   const double t1 = omp_get_wtime();
+   device_color_order(n, C, m->d_color, &m->d_order, m->cstart, s);
+   m->count.assign((size_t) C, 0);
+   for (int c = 0; c < C; c++) { m->count[(size_t) c] = m->cstart[(size_t) c + 1] - m->cstart[(size_t) c]; }
+   HIP_CHECK(hipMalloc((void **) &m->d_cstart, sizeof(int) * ((size_t) C + 1)));
+   HIP_CHECK(hipMemcpyAsync(m->d_cstart, m->cstart.data(), sizeof(int) * ((size_t) C + 1), hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   m->small = A->num_nonzeros <= MC_SMALL_NNZ;
+   if (!m->small)
+   {
+      std::vector<int> slice0, slice_nnz;
+      device_color_matrices(n, C, m->d_color, m->d_order, m->cstart, A->i, A->j, A->data, &m->d_ptr, &m->d_cj, &m->d_ca, slice0, slice_nnz, s);
+      m->rows_of.assign((size_t) C, nullptr);
+      for (int c = 0; c < C; c++)
+      {
+         hypre_CSRMatrix *M = hypre_CSRMatrixCreate(m->count[(size_t) c], A->num_cols, slice_nnz[(size_t) c]);
+         M->i = m->d_ptr + m->cstart[(size_t) c] + c;
+         M->j = m->d_cj + slice0[(size_t) c];
+         M->data = m->d_ca + slice0[(size_t) c];
+         M->memory_location = HYPRE_MEMORY_DEVICE;
+         M->owns_data = 0;
+         m->rows_of[(size_t) c] = M;
+         if (M->num_rows > 0 && M->num_nonzeros > 0) { (void) get_plan(M); }    // the colour's SpMV plan: part of the setup
+      }
+   }
+   if (timing)
+   {
+      fprintf(stderr, "   multicolour plan: %d rows, %d colours, colouring %.3fs (%d rounds), classes%s %.3fs\n", n, C, t1 - t0, rounds,
+              m->small ? "" : " + matrices + plans", omp_get_wtime() - t1);
+   }
    t[A] = m;
    return m;
 }
@@ -172,6 +155,12 @@ double *mc_scratch(size_t n)
 }  // namespace
 
 namespace hamd {
+// colouring and colour classes of a device matrix now rather than at its first sweep (the setup calls this for the levels
+// a hierarchy smooths with relax 21 / 22)
+void prepare_mc_plan(hypre_CSRMatrix *A)
+{
+   if (A && A->memory_location == HYPRE_MEMORY_DEVICE && A->num_rows > 0) { (void) get_mc(A); }
+}
 void drop_mc_plan(const hypre_CSRMatrix *A)
 {
    auto &t = mc_table();
@@ -237,6 +226,13 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
    }
    const double *d = diag ? diag : m->d_diag;
    const int C = m->num_colors;
+   if (m->small)
+   {
+      const bool masked = relax_points != 0 && cf_marker;
+      launch_mc_small_sweep(C, direction, m->d_cstart, m->d_order, dg->i, dg->j, dg->data, handle().fp32_values ? fp32_values_of(dg) : nullptr,
+                            ft, d, masked ? cf_marker : nullptr, relax_points, relax_weight, ud, n, dg->num_nonzeros, s);
+   }
+   else
    for (int q = 0; q < C; q++)
    {
       const int c = direction > 0 ? q : C - 1 - q;
@@ -248,7 +244,7 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
       a.x = ud; a.b = ft; a.y = ud; a.aux = nullptr; a.d = d;
       a.marker = cf_marker; a.marker_val = relax_points;
       a.alpha = relax_weight; a.beta = 0.0; a.fill = HYPRE_SPMV_FILL_WHOLE; a.row_offset = 0;
-      a.rowmap = m->rowmap[(size_t) c];
+      a.rowmap = m->rowmap(c);
       spmv_default_flags(a);
       if (!(relax_points != 0 && cf_marker)) { a.marker = nullptr; }
       launch_spmv(plan, a, OP_JACOBI_MAP, s);

@@ -117,7 +117,7 @@ bool ensure_device()
    }
    h.device_ok = true;
    preload_cheby_kernels(); preload_gs_kernels(); preload_interp_kernels(); preload_vector_kernels();
-   preload_rap_kernels(); preload_setup_kernels(); preload_spmv_kernels(); preload_dist_setup_kernels();
+   preload_rap_kernels(); preload_setup_kernels(); preload_spmv_kernels(); preload_dist_setup_kernels(); preload_mc_kernels();
    return true;
 }
 
