@@ -188,6 +188,7 @@ PROTOTYPES = {
     "hypre_CSRMatrixMatvecDevice": (Int, [Int, Real, CSRp, Vecp, Real, Vecp, Vecp, Int]),
     "hypre_CSRMatrixSpMVDevice": (Int, [Int, Real, CSRp, Vecp, Real, Vecp, Int]),
     "hypre_amd_CSRMatrixInvalidatePlan": (Int, [CSRp]),
+    "hypre_amd_CSRMatrixSortRows": (Int, [CSRp, Int]),
     "hypre_amd_SpmvSetBandPolicy": (Int, [Int, Int, Int]),
     "hypre_amd_SpmvSetVariant": (Int, [Int, Int]),
     "hypre_amd_CSRMatrixPlanInfo": (Int, [CSRp, IntP, IntP]),

@@ -533,9 +533,8 @@ void launch_scan_exclusive(int *data, int n, hipStream_t s)
 }
 // Columns of every row in ascending order, the first entry (the diagonal of a square block) left in front.  One wave per
 // row: bitonic network over the row in LDS.  Rows longer than the network (2048 entries) are left as they are.
-// Why: the x-staged SpMV reads a lane's consecutive entries from LDS positions that follow the columns' order; with the
-// first-touch order a Galerkin product leaves, the eight reads of a lane scatter over the staged copy and half of the
-// LDS cycles are bank conflicts (levels 1 - 2 of the benchmark hierarchy: 6 % slower than with sorted rows).
+// (A utility, hypre_amd_CSRMatrixSortRows: the x-staged SpMV runs no faster on sorted rows — measured on one and the same
+// allocation, tools/experiments/sorted_rows_inplace.py — so the setup leaves the Galerkin products' first-touch order.)
 constexpr int SORT_CAP = 2048;
 __global__ __launch_bounds__(64)
 void sort_rows_kernel(int n, const int *__restrict__ Ai, int *__restrict__ Aj, double *__restrict__ Aa, int keep_first)

@@ -2303,25 +2303,6 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
             a->data = dd; a->memory_location = HYPRE_MEMORY_DEVICE;
          }
       }
-      // The coarse operators come out of the Galerkin products with their columns in first-touch order — the order the
-      // next level's strength, coarsening and product were computed from, so it had to stay until now.  The solve phase
-      // is faster on rows whose columns ascend (a lane's consecutive entries then read consecutive positions of the staged
-      // x: half of the LDS bank conflicts of levels 1 - 2 go, 6 % of their SpMV time), and nothing downstream depends on
-      // the order except the last bits of a row's sum: the device-resident operators below the finest are sorted in place,
-      // diagonal kept in front (HYPRE_AMD_SORT_COARSE_ROWS=0 keeps the first-touch order).
-      static const bool sort_rows = [] { const char *e = getenv("HYPRE_AMD_SORT_COARSE_ROWS"); return e ? atoi(e) != 0 : true; }();
-      if (sort_rows)
-      {
-         for (int l = 1; l < num_levels; l++)
-         {
-            hypre_CSRMatrix *Ad = d->A_array[l]->diag;
-            if (Ad->memory_location == HYPRE_MEMORY_DEVICE && Ad->num_nonzeros > 0)
-            {
-               drop_plan(Ad);
-               launch_sort_rows(Ad->i, Ad->j, Ad->data, Ad->num_rows, 1, stream());
-            }
-         }
-      }
       // the kernels' per-matrix plans (tile bounds, placement tables, x-staging descriptors and local indices) are part of
       // the setup: built here, not inside the first cycle
       for (int l = 0; l < num_levels; l++)

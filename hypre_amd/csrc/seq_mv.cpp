@@ -413,6 +413,17 @@ extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanStaging(hypre_CSRMatrix *A, HYPRE_In
    return (HYPRE_Int) staged;
 }
 
+// Columns ascending inside every row of a device matrix, in place (keep_first != 0: the first entry of a row — the
+// diagonal of a square block — stays in front); the matrix's plan is dropped.
+extern "C" HYPRE_Int hypre_amd_CSRMatrixSortRows(hypre_CSRMatrix *A, HYPRE_Int keep_first)
+{
+   HYPRE_AMD_REQUIRE_DEVICE(A->memory_location, "hypre_amd_CSRMatrixSortRows(A)");
+   hamd::drop_plan(A);
+   if (A->num_nonzeros > 0) { hamd::launch_sort_rows(A->i, A->j, A->data, A->num_rows, keep_first, hamd::stream()); }
+   hamd::maybe_sync();
+   return hypre_error_flag;
+}
+
 extern "C" HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A)
 {
    drop_plan(A);

@@ -132,6 +132,10 @@ HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_
  * Call after changing i/j/data in place or before freeing arrays that the
  * library does not own. */
 HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A);
+/* Columns ascending inside every row of a device matrix, in place (keep_first != 0: a row's first entry — the diagonal of a
+ * square block, seq_mv/csr_matop.c:1536-1604 — stays in front); the plan is dropped.  A utility (the reference's
+ * hypre_CSRMatrixSortRow, seq_mv/csr_matop.c, for device matrices); nothing on the solve path needs sorted rows. */
+HYPRE_Int hypre_amd_CSRMatrixSortRows(hypre_CSRMatrix *A, HYPRE_Int keep_first);
 /* Tile -> XCD placement policy of the plans built from now on (speed only; no reference
  * counterpart): enabled 0/1, min_tiles = smallest matrix, in 2048-entry tiles, that gets a
  * placement table, force != 0 also drops the minimum slab size so that small (test) matrices

@@ -2,7 +2,7 @@
 # copy the judged summaries of tools/r03_measure.sh (+ tools/pmc_levels.sh) from gpurun_out/ (scratch) into profiles/ (tracked)
 set -e
 m=gpurun_out/${1:-r03_measure}
-for f in c2 c4 c5 rehearsal_dev2 rehearsal_host2 rehearsal_dev4; do tail -1 $m/bench_$f.json > profiles/r03_bench_$f.json; done
+for f in c2 c4 c4_again c5 mc128 mc256 rehearsal_dev2 rehearsal_host2 rehearsal_dev4; do tail -1 $m/bench_$f.json > profiles/r03_bench_$f.json; done
 cp $m/prof_c2/b_kernel_stats.csv profiles/r03_bench256_kernel_stats.csv
 cp $m/prof_c4/b_kernel_stats.csv profiles/r03_c4_27pt256_tsgs_kernel_stats.csv
 cp $m/prof_c5/b_kernel_stats.csv profiles/r03_c5_difconv256_mixed_kernel_stats.csv

@@ -9,6 +9,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c2 -o b --output
 timeout -k 10 400 python bench.py --problem 27pt --relax 11 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c4 -o b --output-format csv -- python3 bench.py --problem 27pt --relax 11 --no-cpu-baseline > $out/prof_c4.log 2>&1
 timeout -k 10 300 python bench.py --problem difconv --mixed > $out/bench_c5.json 2> $out/bench_c5.err; echo "c5 exit $?"
+timeout -k 10 400 python bench.py --problem 27pt --relax 11 --no-cpu-baseline > $out/bench_c4_again.json 2> $out/bench_c4_again.err; echo "c4 again exit $?"
+timeout -k 10 300 python bench.py --relax 21 --relax-up 22 --cpu-cycles 1 > $out/bench_mc256.json 2> $out/bench_mc256.err; echo "mc256 exit $?"
+timeout -k 10 300 python bench.py --grid 128 --relax 21 --relax-up 22 --cpu-cycles 1 > $out/bench_mc128.json 2> $out/bench_mc128.err; echo "mc128 exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c5 -o b --output-format csv -- python3 bench.py --problem difconv --mixed --no-cpu-baseline > $out/prof_c5.log 2>&1
 timeout -k 10 300 python tools/bench_levels.py 256 20 --variants 2 --json $out/levels_7pt.json > $out/levels_7pt.log 2>&1; echo "levels 7pt exit $?"
 timeout -k 10 300 python tools/bench_levels.py 256 20 --variants 2 --problem 27pt --relax 11 --json $out/levels_27pt.json > $out/levels_27pt.log 2>&1; echo "levels 27pt exit $?"
