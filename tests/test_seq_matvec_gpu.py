@@ -350,3 +350,40 @@ def test_a_plan_that_outlived_its_matrix_is_found_out(gpu_lib, oracle, how):
     for o in (dx, dy):
         lib.hypre_SeqVectorDestroy(o)
     lib.hypre_CSRMatrixDestroy(dA)
+
+
+def test_sort_rows_and_byte_counters(gpu_lib, oracle):
+    """hypre_amd_CSRMatrixSortRows: columns ascending inside every row, a row's first entry kept in front, the product
+    unchanged up to the order of a row's sum.  hypre_amd_ByteCounters: one product accounts for the SURVEY 8(d) count of its
+    matrix (12 bytes per entry, row pointers, x once, y once) and for 2 bytes less per entry streamed where x is staged."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = random_csr(7000, 7000, 3, 60, seed=21)
+    x = rand_vector(7000, 4)
+    dA = B.csr_from_scipy(A)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(7000))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)          # builds the plan
+    csr, streamed = C.c_double(), C.c_double()
+    lib.hypre_amd_ByteCounters(None, None, 1)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    lib.hypre_amd_ByteCounters(C.byref(csr), C.byref(streamed), 1)
+    nnz, n = A.nnz, 7000
+    assert csr.value == nnz * 12 + (n + 1) * 4 + n * 8 + n * 8
+    assert streamed.value in (csr.value, csr.value - 2 * nnz)
+    y0 = B.vec_to_numpy(dy)
+    lib.hypre_amd_CSRMatrixSortRows(dA, 1)
+    B.check()
+    ii, jj, aa = B.csr_to_arrays(dA)
+    assert np.array_equal(ii, A.indptr)
+    for r in (0, 1, 17, 3500, 6999):
+        b, e = ii[r], ii[r + 1]
+        assert jj[b] == A.indices[b] and aa[b] == A.data[b]                        # first entry stays
+        assert np.all(np.diff(jj[b + 1:e]) > 0)                                     # the rest ascends
+        assert sorted(zip(jj[b:e], aa[b:e])) == sorted(zip(A.indices[b:e], A.data[b:e]))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - y0) <= _bound(A, x, 1.0, 0.0, x))
+    for o in (dx, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
