@@ -141,6 +141,24 @@ struct SpmvPlan
    int            *d_stale = nullptr;    // the same word as the device sees it
 };
 void bump_plan_generation();
+// A sampled fingerprint of a device CSR matrix — row pointers, columns and, if asked, values at 4096 positions spread over
+// it — kept on the device, and a pinned flag that a checking launch raises when the matrix no longer matches.  For the
+// caches that pre-digest a matrix and are found again by its address (colour classes: a colour-sorted COPY of the values;
+// level schedules of the hybrid sweeps: the dependency levels of the pattern): the same exposure as the SpMV plan's — the
+// caller frees the matrix with hypre's own destroy routine, the next one lands on the same addresses.
+struct MatrixWatch
+{
+   unsigned long long *d_fp = nullptr;
+   int *h_stale = nullptr, *d_stale = nullptr;
+};
+void watch_record(MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hipStream_t s);
+void watch_check(const MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hipStream_t s);    // one small launch
+bool watch_flagged(const MatrixWatch &w);
+void watch_release(MatrixWatch &w);
+int *take_stale_slot(int **device_view);      // a word of pinned, device-visible host memory (nullptr: none to be had)
+void give_stale_slot(int *slot);
+void launch_matrix_fingerprint(const int *Ai, const int *Aj, const double *Aa, int n, int nnz, unsigned long long *fp, int *stale,
+                               int record, hipStream_t s);
 unsigned long long plan_generation();    // bumped whenever a plan (or a colour plan) is freed: recorded graphs watch it
 bool plan_is_stale(const hypre_CSRMatrix *A);   // the plan of A, if one exists, was flagged by a kernel
 void launch_build_fp(const HYPRE_Int *Aj, int nnz, int num_tiles, int *fp, hipStream_t s);

@@ -590,6 +590,45 @@ void launch_sort_rows(const int *Ai, int *Aj, double *Aa, int n, int keep_first,
    hipLaunchKernelGGL(sort_rows_kernel, dim3(grid), dim3(64), 0, s, n, Ai, Aj, Aa, keep_first);
 }
 
+// fingerprint of a CSR matrix over 4096 positions spread over its rows and entries (MatrixWatch, internal.hpp)
+__global__ __launch_bounds__(256)
+void matrix_fingerprint_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa, int n, int nnz,
+                               unsigned long long *fp, int *stale, int record)
+{
+   auto mix = [](unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; };
+   unsigned long long h = 0ull;
+   for (int q = 0; q < 16; q++)
+   {
+      const long long k = (long long) threadIdx.x * 16 + q;
+      if (n > 0) { const int r = (int) (k * n / 4096); h ^= mix((unsigned long long) (unsigned) Ai[r + 1] + ((unsigned long long) k << 32)); }
+      if (nnz > 0)
+      {
+         const int p = (int) (k * nnz / 4096);
+         h ^= mix((unsigned long long) (unsigned) Aj[p] + ((unsigned long long) (k + 4096) << 32));
+         if (Aa) { h ^= mix((unsigned long long) __double_as_longlong(Aa[p]) + (unsigned long long) k); }
+      }
+   }
+   for (int off = 32; off > 0; off >>= 1)
+   {
+      const unsigned lo = __shfl_xor((unsigned) h, off, 64), hi = __shfl_xor((unsigned) (h >> 32), off, 64);
+      h ^= ((unsigned long long) hi << 32) | lo;
+   }
+   __shared__ unsigned long long part[4];
+   if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = h; }
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      h = part[0] ^ part[1] ^ part[2] ^ part[3];
+      if (record) { *fp = h; }
+      else if (*fp != h) { __hip_atomic_fetch_or(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+   }
+}
+void launch_matrix_fingerprint(const int *Ai, const int *Aj, const double *Aa, int n, int nnz, unsigned long long *fp, int *stale,
+                               int record, hipStream_t s)
+{
+   hipLaunchKernelGGL(matrix_fingerprint_kernel, dim3(1), dim3(256), 0, s, Ai, Aj, Aa, n, nnz, fp, stale, record);
+}
+
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s)
 { if (n > 0 && nv > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(((size_t) n * nv + 255) / 256), dim3(256), 0, s, in, out, n, nv); }
 void launch_interleave(const double *in, double *out, int n, int nv, hipStream_t s)

@@ -32,6 +32,7 @@ struct GsSchedule
    int              n = 0, nnz = 0, threads = 1;
    int              lanes = 8;      // lanes that share a row (power of two covering the average row)
    GsDirection      dir[2];         // 0 forward, 1 backward
+   MatrixWatch      watch;          // the levels come from the pattern: every sweep checks it is still the same
 };
 
 std::unordered_map<const hypre_CSRMatrix *, GsSchedule *> &gs_table()
@@ -48,6 +49,7 @@ void free_schedule(GsSchedule *g)
       if (g->dir[d].d_sched) { (void) hipFree(g->dir[d].d_sched); }
       if (g->dir[d].d_lev_start) { (void) hipFree(g->dir[d].d_lev_start); }
    }
+   watch_release(g->watch);
    delete g;
 }
 
@@ -118,9 +120,15 @@ GsSchedule *get_schedule(hypre_CSRMatrix *A, int threads)
    if (it != t.end())
    {
       GsSchedule *g = it->second;
-      if (g->key_i == A->i && g->key_j == A->j && g->n == A->num_rows && g->nnz == A->num_nonzeros && g->threads == threads)
+      const bool flagged = watch_flagged(g->watch);
+      if (!flagged && g->key_i == A->i && g->key_j == A->j && g->n == A->num_rows && g->nnz == A->num_nonzeros && g->threads == threads)
       {
          return g;
+      }
+      if (flagged)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hybrid Gauss-Seidel: the level schedule was built from another pattern than the one at this "
+                                                "address now: the sweeps since then are wrong; the schedule is rebuilt");
       }
       free_schedule(g);
       t.erase(it);
@@ -136,6 +144,7 @@ GsSchedule *get_schedule(hypre_CSRMatrix *A, int threads)
    g->lanes = avg <= 4.5 ? 4 : avg <= 9.0 ? 8 : avg <= 18.0 ? 16 : 32;
    build_direction(g->dir[0], n, threads, hi.data(), hj.data(), true);
    build_direction(g->dir[1], n, threads, hi.data(), hj.data(), false);
+   if (n > 0) { watch_record(g->watch, A, false, stream()); }
    t[A] = g;
    return g;
 }
@@ -214,6 +223,7 @@ extern "C" HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMat
    const bool zero_guess = u->all_zeros != 0;
    hypre_ParCSRCommHandle *ch = (nprocs > 1 && !zero_guess) ? dev_halo_begin(A, ud) : nullptr;
    GsSchedule *g = get_schedule(diag, std::max(1, std::min(handle().gs_threads, n)));
+   watch_check(g->watch, diag, false, s);
    dev_halo_end(ch);
 
    GsArgs a{};

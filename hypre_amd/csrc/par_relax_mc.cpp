@@ -47,6 +47,7 @@ struct McPlan
    double *d_ca = nullptr;
    int    *d_color = nullptr;                  // [n] colour of every row (device; for the tests / oracle)
    double *d_diag = nullptr;                   // [n] first entry of every row (the diagonal), zero replaced by one
+   MatrixWatch watch;                          // the classes hold COPIES of the matrix: every sweep checks it is still the same
    const int *rowmap(int c) const { return d_order + cstart[(size_t) c]; }
 };
 
@@ -67,6 +68,7 @@ void free_mc(McPlan *m)
    if (m->d_ca) { HIP_CHECK(hipFree(m->d_ca)); }
    if (m->d_color) { hypre_Free(m->d_color, HYPRE_MEMORY_DEVICE); }
    if (m->d_diag) { hypre_Free(m->d_diag, HYPRE_MEMORY_DEVICE); }
+   watch_release(m->watch);
    delete m;
 }
 
@@ -79,9 +81,17 @@ McPlan *get_mc(hypre_CSRMatrix *A)
    if (it != t.end())
    {
       McPlan *m = it->second;
-      if (m->key_i == A->i && m->key_j == A->j && m->key_a == A->data && m->n == A->num_rows && m->nnz == A->num_nonzeros) { return m; }
+      const bool flagged = watch_flagged(m->watch);
+      if (!flagged && m->key_i == A->i && m->key_j == A->j && m->key_a == A->data && m->n == A->num_rows && m->nnz == A->num_nonzeros) { return m; }
+      if (flagged)
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "multicolour Gauss-Seidel: the colour classes were built from another matrix than the one at "
+                                                "this address now (or its values changed without hypre_amd_CSRMatrixInvalidatePlan): the "
+                                                "sweeps since then are wrong; the classes are rebuilt");
+      }
       free_mc(m);
       t.erase(it);
+      bump_plan_generation();
    }
    McPlan *m = new McPlan();
    m->key_i = A->i; m->key_j = A->j; m->key_a = A->data; m->n = A->num_rows; m->nnz = A->num_nonzeros;
@@ -135,6 +145,7 @@ McPlan *get_mc(hypre_CSRMatrix *A)
       fprintf(stderr, "   multicolour plan: %d rows, %d colours, colouring %.3fs (%d rounds), classes%s %.3fs\n", n, C, t1 - t0, rounds,
               m->small ? "" : " + matrices + plans", omp_get_wtime() - t1);
    }
+   if (n > 0) { watch_record(m->watch, A, true, s); }
    t[A] = m;
    return m;
 }
@@ -210,6 +221,7 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
    const bool zero_guess = u->all_zeros != 0;
    hypre_ParCSRCommHandle *ch = (nprocs > 1 && !zero_guess) ? dev_halo_begin(A, ud) : nullptr;
    McPlan *m = get_mc(dg);
+   watch_check(m->watch, dg, true, s);          // (a mismatch is reported by the next call that asks for the classes)
    dev_halo_end(ch);
    // right-hand side with the ghost couplings folded in: ft = f - A_offd u_ghost
    const double *ft = fd;

@@ -162,6 +162,38 @@ struct StaleSlots
 StaleSlots &stale_slots() { static StaleSlots s; return s; }
 }  // namespace
 
+int *take_stale_slot(int **device_view)
+{
+   int *h = stale_slots().take();
+   int *d = nullptr;
+   if (h && hipHostGetDevicePointer((void **) &d, h, 0) != hipSuccess) { (void) hipGetLastError(); d = nullptr; }
+   if (!d) { stale_slots().give(h); h = nullptr; }
+   if (device_view) { *device_view = d; }
+   return h;
+}
+void give_stale_slot(int *slot) { stale_slots().give(slot); }
+
+void watch_record(MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hipStream_t s)
+{
+   watch_release(w);
+   w.h_stale = take_stale_slot(&w.d_stale);
+   if (!w.h_stale) { return; }
+   HIP_CHECK(hipMalloc((void **) &w.d_fp, sizeof(unsigned long long)));
+   launch_matrix_fingerprint(A->i, A->j, with_values ? A->data : nullptr, A->num_rows, A->num_nonzeros, w.d_fp, w.d_stale, 1, s);
+}
+void watch_check(const MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hipStream_t s)
+{
+   if (!w.d_fp) { return; }
+   launch_matrix_fingerprint(A->i, A->j, with_values ? A->data : nullptr, A->num_rows, A->num_nonzeros, w.d_fp, w.d_stale, 0, s);
+}
+bool watch_flagged(const MatrixWatch &w) { return w.h_stale && __atomic_load_n(w.h_stale, __ATOMIC_RELAXED) != 0; }
+void watch_release(MatrixWatch &w)
+{
+   if (w.d_fp) { HIP_CHECK(hipFree(w.d_fp)); }
+   give_stale_slot(w.h_stale);
+   w = MatrixWatch();
+}
+
 static void free_plan(SpmvPlan *p)
 {
    if (!p) { return; }

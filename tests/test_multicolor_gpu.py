@@ -190,3 +190,64 @@ def test_pcg_with_symmetric_multicolour_smoothing(gpu_lib, oracle):
     assert its == oits and abs(rel - orel) <= 1e-6 * orel
     jits = pcg(relax_type=18)[0]
     assert its < jits
+
+
+@pytest.mark.parametrize("relax_type", [21, 3])
+def test_caches_keyed_by_the_matrix_address_notice_another_matrix(gpu_lib, relax_type):
+    """The colour classes of relax 21 hold a colour-sorted COPY of the matrix, the level schedule of relax 3 the dependency
+    levels of its pattern; both are found again by the matrix's address.  A different matrix at the same address (the caller
+    freed the first with hypre's own destroy routine and built the next one of the same size) must not be swept with the old
+    one's classes silently: every sweep compares a sampled fingerprint of the matrix with the one taken when the cache was
+    built; a mismatch raises HYPRE_ERROR_GENERIC at the next call, which rebuilds, and the sweep after that is the new
+    matrix's (checked against a fresh copy of it at another address)."""
+    import scipy.sparse as sp
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A1 = B.laplacian(10, 9, 8, kind="27pt")
+    M1 = B.csr_to_scipy(A1.contents.diag)
+    n = M1.shape[0]
+    # relax 21 (the classes copy the values): other values on the same pattern
+    M2 = sp.csr_matrix((M1.data * 1.5, M1.indices.copy(), M1.indptr), shape=M1.shape)
+    if relax_type == 3:
+        # another PATTERN of the same size for the level schedule: reverse the off-diagonal part of every row
+        idx = M1.indices.copy()
+        for r in range(n):
+            b, e = M1.indptr[r], M1.indptr[r + 1]
+            idx[b + 1:e] = (n - 1 - M1.indices[b + 1:e])[::-1] if r % 2 else M1.indices[b + 1:e]
+            # a reflected column may coincide with the diagonal: keep such rows as they were
+            if r % 2 and (r in idx[b + 1:e] or len(set(idx[b + 1:e])) != e - b - 1):
+                idx[b + 1:e] = M1.indices[b + 1:e]
+        M2 = sp.csr_matrix((M1.data.copy(), idx.astype(np.int32), M1.indptr), shape=M1.shape)
+    lib.hypre_ParCSRMatrixMigrate(A1, B.HYPRE_MEMORY_DEVICE)
+    f = rand_vector(n, 7)
+    u0 = rand_vector(n, 8)
+
+    def sweep(Apar):
+        du, df, dv, dz = (B.parvec_from_numpy(u0), B.parvec_from_numpy(f), B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(np.zeros(n)))
+        lib.hypre_BoomerAMGRelax(Apar, df, None, relax_type, 0, 1.0, 1.0, None, du, dv, dz)
+        lib.hypre_SyncComputeStream()
+        return B.parvec_to_numpy(du)
+
+    sweep(A1)                                              # builds the cache for the matrix at this address
+    B.check()
+    d = A1.contents.diag.contents
+    for dst, src in ((d.j, np.ascontiguousarray(M2.indices, dtype=np.int32)), (d.data, np.ascontiguousarray(M2.data))):
+        lib.hypre_Memcpy(C.cast(dst, C.c_void_p), src.ctypes.data_as(C.c_void_p), src.nbytes, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+    sweep(A1)                                              # swept with the old cache: the launch notices ...
+    sweep(A1)                                              # ... this call reports it and rebuilds
+    assert lib.HYPRE_GetError() & 1
+    lib.HYPRE_ClearAllErrors()
+    got = sweep(A1)
+    B.check()
+    # the same matrix, built fresh at another address
+    A2 = B.laplacian(10, 9, 8, kind="27pt")
+    d2 = A2.contents.diag.contents
+    for dst, src in ((d2.j, np.ascontiguousarray(M2.indices, dtype=np.int32)), (d2.data, np.ascontiguousarray(M2.data))):
+        lib.hypre_Memcpy(C.cast(dst, C.c_void_p), src.ctypes.data_as(C.c_void_p), src.nbytes, B.HYPRE_MEMORY_HOST, B.HYPRE_MEMORY_HOST)
+    lib.hypre_ParCSRMatrixMigrate(A2, B.HYPRE_MEMORY_DEVICE)
+    want = sweep(A2)
+    B.check()
+    assert np.array_equal(got, want) if relax_type == 3 else np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want))
+    lib.hypre_ParCSRMatrixDestroy(A1)
+    lib.hypre_ParCSRMatrixDestroy(A2)
+    B.check()
