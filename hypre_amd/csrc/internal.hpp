@@ -120,6 +120,14 @@ struct SpmvPlan
    hypre_CSRMatrix *Lstrict = nullptr;
    // fp32 copy of the values for the mixed-precision path (lazily built)
    float *a32 = nullptr;
+   // Value codes (x-staged kernel only).  A matrix that holds at most 256 distinct values — a constant-coefficient stencil
+   // holds a handful — is streamed as one byte per entry plus the table of its values (sorted by bit pattern), which every
+   // tile stages in LDS beside its x pieces: 1 + 2 bytes per entry instead of 8 + 2, the products bit for bit the same.
+   // d_dict32 is the same table rounded through fp32 (what the mixed-precision path multiplies by).  Built with the plan
+   // (spmv_value_codes(): on by default); the staleness watch compares one decoded value per tile with the fp64 original.
+   unsigned char *d_codes = nullptr;   // [nnz rounded up to 16]
+   double        *d_dict = nullptr, *d_dict32 = nullptr;   // [256]
+   int            ndict = 0;
    // x staging (spmv_xs_kernel): per tile the number of column segments that cover its entries (0: they do not fit, gather
    // instead) and their descriptors (2 * SPMV_XS_SEGS ints per tile); per entry the index of its column in the tile's
    // staged copy
@@ -184,6 +192,10 @@ struct SpmvArgs
    const HYPRE_Int     *Aj;
    const HYPRE_Complex *Aa;
    const float         *Aa32;     // non-null selects fp32 matrix values
+   const unsigned char *Ac8;      // x-staged kernel: non-null selects value codes (filled from the plan by launch_spmv) ...
+   const double        *dict;     // ... and the table they index (ndict entries; allocated and readable up to 256)
+   int                  ndict;
+   int                  dict_rounded;   // the table was rounded through fp32 (mixed precision)
    const HYPRE_Complex *x;
    const HYPRE_Complex *b;        // may be null when beta == 0
    HYPRE_Complex       *y;
@@ -211,6 +223,10 @@ void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tun
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);
 void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s);
+// value codes of a matrix (nullptr / 0 when it holds more than 256 distinct values): codes[nnz], the sorted table, its fp32-rounded twin
+bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out, double **dict_out, double **dict32_out, int *ndict_out,
+                        hipStream_t s);
+bool &spmv_value_codes();              // plans built from now on look for value codes (default: on; HYPRE_AMD_SPMV_VALUE_CODES=0)
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
                         int *d_tile_k, hipStream_t s);
 void launch_build_xs(const HYPRE_Int *Aj, const int *d_tile_k, int num_tiles, int *xs_cnt, int *xs_desc, unsigned short *lidx,

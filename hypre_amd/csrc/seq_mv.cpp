@@ -207,6 +207,8 @@ static void free_plan(SpmvPlan *p)
    if (p->d_xs_desc) { HIP_CHECK(hipFree(p->d_xs_desc)); }
    if (p->d_lidx) { HIP_CHECK(hipFree(p->d_lidx)); }
    if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
+   if (p->d_codes) { HIP_CHECK(hipFree(p->d_codes)); }
+   if (p->d_dict) { HIP_CHECK(hipFree(p->d_dict)); }       // d_dict32 is its second half
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
    if (p->Lstrict) { hypre_CSRMatrixDestroy(p->Lstrict); }
    delete p;
@@ -332,11 +334,18 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
                }
             }
             p->prod_elems = std::max(p->prod_elems, 2 * p->xs_launch_units + 8);
+            if (spmv_value_codes()) { device_value_codes(A->data, (size_t) A->num_nonzeros, &p->d_codes, &p->d_dict, &p->d_dict32, &p->ndict, s); }
          }
       }
    }
    t[A] = p;
    return p;
+}
+
+bool &spmv_value_codes()
+{
+   static bool on = [] { const char *e = getenv("HYPRE_AMD_SPMV_VALUE_CODES"); return !(e && atoi(e) == 0); }();
+   return on;
 }
 
 bool plan_is_stale(const hypre_CSRMatrix *A)
@@ -414,6 +423,22 @@ extern "C" HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int unuse
    hamd::SpmvVariant &v = hamd::spmv_variant();
    if (variant >= 0) { v.variant = variant; }
    return hypre_error_flag;
+}
+
+// Value codes for the plans built from now on (existing plans keep theirs): a matrix that holds at most 256 distinct values
+// is streamed by the x-staged kernel as one byte per entry and a table.  Speed only: same products, bit for bit.
+extern "C" HYPRE_Int hypre_amd_SpmvSetValueCodes(HYPRE_Int on)
+{
+   if (on >= 0) { hamd::spmv_value_codes() = on != 0; }
+   return hypre_error_flag;
+}
+
+// number of distinct values in the value table of A's plan (built on demand); 0: the matrix is not coded
+extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanValueCodes(hypre_CSRMatrix *A)
+{
+   if (A->memory_location != HYPRE_MEMORY_DEVICE) { return 0; }
+   hamd::SpmvPlan *p = hamd::get_plan(A);
+   return p->d_codes ? p->ndict : 0;
 }
 
 // 1 when the plan of A (built on demand) carries a placement table, with the band distance it was built for

@@ -320,6 +320,7 @@ __device__ __forceinline__ void stream_consume(const SpmvArgs &p, int k0, int k1
       {
          const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
          v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+         if (p.dict_rounded) { v0 = (double) (float) v0; v1 = (double) (float) v1; v2 = (double) (float) v2; v3 = (double) (float) v3; }
       }
       double *dst = prod + (k - ka);
       if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
@@ -390,6 +391,7 @@ __device__ __forceinline__ void stream_consume_gt(const SpmvArgs &p, int k0, int
       {
          const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
          v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+         if (p.dict_rounded) { v0 = (double) (float) v0; v1 = (double) (float) v1; v2 = (double) (float) v2; v3 = (double) (float) v3; }
       }
       double *dst = prod + (k - ka);
       if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
@@ -508,17 +510,29 @@ constexpr int XS_CAP   = SPMV_XS_CAP;       // doubles a tile may stage at most 
 #endif
 constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first column of every piece, then (offset << 16 | length)
 
-template <int OP, bool F32, bool HASFILL>
+// VF, the form the matrix values are streamed in: 0 fp64, 1 fp32 (mixed precision), 2 one-byte codes into a table of at
+// most 256 values that every tile stages in LDS with its x pieces (SpmvPlan::d_codes).
+constexpr int VF_F64 = 0, VF_F32 = 1, VF_CODE = 2;
+constexpr int DICT_CAP = 256;
+// bytes of LDS in front of the value table: products, row sums, row pointers, rounded up to the table's 16-byte alignment
+__host__ __device__ inline size_t xs_dict_offset(int prod_elems, int rowsum_elems, int rp_cap)
+{
+   return (sizeof(double) * (size_t) (prod_elems + rowsum_elems) + sizeof(int) * (size_t) (rp_cap + 4) + 15) & ~(size_t) 15;
+}
+
+template <int OP, int VF, bool HASFILL>
 __global__ __launch_bounds__(SPMV_THREADS)
 void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
                     const int *__restrict__ xs_cnt, const int *__restrict__ xs_desc,
                     const unsigned short *__restrict__ lidx,
                     int num_tiles, int prod_elems, int rowsum_elems, int rp_cap, int xs_units)
 {
+   constexpr bool F32 = VF == VF_F32, CODED = VF == VF_CODE;
    extern __shared__ __align__(16) unsigned char smem_raw[];
    double *prod   = reinterpret_cast<double *>(smem_raw);     // staged x first, products after the second barrier
    double *rowsum = prod + prod_elems;
    int    *rp     = reinterpret_cast<int *>(rowsum + rowsum_elems);
+   const double *dictl = reinterpret_cast<const double *>(smem_raw + xs_dict_offset(prod_elems, rowsum_elems, rp_cap));   // CODED only
 
    int tile = (int) blockIdx.x;
    if (p.tile_perm)
@@ -547,8 +561,14 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    TileStream S;
    const int kA = ka + 4 * tid, kB = kA + 4 * SPMV_THREADS;
    const int qA = min(kA, p.last_quad), qB = min(kB, p.last_quad);
+   unsigned cdA = 0, cdB = 0;                   // CODED: four value codes each
 #if XS_EARLY_STREAM
-   if (F32)
+   if (CODED)
+   {
+      cdA = stream_load<unsigned>(p.Ac8 + qA);
+      cdB = stream_load<unsigned>(p.Ac8 + qB);
+   }
+   else if (F32)
    {
       S.fA = stream_load<v4f>(p.Aa32 + qA);
       S.fB = stream_load<v4f>(p.Aa32 + qB);
@@ -578,15 +598,33 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    double fv64 = 0.0;
    float  fv32 = 0.0f;
    if (F32) { fv64 = p.Aa[qs0]; fv32 = p.Aa32[qs0]; }
-   asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aa32), "s"(p.Aj), "s"(p.tile_fp) : "memory");
+   if (CODED) { fv64 = p.Aa[min(ka, p.last_quad)]; }      // the first entry lane 0 streams: compared once it is decoded
+   asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aa32), "s"(p.Aj), "s"(p.tile_fp), "s"(p.Ac8) : "memory");
    if (r1 <= r0) { return; }
    {
       bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1);
       if (F32) { off = off || ((float) fv64 != fv32); }
       if (off && tid == 0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
    }
+   if (CODED)
+   {
+      // the value table: 16 bytes per lane straight into LDS, in the same trip as the stream (the table is allocated, and
+      // readable, up to DICT_CAP entries whatever it holds)
+      const int dl = (p.ndict + 1) >> 1;                   // lanes the table takes
+      const int mine = dl - 64 * wave;
+      if (lane < mine)
+      {
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.dict + 128 * wave + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(const_cast<double *>(dictl)) + 1024 * wave), 16, 0, 0);
+      }
+   }
 #if !XS_EARLY_STREAM
-   if (F32)
+   if (CODED)
+   {
+      cdA = stream_load<unsigned>(p.Ac8 + qA);
+      cdB = stream_load<unsigned>(p.Ac8 + qB);
+   }
+   else if (F32)
    {
       S.fA = stream_load<v4f>(p.Aa32 + qA);
       S.fB = stream_load<v4f>(p.Aa32 + qB);
@@ -619,6 +657,19 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
          for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
       }
       const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
+      if (CODED)
+      {
+         // decode into the fp64 slots of the stream, then as the uncoded tile; the spill and the tail of a very long last
+         // row were read from the fp64 array by the calls above and below
+         __syncthreads();
+         S.vA01.x = dictl[cdA & 0xff]; S.vA01.y = dictl[(cdA >> 8) & 0xff]; S.vA23.x = dictl[(cdA >> 16) & 0xff]; S.vA23.y = dictl[cdA >> 24];
+         S.vB01.x = dictl[cdB & 0xff]; S.vB01.y = dictl[(cdB >> 8) & 0xff]; S.vB23.x = dictl[(cdB >> 16) & 0xff]; S.vB23.y = dictl[cdB >> 24];
+         if (tid == 0 && __double_as_longlong(dictl[cdA & 0xff]) != __double_as_longlong(p.dict_rounded ? (double) (float) fv64 : fv64))
+         {
+            __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+         }
+         if (p.dict_rounded) { S.vC = (double) (float) S.vC; }
+      }
       stream_consume_gt<F32>(p, k0, k1, ka, S, prod);
       __syncthreads();
       tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
@@ -646,7 +697,8 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    const int kC = ka + 8 * SPMV_THREADS + tid;
    const int qC = kC < k1 ? kC : min(ka + 8 * SPMV_THREADS, p.last_quad);
    const unsigned lC = lidx[qC];
-   S.vC = F32 ? (double) p.Aa32[qC] : p.Aa[qC];
+   unsigned cdC = 0;
+   if (CODED) { cdC = p.Ac8[qC]; } else { S.vC = F32 ? (double) p.Aa32[qC] : p.Aa[qC]; }
    constexpr int RPJ = (RP_CAP + SPMV_THREADS) / SPMV_THREADS;
    const int lim = min(nrows, rp_cap);
    int rpv[RPJ];
@@ -665,7 +717,18 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    const double xb0 = prod[lB.x & 0xffff], xb1 = prod[(unsigned) lB.x >> 16], xb2 = prod[lB.y & 0xffff], xb3 = prod[(unsigned) lB.y >> 16];
    const double xC = prod[lC];
    v2d lo0, hi0, lo1, hi1;
-   if (F32)
+   if (CODED)
+   {
+      // the values: eight more LDS reads (a stencil's few values: broadcasts)
+      lo0.x = dictl[cdA & 0xff] * xa0; lo0.y = dictl[(cdA >> 8) & 0xff] * xa1; hi0.x = dictl[(cdA >> 16) & 0xff] * xa2; hi0.y = dictl[cdA >> 24] * xa3;
+      lo1.x = dictl[cdB & 0xff] * xb0; lo1.y = dictl[(cdB >> 8) & 0xff] * xb1; hi1.x = dictl[(cdB >> 16) & 0xff] * xb2; hi1.y = dictl[cdB >> 24] * xb3;
+      S.vC = dictl[cdC];
+      if (tid == 0 && __double_as_longlong(dictl[cdA & 0xff]) != __double_as_longlong(p.dict_rounded ? (double) (float) fv64 : fv64))
+      {
+         __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+   }
+   else if (F32)
    {
       lo0.x = (double) S.fA.x * xa0; lo0.y = (double) S.fA.y * xa1; hi0.x = (double) S.fA.z * xa2; hi0.y = (double) S.fA.w * xa3;
       lo1.x = (double) S.fB.x * xb0; lo1.y = (double) S.fB.y * xb1; hi1.x = (double) S.fB.z * xb2; hi1.y = (double) S.fB.w * xb3;
@@ -692,6 +755,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       {
          const v2d lo = stream_load<v2d>(p.Aa + k), hi = stream_load<v2d>(p.Aa + k + 2);
          v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+         if (p.dict_rounded) { v0 = (double) (float) v0; v1 = (double) (float) v1; v2 = (double) (float) v2; v3 = (double) (float) v3; }
       }
       double *dst = prod + (k - ka);
       if (k     < k1) { dst[0] = v0 * p.x[c.x]; }
@@ -1059,6 +1123,119 @@ int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
    return h;
 }
 
+// ---- value codes (SpmvPlan::d_codes).  Distinct values are collected as bit patterns in an open-addressed table with
+// room for four times what a code can name; the pass ends early once more than DICT_CAP patterns are in (a matrix that is
+// not a stencil overflows within its first few thousand entries).  The all-ones pattern marks an empty slot: a matrix that
+// holds that NaN is not coded.
+constexpr int DICT_SLOTS = 4 * DICT_CAP;
+constexpr unsigned long long DICT_EMPTY = ~0ull;
+__device__ __forceinline__ unsigned dict_hash(unsigned long long v)
+{
+   v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 29;
+   return (unsigned) v & (DICT_SLOTS - 1);
+}
+__global__ __launch_bounds__(256)
+void dict_collect_kernel(const unsigned long long *__restrict__ vals, size_t n, unsigned long long *table, int *count)
+{
+   unsigned long long last = DICT_EMPTY;
+   for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t) gridDim.x * blockDim.x)
+   {
+      const unsigned long long v = vals[k];
+      if (v == last) { continue; }
+      if (v == DICT_EMPTY || __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > DICT_CAP)
+      {
+         __hip_atomic_store(count, DICT_CAP + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         return;
+      }
+      unsigned slot = dict_hash(v);
+      for (;;)
+      {
+         unsigned long long cur = __hip_atomic_load(table + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+         if (cur == DICT_EMPTY)
+         {
+            cur = atomicCAS(table + slot, DICT_EMPTY, v);
+            if (cur == DICT_EMPTY) { atomicAdd(count, 1); break; }
+         }
+         if (cur == v) { break; }
+         // threads in flight may overshoot DICT_CAP before they see the count: a full table ends here, not in an endless probe
+         if (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > DICT_CAP) { return; }
+         slot = (slot + 1) & (DICT_SLOTS - 1);
+      }
+      last = v;
+   }
+}
+__global__ __launch_bounds__(256)
+void dict_encode_kernel(const unsigned long long *__restrict__ vals, size_t n, const unsigned long long *__restrict__ table,
+                        const unsigned char *__restrict__ code_of_slot, unsigned char *__restrict__ codes)
+{
+   __shared__ unsigned long long t[DICT_SLOTS];
+   __shared__ unsigned char c[DICT_SLOTS];
+   for (int i = threadIdx.x; i < DICT_SLOTS; i += blockDim.x) { t[i] = table[i]; c[i] = code_of_slot[i]; }
+   __syncthreads();
+   for (size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (size_t) gridDim.x * blockDim.x)
+   {
+      const unsigned long long v = vals[k];
+      unsigned slot = dict_hash(v);
+      while (t[slot] != v) { slot = (slot + 1) & (DICT_SLOTS - 1); }
+      codes[k] = c[slot];
+   }
+}
+
+bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out, double **dict_out, double **dict32_out, int *ndict_out,
+                        hipStream_t s)
+{
+   *codes_out = nullptr; *dict_out = nullptr; *dict32_out = nullptr; *ndict_out = 0;
+   if (nnz == 0) { return false; }
+   unsigned long long *d_table = nullptr;
+   int *d_count = nullptr;
+   HIP_CHECK(hipMalloc((void **) &d_table, sizeof(unsigned long long) * DICT_SLOTS + sizeof(int) * 4));
+   d_count = reinterpret_cast<int *>(d_table + DICT_SLOTS);
+   HIP_CHECK(hipMemsetAsync(d_table, 0xff, sizeof(unsigned long long) * DICT_SLOTS, s));
+   HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int) * 4, s));
+   const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(Aa);
+   int grid = (int) std::min<size_t>((nnz + 255) / 256, (size_t) 8 * handle().num_cus);
+   hipLaunchKernelGGL(dict_collect_kernel, dim3(grid), dim3(256), 0, s, bits, nnz, d_table, d_count);
+   std::vector<unsigned long long> table(DICT_SLOTS);
+   int count = 0;
+   HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipMemcpyAsync(table.data(), d_table, sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   if (count > DICT_CAP || count <= 0) { HIP_CHECK(hipFree(d_table)); return false; }
+   // codes in the order of the bit patterns: the same matrix gets the same codes whatever order the table filled in
+   std::vector<unsigned long long> vals;
+   for (unsigned long long v : table) { if (v != DICT_EMPTY) { vals.push_back(v); } }
+   std::sort(vals.begin(), vals.end());
+   if ((int) vals.size() != count) { HIP_CHECK(hipFree(d_table)); hypre_error_w_msg(HYPRE_ERROR_GENERIC, "value table: count and contents disagree"); return false; }
+   std::vector<unsigned char> code_of_slot(DICT_SLOTS, 0);
+   for (int i = 0; i < DICT_SLOTS; i++)
+   {
+      if (table[(size_t) i] != DICT_EMPTY) { code_of_slot[(size_t) i] = (unsigned char) (std::lower_bound(vals.begin(), vals.end(), table[(size_t) i]) - vals.begin()); }
+   }
+   std::vector<double> dict(DICT_CAP, 0.0), dict32(DICT_CAP, 0.0);
+   for (size_t i = 0; i < vals.size(); i++)
+   {
+      double d; memcpy(&d, &vals[i], sizeof(double));
+      dict[i] = d; dict32[i] = (double) (float) d;
+   }
+   unsigned char *d_cos = nullptr, *d_codes = nullptr;
+   double *d_dict = nullptr;
+   const size_t ncodes = (nnz + 31) & ~(size_t) 15;
+   HIP_CHECK(hipMalloc((void **) &d_cos, DICT_SLOTS));
+   HIP_CHECK(hipMalloc((void **) &d_codes, ncodes));
+   HIP_CHECK(hipMalloc((void **) &d_dict, sizeof(double) * 2 * DICT_CAP));
+   HIP_CHECK(hipMemcpyAsync(d_cos, code_of_slot.data(), DICT_SLOTS, hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipMemcpyAsync(d_dict, dict.data(), sizeof(double) * DICT_CAP, hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipMemcpyAsync(d_dict + DICT_CAP, dict32.data(), sizeof(double) * DICT_CAP, hipMemcpyHostToDevice, s));
+   HIP_CHECK(hipMemsetAsync(d_codes + (ncodes - 32), 0, 32, s));
+   grid = (int) std::min<size_t>((nnz + 255) / 256, (size_t) 16 * handle().num_cus);
+   hipLaunchKernelGGL(dict_encode_kernel, dim3(grid), dim3(256), 0, s, bits, nnz, d_table, d_cos, d_codes);
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(d_cos));
+   HIP_CHECK(hipFree(d_table));
+   *codes_out = d_codes; *dict_out = d_dict; *dict32_out = d_dict + DICT_CAP; *ndict_out = count;
+   return true;
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1087,26 +1264,33 @@ static void launch_tiled_gt(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t
                       plan->d_tile_row, plan->d_tile_k, plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap);
 }
 
-template <int OP, bool F32, bool FILL>
+template <int OP, int VF, bool FILL>
 static void launch_xs(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
    int rowsum_elems, rp_cap;
-   const size_t lds = tiled_lds_bytes(plan, rowsum_elems, rp_cap);
+   size_t lds = tiled_lds_bytes(plan, rowsum_elems, rp_cap);
+   if (VF == VF_CODE) { lds = xs_dict_offset(plan->prod_elems, rowsum_elems, rp_cap) + sizeof(double) * (size_t) ((a.ndict + 1) & ~1); }
    const int unit = a.tile_perm ? 1 : (a.xcd_map > 0 ? 8 * a.xcd_map : 8);
    const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
-   hipLaunchKernelGGL((spmv_xs_kernel<OP, F32, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
+   hipLaunchKernelGGL((spmv_xs_kernel<OP, VF, FILL>), dim3(grid), dim3(SPMV_THREADS), lds, s, a,
                       plan->d_tile_row, plan->d_tile_k, plan->d_xs_cnt, plan->d_xs_desc, plan->d_lidx,
                       plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap, plan->xs_launch_units);
+}
+
+// the x-staged kernel serves this launch: the plan carries the per-tile piece lists and x can be read in 16-byte pieces
+static inline bool takes_xs(const SpmvPlan *plan, const SpmvArgs &a)
+{
+   return plan->tiled && a.variant == 2 && a.gather_t && plan->d_lidx && (((uintptr_t) a.x) & 15) == 0;
 }
 
 template <int OP, bool F32, bool FILL>
 static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
-   // x staged through LDS (variant 2, the default) when the plan carries the per-tile segment lists and x can be read in
-   // 16-byte pieces
-   if (a.variant == 2 && a.gather_t && plan->d_lidx && (((uintptr_t) a.x) & 15) == 0)
+   // x staged through LDS (variant 2, the default)
+   if (takes_xs(plan, a))
    {
-      launch_xs<OP, F32, FILL>(plan, a, s);
+      if (a.Ac8) { launch_xs<OP, VF_CODE, FILL>(plan, a, s); }
+      else { launch_xs<OP, F32 ? VF_F32 : VF_F64, FILL>(plan, a, s); }
       return;
    }
    if (a.gather_t) { launch_tiled_gt<OP, F32, FILL, true>(plan, a, s); }
@@ -1151,7 +1335,16 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    a.tile_perm = plan->d_tile_perm;
    a.tile_fp = plan->d_tile_fp;
    a.stale = plan->d_stale;
-   if (handle().fp32_values && !a.Aa32 && plan->nnz > 0)
+   // value codes (the x-staged kernel only): one byte per entry and the table of the matrix's values
+   a.Ac8 = nullptr; a.dict = nullptr; a.ndict = 0; a.dict_rounded = 0;
+   if (plan->d_codes && takes_xs(plan, a))
+   {
+      const bool rounded = handle().fp32_values || a.Aa32 != nullptr;
+      a.Ac8 = plan->d_codes; a.ndict = plan->ndict;
+      a.dict = rounded ? plan->d_dict32 : plan->d_dict;
+      a.dict_rounded = rounded ? 1 : 0;
+   }
+   if (handle().fp32_values && !a.Aa32 && !a.Ac8 && plan->nnz > 0)
    {
       // mixed precision: matrix values stream as fp32 (converted once per matrix), vectors and
       // accumulation stay fp64
@@ -1167,7 +1360,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    {
       // byte accounting (Handle::bytes_csr / bytes_stream): the matrix pass, the compulsory read of x (every column once,
       // or every entry's column when the matrix has fewer entries than columns: a colour's rows) and the row operands
-      const double nz = (double) plan->nnz, nr = (double) plan->num_rows, vw = a.Aa32 ? 4.0 : 8.0;
+      const double nz = (double) plan->nnz, nr = (double) plan->num_rows, vw = (a.Aa32 || a.dict_rounded) ? 4.0 : 8.0;
       const double xcols = 8.0 * std::min((double) plan->num_cols, nz);
       double rowb = 0.0;
       switch (op)
@@ -1180,7 +1373,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       }
       const double rows_b = 4.0 * (nr + 1.0) + rowb * nr + xcols;
       const bool staged = plan->tiled && a.variant == 2 && plan->d_lidx != nullptr;
-      account_bytes(nz * (vw + 4.0) + rows_b, nz * (vw + (staged ? 2.0 : 4.0)) + rows_b);
+      account_bytes(nz * (vw + 4.0) + rows_b, nz * ((a.Ac8 ? 1.0 : vw) + (staged ? 2.0 : 4.0)) + rows_b + (a.Ac8 ? 8.0 * a.ndict * plan->num_tiles : 0.0));
    }
    switch (op)
    {
@@ -1209,6 +1402,6 @@ void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs 
 
 // The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
 // the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
-void preload_spmv_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) (spmv_xs_kernel<0, false, false>)); (void) hipGetLastError(); }
+void preload_spmv_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) (spmv_xs_kernel<0, 0, false>)); (void) hipGetLastError(); }
 
 }  // namespace hamd

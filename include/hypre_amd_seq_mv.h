@@ -146,6 +146,15 @@ HYPRE_Int hypre_amd_SpmvSetBandPolicy(HYPRE_Int enabled, HYPRE_Int min_tiles, HY
  * plans built afterwards (a plan built under 0 has no chunk lists and keeps gathering).  variant < 0: unchanged;
  * the second argument is unused. */
 HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int unused);
+/* Value codes (speed only; results are the same bits; no reference counterpart): when a matrix holds at most 256 distinct
+ * values — constant-coefficient stencils hold a handful — the x-staged kernel streams one byte per entry and looks the
+ * value up in a table each tile keeps in LDS (1 + 2 bytes per entry instead of 8 + 2).  Found when the plan is built; on by
+ * default (environment: HYPRE_AMD_SPMV_VALUE_CODES=0).  on < 0: unchanged.  Takes effect for plans built afterwards.
+ * A caller that changes the values of a device matrix in place calls hypre_amd_CSRMatrixInvalidatePlan, as for the other
+ * things a plan caches. */
+HYPRE_Int hypre_amd_SpmvSetValueCodes(HYPRE_Int on);
+/* Number of distinct values in the value table of the plan of the device matrix A; 0 when A is not coded. */
+HYPRE_Int hypre_amd_CSRMatrixPlanValueCodes(hypre_CSRMatrix *A);
 /* x staging of the plan of the device matrix A: returns the number of tiles that take the LDS-staged path of the tiled
  * kernel; fills the plan's tile count and the mean number of x pieces of a staged tile. */
 HYPRE_Int hypre_amd_CSRMatrixPlanStaging(hypre_CSRMatrix *A, HYPRE_Int *num_tiles, HYPRE_Real *mean_pieces);

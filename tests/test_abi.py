@@ -110,8 +110,9 @@ def test_hot_kernels_keep_full_occupancy():
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, r
 
 
-def _xs_kernel_listing(extra_flags):
-    """instructions of spmv_xs_kernel<OP_AXPBY, fp64, no fill> as the build's flags compile it (device code only)"""
+def _xs_kernel_listing(extra_flags, vf=0):
+    """instructions of spmv_xs_kernel<OP_AXPBY, value form vf (0 fp64, 2 one-byte codes), no fill> as the build's flags
+    compile it (device code only)"""
     import subprocess
     import tempfile
     src = os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip")
@@ -123,7 +124,7 @@ def _xs_kernel_listing(extra_flags):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = open(out).read().splitlines()
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4hamd14spmv_xs_kernelILi0ELb0ELb0E") and l.rstrip().endswith(":") is False and ":" in l)
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4hamd14spmv_xs_kernelILi0ELi%dELb0E" % vf) and l.rstrip().endswith(":") is False and ":" in l)
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     return [l.strip() for l in lines[start:end + 1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
 
@@ -131,7 +132,7 @@ def _xs_kernel_listing(extra_flags):
 def _xs_schedule(ins):
     """where the loads of one tile sit: indices of the first matrix-stream load, of the wait that ends the scalar batch
     with the tile's piece descriptors, of the first LDS-DMA load of x, of the first barrier; and the waits between them"""
-    first_stream = next(i for i, l in enumerate(ins) if l.startswith("global_load_dwordx4") or l.startswith("global_load_dwordx2"))
+    first_stream = next(i for i, l in enumerate(ins) if l.startswith(("global_load_dwordx4", "global_load_dwordx2", "global_load_dword ")))
     first_dma = next(i for i, l in enumerate(ins) if l.startswith("global_load_lds_dwordx4"))
     # the descriptors are the scalar loads at a register offset (tile * 96 ints into the plan's table)
     import re
@@ -143,7 +144,7 @@ def _xs_schedule(ins):
     return dict(first_stream=first_stream, batch_wait=batch_wait, first_dma=first_dma, first_barrier=first_barrier,
                 vm_waits_before_dma=[l for l in ins[first_stream:first_dma] if l.startswith("s_waitcnt") and "vmcnt" in l],
                 vm_waits_dma_to_barrier=[l for l in ins[first_dma:first_barrier] if l.startswith("s_waitcnt") and "vmcnt" in l],
-                stream_loads_before_batch_wait=sum(1 for l in ins[:batch_wait] if l.startswith(("global_load_dwordx4", "global_load_dwordx2"))),
+                stream_loads_before_batch_wait=sum(1 for l in ins[:batch_wait] if l.startswith(("global_load_dwordx4", "global_load_dwordx2", "global_load_dword "))),
                 dma_loads=sum(1 for l in ins[first_dma:first_barrier] if l.startswith("global_load_lds_dwordx4")))
 
 
@@ -165,6 +166,14 @@ def test_the_x_staged_kernel_keeps_its_load_schedule():
     assert len(good["vm_waits_dma_to_barrier"]) == 1 and "vmcnt(0)" in good["vm_waits_dma_to_barrier"][0], good
     late = _xs_schedule(_xs_kernel_listing(["-DXS_EARLY_STREAM=0"]))
     assert not (late["first_stream"] < late["batch_wait"]), late
+    # the coded form (one-byte value codes and their table): 2 x 4 bytes of codes + 2 x 8 bytes of indices per lane, and the
+    # table rides with the x pieces as a thirteenth LDS-DMA load
+    coded = _xs_schedule(_xs_kernel_listing([], vf=2))
+    assert coded["first_stream"] < coded["batch_wait"] < coded["first_dma"] < coded["first_barrier"], coded
+    assert coded["stream_loads_before_batch_wait"] >= 4, coded
+    assert coded["vm_waits_before_dma"] == [], coded
+    assert coded["dma_loads"] == 13, coded
+    assert len(coded["vm_waits_dma_to_barrier"]) == 1 and "vmcnt(0)" in coded["vm_waits_dma_to_barrier"][0], coded
 
 
 def test_option_gates_accept_the_built_branch_and_refuse_the_rest(lib):

@@ -387,3 +387,84 @@ def test_sort_rows_and_byte_counters(gpu_lib, oracle):
     for o in (dx, dy):
         lib.hypre_SeqVectorDestroy(o)
     lib.hypre_CSRMatrixDestroy(dA)
+
+
+def _table_matrix(shape, lo, hi, nvals, seed):
+    """random pattern whose values are drawn from a table of nvals distinct doubles (signed zeros, a subnormal and an
+    infinity-free mix of magnitudes among them), every table entry used at least once"""
+    A = random_csr(shape[0], shape[1], lo, hi, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    table = np.unique(np.concatenate([[0.0, 6.0, -1.0, 5e-324, 1e300, -1e-300], rng.uniform(-3, 3, nvals + 8)]))
+    table = table[:nvals].copy()
+    if nvals >= 2:
+        table[-1] = -0.0 if 0.0 in table[:-1] else table[-1]        # 0.0 and -0.0 are two table entries (bit patterns)
+    pick = rng.integers(0, len(table), A.nnz)
+    pick[:len(table)] = np.arange(len(table))
+    A.data[:] = table[pick]
+    return A, len(np.unique(table.view(np.int64)))
+
+
+@pytest.mark.parametrize("nvals,shape,lo,hi", [(1, (6000, 6000), 3, 30), (2, (6000, 6000), 3, 30), (7, (20000, 20000), 5, 9),
+                                               (255, (6000, 6000), 20, 60), (256, (6000, 6000), 20, 60),
+                                               (257, (6000, 6000), 20, 60), (5000, (6000, 6000), 20, 60),
+                                               (3, (3000, 2500), 200, 900), (3, (4000, 400000), 10, 40)])
+def test_value_codes_give_the_same_bits(gpu_lib, oracle, nvals, shape, lo, hi):
+    """A matrix with at most 256 distinct values (bit patterns) is streamed by the x-staged kernel as one byte per entry
+    plus a table staged in LDS: the product must be the SAME BITS as with the fp64 stream (same values, same order of
+    every row's sum) — staged tiles, tiles that gather (400 000 columns), spilling last rows (up to 900 entries) — and a
+    matrix with more values must not be coded at all."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A, distinct = _table_matrix(shape, lo, hi, nvals, seed=nvals)
+    x = rand_vector(shape[1], 7)
+    b = rand_vector(shape[0], 8)
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.hypre_amd_SpmvSetValueCodes(on)
+            dA = B.csr_from_scipy(A)
+            dx, db, dy = B.vec_from_numpy(x), B.vec_from_numpy(b), B.vec_from_numpy(np.zeros(shape[0]))
+            lib.hypre_CSRMatrixMatvecOutOfPlace(-0.75, dA, dx, 1.5, db, dy, 0)
+            B.check()
+            coded = lib.hypre_amd_CSRMatrixPlanValueCodes(dA)
+            assert coded == (distinct if (on and distinct <= 256) else 0), (coded, distinct)
+            out[on] = B.vec_to_numpy(dy)
+            for o in (dx, db, dy):
+                lib.hypre_SeqVectorDestroy(o)
+            lib.hypre_CSRMatrixDestroy(dA)
+    finally:
+        lib.hypre_amd_SpmvSetValueCodes(1)
+    assert np.array_equal(out[1].view(np.int64), out[0].view(np.int64))
+    with np.errstate(over="ignore", invalid="ignore"):
+        bound = _bound(A, x, -0.75, 1.5, b)
+    ok = np.isfinite(bound)
+    assert np.all(np.abs(out[1] - (-0.75 * (A @ x) + 1.5 * b))[ok] <= bound[ok])
+
+
+def test_values_changed_behind_a_coded_plan_are_found_out(gpu_lib, oracle):
+    """The coded kernel never reads the fp64 values: every tile compares the first value it decodes with the fp64 original,
+    so values changed in place without hypre_amd_CSRMatrixInvalidatePlan raise HYPRE_ERROR_GENERIC and the synchronous
+    product repeats itself with a fresh plan."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A1 = laplace_3d(20, 20, 20)
+    A2 = sp.csr_matrix((A1.data * 0.5, A1.indices, A1.indptr), shape=A1.shape)
+    n = A1.shape[0]
+    x = rand_vector(n, 3)
+    dA = B.csr_from_scipy(A1)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(n))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert lib.hypre_amd_CSRMatrixPlanValueCodes(dA) == 2
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A1 @ x) <= _bound(A1, x, 1.0, 0.0, x))
+    _overwrite(lib, dA, A2)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    with pytest.raises(B.HypreAmdError):
+        B.check()
+    lib.HYPRE_ClearAllErrors()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A2 @ x) <= _bound(A2, x, 1.0, 0.0, x))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    for o in (dx, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
