@@ -78,7 +78,7 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
    if (OP == OP_JACOBI_MAP) { row = p.rowmap[row]; }
    o.g = row;
    if (OP == OP_AXPBY) { if (p.beta != 0.0) { o.b = p.b[row]; } }
-   else if (OP == OP_TSGS) { o.d = p.d[row]; }
+   else if (OP == OP_TSGS) { o.d = p.d[row]; o.x = p.aux[row]; }      // aux: read here, with the other operands, not in the epilogue
    else
    {
       o.b = p.b[row]; o.d = p.d[row]; o.x = p.x[row];
@@ -105,7 +105,7 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum,
       //    z_out = (L_strict z_in) ./ D ;  u += mult * z_out
       const double z = sum * (1.0 / o.d);
       p.y[row] = z;
-      p.aux[row] += p.alpha * z;
+      p.aux[row] = o.x + p.alpha * z;
    }
    else
    {
@@ -117,8 +117,20 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum,
    }
 }
 
+#ifndef SPMV_REDUCE_BATCH
+#define SPMV_REDUCE_BATCH 4
+#endif
+constexpr int RB = SPMV_REDUCE_BATCH;   // products a lane of the row reduction has in flight
 constexpr int RP_CAP = 640;      // upper bound of the row pointers staged in LDS per tile (the plan asks for fewer
                                  // when no tile of the matrix holds that many rows)
+
+// a workgroup barrier that orders LDS accesses only: __syncthreads() also waits for every global load in flight
+__device__ __forceinline__ void lds_barrier()
+{
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+   __builtin_amdgcn_s_barrier();
+   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // row sums of a tile with W lanes per row (products in LDS, sums to rowsum[]); W is a compile-time width: the shuffle
 // tree and the lane arithmetic unroll (a run-time W cost levels 2+ of the benchmark hierarchy 5 %)
@@ -136,11 +148,22 @@ __device__ __forceinline__ void tile_row_sums(const SpmvArgs &p, int r0, int nro
       {
          const int row = r0 + rr;
          const int s = rp[rr], e = rp[rr + 1];
-         for (int k = s + sub; k < e; k += W)
+         // RB products at a time: the LDS reads of a batch are in flight together (clamped addresses, so that they are
+         // unconditional), the additions keep the order of the one-by-one loop
+         for (int k = s + sub; k < e; k += RB * W)
          {
-            double t = prod[k - ka];
-            if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-            sum += t;
+            double t[RB];
+#pragma unroll
+            for (int i = 0; i < RB; i++) { t[i] = prod[min(k + i * W, e - 1) - ka]; }
+#pragma unroll
+            for (int i = 0; i < RB; i++)
+            {
+               if (k + i * W < e)
+               {
+                  if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k + i * W])) { t[i] = 0.0; } }
+                  sum += t[i];
+               }
+            }
          }
       }
       sum = subwave_sum<W>(sum);
@@ -167,11 +190,21 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
          const int s = (rr     <= rp_cap) ? rp[rr]     : p.Ai[row];
          const int e = (rr + 1 <= rp_cap) ? rp[rr + 1] : p.Ai[row + 1];
          double sum = 0.0;
-         for (int k = s; k < e; k++)
+         // RB products at a time (see tile_row_sums)
+         for (int k = s; k < e; k += RB)
          {
-            double t = prod[k - ka];
-            if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k])) { t = 0.0; } }
-            sum += t;
+            double t[RB];
+#pragma unroll
+            for (int i = 0; i < RB; i++) { t[i] = prod[min(k + i, e - 1) - ka]; }
+#pragma unroll
+            for (int i = 0; i < RB; i++)
+            {
+               if (k + i < e)
+               {
+                  if (HASFILL) { if (!fill_keep(p.fill, row, p.Aj[k + i])) { t[i] = 0.0; } }
+                  sum += t[i];
+               }
+            }
          }
          if (rr == tid) { row_epilogue<OP>(p, row, sum, ops); }
          else { const RowOps o = load_row_ops<OP>(p, row); row_epilogue<OP>(p, row, sum, o); }
@@ -194,7 +227,7 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
          case 16: tile_row_sums<HASFILL, 16>(p, r0, nrows, ka, prod, rowsum, rp); break;
          default: tile_row_sums<HASFILL, 32>(p, r0, nrows, ka, prod, rowsum, rp); break;
       }
-      __syncthreads();
+      lds_barrier();                 // row sums are in LDS
       if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, rowsum[tid], ops); }
    }
 }
@@ -510,6 +543,26 @@ constexpr int XS_CAP   = SPMV_XS_CAP;       // doubles a tile may stage at most 
 #endif
 constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first column of every piece, then (offset << 16 | length)
 
+#ifndef XS_TIMING
+#define XS_TIMING 0
+#endif
+// experiments (wrong products, timing only): XS_EXP_SLOTS < XS_WSEG stages only the first pieces of every wave,
+// XS_EXP_NOREDUCE replaces the row sums by one store per lane
+#ifndef XS_EXP_SLOTS
+#define XS_EXP_SLOTS 1000
+#endif
+#ifndef XS_EXP_NOREDUCE
+#define XS_EXP_NOREDUCE 0
+#endif
+#if XS_TIMING
+// experiment (tools/experiments/tile_phases.sh): where a tile's life goes, in ticks of the 100 MHz wall clock, summed over
+// the tiles of the last launch, four numbers per tile: entry -> scalar batch back, -> stream and x pieces landed (first
+// barrier), -> products parked, -> row sums and epilogue issued.  Plain stores into a buffer the host hands over.
+__device__ unsigned *xs_timing_buf;
+#define XS_STAMP(n) const unsigned long long ts##n = wall_clock64()
+#else
+#define XS_STAMP(n)
+#endif
 // VF, the form the matrix values are streamed in: 0 fp64, 1 fp32 (mixed precision), 2 one-byte codes into a table of at
 // most 256 values that every tile stages in LDS with its x pieces (SpmvPlan::d_codes).
 constexpr int VF_F64 = 0, VF_F32 = 1, VF_CODE = 2;
@@ -551,6 +604,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    const int tid = threadIdx.x, lane = tid & 63;
    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
    const int ka = tile * SPMV_TILE;
+   XS_STAMP(0);
    // Values and local indices of the tile's window, then — wave-uniform, through the scalar cache — the tile's bounds
    // and this wave's twelve piece descriptors: ONE batch of requests issued before anything about the tile is known.
    // Left alone, the compiler sinks every one of these loads below the first branch that does not need it (the stream
@@ -638,6 +692,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
 #endif
    const int nrows = r1 - r0;
    const int nseg = (xc >> 8) <= xs_units ? (xc & 0xff) : 0;     // the launch may stage less than the plan allows (occupancy)
+   XS_STAMP(1);
 
    if (nseg == 0)
    {
@@ -682,7 +737,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    // column and x is 16-byte aligned, so a lane's 16 bytes never straddle a page: when x has an odd length the upper
    // half of its last pair is read (not used) but cannot fault.
 #pragma unroll
-   for (int j = 0; j < XS_WSEG; j++)
+   for (int j = 0; j < (XS_WSEG < XS_EXP_SLOTS ? XS_WSEG : XS_EXP_SLOTS); j++)
    {
       // (the plan keeps what the slot needs as it needs it: the piece's LDS offset in bytes, its length in lanes, an
       // unsigned first column — a slot is a dozen instructions per wave whether it loads or not)
@@ -710,6 +765,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
    if (tid == 0 && rpv[0] != k0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // the tile table is not this matrix's
    __syncthreads();
+   XS_STAMP(2);
 
    // "gathers": eight LDS reads per lane.  Entries of the window that belong to a neighbouring tile carry that tile's
    // numbering: any index below the staging capacity reads initialised-or-not LDS and the product is never used.
@@ -764,7 +820,21 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       if (k + 3 < k1) { dst[3] = v3 * p.x[c.w]; }
    }
    __syncthreads();
+   XS_STAMP(3);
+#if XS_EXP_NOREDUCE
+   if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, prod[tid], ops); }
+#else
    tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
+#endif
+#if XS_TIMING
+   {
+      const unsigned long long ts4 = wall_clock64();
+      if (tid == 0 && xs_timing_buf)
+      {
+         *reinterpret_cast<uint4 *>(xs_timing_buf + 4 * (size_t) tile) = make_uint4((unsigned) (ts1 - ts0), (unsigned) (ts2 - ts1), (unsigned) (ts3 - ts2), (unsigned) (ts4 - ts3));
+      }
+   }
+#endif
 }
 
 // ---- plan construction: per tile, the segments of x its entries touch and per entry the index of its column in
@@ -1402,6 +1472,24 @@ void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs 
 
 // The code object of this file is loaded when one of its kernels is first asked for: ensure_device() asks here, so that
 // the load (tens of milliseconds per file) is part of bringing the device up, not of the first setup or solve.
+#if XS_TIMING
+// tiles > 0: the launches from now on record into a fresh buffer of 4 * tiles numbers; out != null: the buffer's contents
+extern "C" void hypre_amd_XsTiming(unsigned *out, int tiles)
+{
+   static unsigned *buf = nullptr;
+   static int len = 0;
+   HIP_CHECK(hipDeviceSynchronize());
+   if (out && buf) { HIP_CHECK(hipMemcpy(out, buf, sizeof(unsigned) * 4 * (size_t) len, hipMemcpyDeviceToHost)); }
+   if (tiles > 0)
+   {
+      if (buf) { HIP_CHECK(hipFree(buf)); }
+      HIP_CHECK(hipMalloc((void **) &buf, sizeof(unsigned) * 4 * (size_t) tiles));
+      HIP_CHECK(hipMemset(buf, 0, sizeof(unsigned) * 4 * (size_t) tiles));
+      len = tiles;
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(xs_timing_buf), &buf, sizeof(buf)));
+   }
+}
+#endif
 void preload_spmv_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) (spmv_xs_kernel<0, 0, false>)); (void) hipGetLastError(); }
 
 }  // namespace hamd
