@@ -279,6 +279,15 @@ def main():
     spmv_ms = L.hypre_amd_EventTimerStopMs() / reps
     spmv_bytes = nnz * 12 + (nloc + 1) * 4 + nloc * 8 + nloc * 8
     spmv_gbs = spmv_bytes / spmv_ms / 1e6
+    # Value codes: a matrix with at most 256 distinct values (these stencils hold 2 - 3) is streamed as one byte per entry
+    # plus a 16-bit local index; the algorithmic (CSR) count above then overstates what the launch reads, and `achieved`
+    # can exceed the HBM peak.  Reported beside it: what the kernel is designed to stream, and the same launch with the
+    # codes switched off (fp64 values streamed: what a variable-coefficient operator of this size gets).
+    ndict = int(L.hypre_amd_CSRMatrixPlanValueCodes(diag))
+    value_width = 4 if args.mixed else 8
+    ntiles = (nnz + 2047) // 2048
+    vec_bytes = (nloc + 1) * 4 + nloc * 8 + nloc * 8
+    spmv_streamed = nnz * ((1 if ndict else value_width) + 2) + vec_bytes + (8 * ndict * ntiles if ndict else 0)
     # Bytes of one cycle on this rank (every rank carries the same share: weak scaling): counted by the launch wrappers
     # over the timed cycles, so the figure follows the smoother, the value width and the levels actually run (two-stage
     # GS: residual pass + inner passes over the strict lower triangle; fp32 values: 4 instead of 8 bytes per entry).
@@ -333,6 +342,48 @@ def main():
     except Exception as exc:      # noqa: BLE001 - the headline metric above stands on its own
         pcg_info = {"error": str(exc)}
         L.HYPRE_ClearAllErrors()
+    # ---- after the solves (dropping the plan of the fine-level matrix also drops what else the library cached for it — the
+    # strictly lower copy of the two-stage sweeps, colour classes, level schedules —, which the next solve would rebuild)
+    uncoded = None
+    if ndict:
+        L.hypre_amd_SpmvSetValueCodes(0)
+        L.hypre_amd_CSRMatrixInvalidatePlan(diag)
+        for _ in range(5):
+            L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
+        L.hypre_SyncComputeStream()
+        L.hypre_amd_EventTimerStart()
+        for _ in range(reps):
+            L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
+        u_ms = L.hypre_amd_EventTimerStopMs() / reps
+        L.hypre_amd_SpmvSetValueCodes(1)
+        L.hypre_amd_CSRMatrixInvalidatePlan(diag)
+        L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)                  # the coded plan again, for what follows
+        L.hypre_SyncComputeStream()
+        B.check()
+        uncoded = {"ms_per_launch": u_ms, "achieved": spmv_bytes / u_ms / 1e6, "frac": spmv_bytes / u_ms / 1e6 / HBM_PEAK_GBS,
+                   "unit": "GB/s", "streamed_bytes_per_launch": nnz * (value_width + 2) + vec_bytes,
+                   "what": "the same launch with hypre_amd_SpmvSetValueCodes(0): matrix values streamed as %s" % ("fp32" if args.mixed else "fp64")}
+    # the largest launch of the cycle below the fine level: y = A_1 x on this rank's block of level 1 (values all distinct)
+    level1 = None
+    if int(L.hypre_amd_BoomerAMGGetNumLevels(s)) > 2:
+        lv1_A = C.cast(L.hypre_amd_BoomerAMGGetA(s, 1), C.POINTER(B.ParCSRMatrix)).contents.diag
+        lv1_n, lv1_nnz = lv1_A.contents.num_rows, lv1_A.contents.num_nonzeros
+        if lv1_n > 0 and lv1_nnz > 0:
+            lv1_x = B.vec_from_numpy(np.random.default_rng(rank + 7).uniform(-1, 1, lv1_A.contents.num_cols))
+            lv1_y = B.vec_from_numpy(np.zeros(lv1_n))
+            for _ in range(5):
+                L.hypre_CSRMatrixMatvec(1.0, lv1_A, lv1_x, 0.0, lv1_y)
+            L.hypre_SyncComputeStream()
+            L.hypre_amd_EventTimerStart()
+            for _ in range(reps):
+                L.hypre_CSRMatrixMatvec(1.0, lv1_A, lv1_x, 0.0, lv1_y)
+            lv1_ms = L.hypre_amd_EventTimerStopMs() / reps
+            lv1_by = lv1_nnz * (4 + value_width) + (lv1_n + 1) * 4 + lv1_A.contents.num_cols * 8 + lv1_n * 8
+            level1 = {"rows": lv1_n, "nnz": lv1_nnz, "algorithmic_bytes_per_launch": lv1_by, "ms_per_launch": lv1_ms, "achieved": lv1_by / lv1_ms / 1e6,
+                      "unit": "GB/s", "frac": lv1_by / lv1_ms / 1e6 / HBM_PEAK_GBS, "value_codes": int(L.hypre_amd_CSRMatrixPlanValueCodes(lv1_A))}
+            L.hypre_SeqVectorDestroy(lv1_x)
+            L.hypre_SeqVectorDestroy(lv1_y)
+            B.check()
     # HBM traffic per launch cannot be read from inside the process (PMC counters need rocprofv3 around it): the figure is
     # taken from the newest committed --pmc pass over this same kernel and matrix (profiles/, tools/pmc_levels.sh) when
     # the workload matches, and labelled as what it is: a profile-derived number of an earlier run of this kernel — with
@@ -343,7 +394,8 @@ def main():
         import hashlib
         with open(os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip"), "rb") as fh:
             kernel_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
-        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "levels_xs" in f and f.endswith("_summary.json"))
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "levels_xs" in f and f.endswith("_summary.json")
+                           and (("codes" in f) == bool(ndict)))
         if pmc_files:
             with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as fh:
                 summary = json.load(fh)
@@ -459,10 +511,19 @@ def main():
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s, "setup_path": setup_path,
                        "matrix_generation_seconds": matrix_s},
-            "roofline": {"bound": "hbm", "kernel": "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS)",
+            "roofline": {"bound": "hbm", "kernel": "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS%s)" % (
+                             "; matrix values as one-byte codes into a table of %d" % ndict if ndict else ""),
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms,
+                         "value_codes": ndict,
+                         "streamed_bytes_per_launch": spmv_streamed, "streamed_GBps": spmv_streamed / spmv_ms / 1e6,
+                         "streamed_frac": spmv_streamed / spmv_ms / 1e6 / HBM_PEAK_GBS,
+                         "note": ("achieved is SURVEY 8(d)'s CSR byte count (12 bytes per entry) over the launch time; with value "
+                                  "codes the launch reads 3 bytes per entry, so achieved may exceed the HBM peak: the launch is "
+                                  "bounded by its streamed bytes (streamed_frac) and by instruction issue, not by the CSR count"
+                                  if ndict else None),
+                         "uncoded": uncoded, "level1": level1,
                          "device_copy_GBps_this_box": copy_gbs},
             "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
                        "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS,

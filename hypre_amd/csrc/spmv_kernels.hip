@@ -174,10 +174,13 @@ __device__ __forceinline__ void tile_row_sums(const SpmvArgs &p, int r0, int nro
 // Per-row reduction of the products parked in LDS and the row epilogue.
 // prod[k - ka] holds entry k of the tile, rp[rr] the row pointer of row r0 + rr
 // (the first rp_cap + 1 of them), ops the epilogue operands of row r0 + tid.
-template <int OP, bool HASFILL>
+// OPS2: the caller also fetched the operands of row r0 + SPMV_THREADS + tid early (tiles of short rows hold more rows than
+// the workgroup has lanes: a 7-point tile 293, an interpolation tile ~512): without them the second pass asks for its
+// operands when it needs them, a third trip to memory at the end of the tile's life.
+template <int OP, bool HASFILL, bool OPS2 = false>
 __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows, int k0, int k1, int ka,
                                             const double *prod, double *rowsum, const int *rp, int rp_cap,
-                                            const RowOps &ops)
+                                            const RowOps &ops, const RowOps *ops2 = nullptr)
 {
    const int tid = threadIdx.x;
    const int avg = (k1 - k0) / nrows;
@@ -207,6 +210,7 @@ __device__ __forceinline__ void tile_reduce(const SpmvArgs &p, int r0, int nrows
             }
          }
          if (rr == tid) { row_epilogue<OP>(p, row, sum, ops); }
+         else if (OPS2 && rr == tid + SPMV_THREADS) { row_epilogue<OP>(p, row, sum, *ops2); }
          else { const RowOps o = load_row_ops<OP>(p, row); row_epilogue<OP>(p, row, sum, o); }
       }
    }
@@ -548,6 +552,9 @@ constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first 
 #endif
 // experiments (wrong products, timing only): XS_EXP_SLOTS < XS_WSEG stages only the first pieces of every wave,
 // XS_EXP_NOREDUCE replaces the row sums by one store per lane
+#ifndef XS_OPS2
+#define XS_OPS2 1
+#endif
 #ifndef XS_EXP_SLOTS
 #define XS_EXP_SLOTS 1000
 #endif
@@ -760,6 +767,11 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
 #pragma unroll
    for (int j = 0; j < RPJ; j++) { rpv[j] = p.Ai[r0 + min(tid + j * SPMV_THREADS, lim)]; }
    const RowOps ops = tile_row_ops<OP>(p, r0, nrows);
+   // the operands of a second row per lane (tiles of short rows), where the registers allow: unconditional, clamped
+   // (y = alpha A x + beta b: one operand; the sweeps' three do not fit 64 registers beside the fp64 or coded stream)
+   constexpr bool OPS2 = XS_OPS2 && !HASFILL && (OP == OP_AXPBY || (OP == OP_JACOBI && VF == VF_F32));
+   RowOps ops2 = ops;
+   if (OPS2) { ops2 = load_row_ops<OP>(p, max(r0 + min(tid + SPMV_THREADS, nrows - 1), 0)); }
    // lanes past the tile's rows repeat its last pointer into the last slot
 #pragma unroll
    for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
@@ -824,7 +836,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
 #if XS_EXP_NOREDUCE
    if (tid < nrows) { row_epilogue<OP>(p, r0 + tid, prod[tid], ops); }
 #else
-   tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
+   tile_reduce<OP, HASFILL, OPS2>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops, &ops2);
 #endif
 #if XS_TIMING
    {

@@ -78,7 +78,8 @@ for lv, d in levels.items():
 import hashlib
 with open(os.path.join("hypre_amd", "csrc", "spmv_kernels.hip"), "rb") as fh:
     kernel_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
-out = {"tag": tag, "kernel_source_sha16": kernel_sha, "command": "bash tools/pmc_levels.sh %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set, "
+out = {"tag": tag, "kernel_source_sha16": kernel_sha, "value_codes": os.environ.get("HYPRE_AMD_SPMV_VALUE_CODES", "1") != "0",
+        "command": "bash tools/pmc_levels.sh %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set, "
                               "each over python3 tools/bench_levels_spmv.py 256 3 10)" % tag,
        "matrix": "levels 0-2 of the 256^3 7-pt hierarchy (PMIS, ext+i(4))",
        "note": "SQ_* cycle counters are in units of 4 cycles and sampled; FETCH_SIZE / WRITE_SIZE in KB, FETCH_SIZE doubled "
