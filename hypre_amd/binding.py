@@ -194,6 +194,8 @@ PROTOTYPES = {
     "hypre_amd_CSRMatrixPlanInfo": (Int, [CSRp, IntP, IntP]),
     "hypre_amd_CSRMatrixPlanStaging": (Int, [CSRp, IntP, RealP]),
     "hypre_amd_SpmvSetValueCodes": (Int, [Int]),
+    "hypre_amd_SpmvSetSliceForm": (Int, [Int]),
+    "hypre_amd_CSRMatrixPlanSliceForm": (Int, [CSRp]),
     "hypre_amd_CSRMatrixPlanValueCodes": (Int, [CSRp]),
     "hypre_SeqVectorSetConstantValues": (Int, [Vecp, Real]),
     "hypre_SeqVectorCopy": (Int, [Vecp, Vecp]),

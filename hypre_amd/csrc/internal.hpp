@@ -128,6 +128,18 @@ struct SpmvPlan
    unsigned char *d_codes = nullptr;   // [nnz rounded up to 16]
    double        *d_dict = nullptr, *d_dict32 = nullptr;   // [256]
    int            ndict = 0;
+   // Slice form (spmv_sl_kernel): a coded matrix whose rows are short (at most 32 entries) and about equally long — a
+   // stencil — is stored a third time with the codes and local indices of a ROW (sl_w = 1: rows of at most 8 entries) or
+   // of every second entry of a row (sl_w = 2) in a lane's own words, entry j of the 64 lane-rows of a wave side by side:
+   // a workgroup takes sl_rows = 256 / sl_w consecutive rows, stages their x pieces as the tiled kernel does, and every
+   // lane sums its entries in stored order from registers — no products parked in LDS, no reduction, one barrier.
+   int       sl_w = 0, sl_rows = 0, sl_k = 0;   // lanes per row; rows per workgroup; entries per lane (every row padded to sl_w * sl_k)
+   int       sl_wc = 0, sl_wl = 0;               // 32-bit words per lane: ceil(sl_k / 4) of codes, ceil(sl_k / 2) of indices
+   int       sl_blocks = 0, sl_launch_units = 0;
+   int      *d_sl_cnt = nullptr, *d_sl_desc = nullptr;    // per block, as d_xs_cnt / d_xs_desc per tile
+   int      *d_sl_k0 = nullptr, *d_sl_fp = nullptr;       // per block: position of its first entry; fingerprint of two of its columns
+   int      *d_sl_perm = nullptr;                          // workgroup -> block (band-aware placement), or null
+   unsigned *d_sl_data = nullptr;                          // [sl_blocks][4 waves][sl_wc + sl_wl][64 lanes]
    // x staging (spmv_xs_kernel): per tile the number of column segments that cover its entries (0: they do not fit, gather
    // instead) and their descriptors (2 * SPMV_XS_SEGS ints per tile); per entry the index of its column in the tile's
    // staged copy
@@ -226,6 +238,9 @@ void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t 
 // value codes of a matrix (nullptr / 0 when it holds more than 256 distinct values): codes[nnz], the sorted table, its fp32-rounded twin
 bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out, double **dict_out, double **dict32_out, int *ndict_out,
                         hipStream_t s);
+// slice form of a coded matrix (false: not applicable — long or very unequal rows, a block that cannot be staged)
+bool device_build_slice_form(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s);
+bool &spmv_slice_form();               // plans built from now on get the slice form where it applies (default: on; HYPRE_AMD_SPMV_SLICE_FORM=0)
 bool &spmv_value_codes();              // plans built from now on look for value codes (default: on; HYPRE_AMD_SPMV_VALUE_CODES=0)
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,
                         int *d_tile_k, hipStream_t s);

@@ -209,6 +209,12 @@ static void free_plan(SpmvPlan *p)
    if (p->a32) { HIP_CHECK(hipFree(p->a32)); }
    if (p->d_codes) { HIP_CHECK(hipFree(p->d_codes)); }
    if (p->d_dict) { HIP_CHECK(hipFree(p->d_dict)); }       // d_dict32 is its second half
+   if (p->d_sl_cnt) { HIP_CHECK(hipFree(p->d_sl_cnt)); }
+   if (p->d_sl_desc) { HIP_CHECK(hipFree(p->d_sl_desc)); }
+   if (p->d_sl_k0) { HIP_CHECK(hipFree(p->d_sl_k0)); }
+   if (p->d_sl_fp) { HIP_CHECK(hipFree(p->d_sl_fp)); }
+   if (p->d_sl_perm) { HIP_CHECK(hipFree(p->d_sl_perm)); }
+   if (p->d_sl_data) { HIP_CHECK(hipFree(p->d_sl_data)); }
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
    if (p->Lstrict) { hypre_CSRMatrixDestroy(p->Lstrict); }
    delete p;
@@ -335,11 +341,18 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
             }
             p->prod_elems = std::max(p->prod_elems, 2 * p->xs_launch_units + 8);
             if (spmv_value_codes()) { device_value_codes(A->data, (size_t) A->num_nonzeros, &p->d_codes, &p->d_dict, &p->d_dict32, &p->ndict, s); }
+            if (p->d_codes && spmv_slice_form()) { device_build_slice_form(p, A, s); }
          }
       }
    }
    t[A] = p;
    return p;
+}
+
+bool &spmv_slice_form()
+{
+   static bool on = [] { const char *e = getenv("HYPRE_AMD_SPMV_SLICE_FORM"); return !(e && atoi(e) == 0); }();
+   return on;
 }
 
 bool &spmv_value_codes()
@@ -431,6 +444,21 @@ extern "C" HYPRE_Int hypre_amd_SpmvSetValueCodes(HYPRE_Int on)
 {
    if (on >= 0) { hamd::spmv_value_codes() = on != 0; }
    return hypre_error_flag;
+}
+
+// Slice form of coded short-row matrices for the plans built from now on.  Speed only.
+extern "C" HYPRE_Int hypre_amd_SpmvSetSliceForm(HYPRE_Int on)
+{
+   if (on >= 0) { hamd::spmv_slice_form() = on != 0; }
+   return hypre_error_flag;
+}
+
+// lanes per row (1 or 2) of the slice form in A's plan (built on demand); 0: the matrix has none
+extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanSliceForm(hypre_CSRMatrix *A)
+{
+   if (A->memory_location != HYPRE_MEMORY_DEVICE) { return 0; }
+   hamd::SpmvPlan *p = hamd::get_plan(A);
+   return p->d_sl_data ? p->sl_w : 0;
 }
 
 // number of distinct values in the value table of A's plan (built on demand); 0: the matrix is not coded

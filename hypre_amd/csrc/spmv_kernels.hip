@@ -94,26 +94,26 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum,
    const int row = o.g;
    if (OP == OP_AXPBY)
    {
-      // y = alpha*(A x) + beta*b
-      double r = p.alpha * sum;
-      if (p.beta != 0.0) { r += p.beta * o.b; }
+      // y = alpha*(A x) + beta*b   (roundings spelled out: every kernel of the family gives the same bits for the same row sum)
+      double r = __dmul_rn(p.alpha, sum);
+      if (p.beta != 0.0) { r = __fma_rn(p.beta, o.b, r); }
       p.y[row] = r;
    }
    else if (OP == OP_TSGS)
    {
       // inner step of the two-stage Gauss-Seidel sweep (par_relax_device.c:139-150):
       //    z_out = (L_strict z_in) ./ D ;  u += mult * z_out
-      const double z = sum * (1.0 / o.d);
+      const double z = __dmul_rn(sum, 1.0 / o.d);
       p.y[row] = z;
-      p.aux[row] = o.x + p.alpha * z;
+      p.aux[row] = __fma_rn(p.alpha, z, o.x);
    }
    else
    {
       // Jacobi / l1-Jacobi sweep fused into the SpMV pass (par_relax.c:1216-1244):
       //    y = x + (w f - w (A x)) ./ d      on the marked rows, y = x elsewhere
       if ((OP == OP_JACOBI_CF || OP == OP_JACOBI_MAP) && o.m != p.marker_val) { p.y[row] = o.x; return; }
-      const double t = p.alpha * o.b - p.alpha * sum;
-      p.y[row] = o.x + t / o.d;
+      const double t = __fma_rn(p.alpha, o.b, -__dmul_rn(p.alpha, sum));
+      p.y[row] = __dadd_rn(o.x, t / o.d);
    }
 }
 
@@ -1055,6 +1055,228 @@ void launch_build_xs(const HYPRE_Int *Aj, const int *d_tile_k, int num_tiles, in
 }
 
 // ---------------------------------------------------------------------------
+// Slice form of coded short-row matrices (SpmvPlan::d_sl_data).
+//
+// With the values coded, a tile of the fine-level operators is bound by its own instruction stream (DESIGN.md section 4,
+// round 3): half of it parks products in LDS and sums them up again.  A stencil's rows are short and equally long, so a
+// lane can own a row: the codes and local indices of the 64 lane-rows of a wave lie side by side, entry j of every
+// lane-row in one word position (a sliced ELL layout of what the plan already keeps privately: one byte and two bytes
+// per entry), a workgroup takes 256 / W consecutive rows (W = 1: rows of at most 8 entries; W = 2: at most 32, a lane
+// takes every second entry), stages their x pieces exactly as spmv_xs_kernel stages a tile's, and every lane multiplies
+// and adds its entries in stored order out of registers: one barrier, no products in LDS, no reduction.  Summation:
+// W = 1 is the stored order of the row (what spmv_xs_kernel does for rows of at most 12 entries: same bits; and what the
+// reference's host loop does); W = 2 is two interleaved partial sums added at the end (spmv_xs_kernel's two-lane path,
+// which it takes for tiles of 65 to 128 rows).
+// The kernel reads neither the column array nor the values: the staleness watch samples both per block.
+// ---------------------------------------------------------------------------
+// KP, the entries a lane holds: 8 or 16 (a compile-time count: every load of the stream is then unconditional and the
+// sum a straight line; with run-time word counts the compiler put a wait behind every load)
+template <int OP, int W, int KP>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_sl_kernel(SpmvArgs p, const int *__restrict__ sl_cnt, const int *__restrict__ sl_desc, const int *__restrict__ sl_k0,
+                    const int *__restrict__ sl_fp, const int *__restrict__ sl_perm, const unsigned *__restrict__ sl_data,
+                    int blocks, int num_rows, int nnz, int stage_elems)
+{
+   constexpr int wc = KP / 4, wl = KP / 2;
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *xs = reinterpret_cast<double *>(smem_raw);
+   const double *dictl = xs + stage_elems;
+
+   int block = (int) blockIdx.x;
+   if (sl_perm)
+   {
+      if (block >= blocks) { return; }
+      block = sl_perm[block];
+   }
+   else { const int g = block >> 3, c = block & 7; block = (g >> 3) * 64 + c * 8 + (g & 7); }     // runs of 8 blocks per XCD
+   if ((unsigned) block >= (unsigned) blocks) { return; }
+
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   constexpr int R = SPMV_THREADS / W;
+   // this lane's words of the slice: one trip, issued before anything about the block is known
+   const unsigned *sd = sl_data + ((size_t) (block * 4 + wave) * (size_t) (wc + wl)) * 64 + lane;
+   unsigned cw[wc], lw[wl];
+#pragma unroll
+   for (int w = 0; w < wc; w++) { cw[w] = sd[w * 64]; }
+#pragma unroll
+   for (int w = 0; w < wl; w++) { lw[w] = sd[(wc + w) * 64]; }
+   const int r = block * R + tid / W, sub = tid % W;
+   const int rs = p.Ai[min(r, num_rows)], re = p.Ai[min(r + 1, num_rows)];
+   const RowOps ops = load_row_ops<OP>(p, max(min(r, num_rows - 1), 0));
+   // wave-uniform, through the scalar cache: this wave's piece descriptors, the block's first entry and fingerprint
+   const int *dsc = sl_desc + (size_t) block * XS_DESC + XS_WSEG * wave;
+   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
+#pragma unroll
+   for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
+   const int k0 = sl_k0[block], fp_plan = sl_fp[block];
+   asm volatile("" :: "s"(sl_desc), "s"(sl_k0), "s"(sl_fp), "s"(sl_data), "s"(p.Ai) : "memory");
+#pragma unroll
+   for (int j = 0; j < XS_WSEG; j++)
+   {
+      const unsigned offb = (unsigned) seg_ol[j] >> 16, lanes = (unsigned) seg_ol[j] & 0xffffu;
+      if ((unsigned) lane < lanes)
+      {
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + (size_t) (unsigned) seg_start[j] + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(xs) + offb), 16, 0, 0);
+      }
+   }
+   {
+      const int dl = (p.ndict + 1) >> 1;
+      if (lane < dl - 64 * wave)
+      {
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.dict + 128 * wave + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(const_cast<double *>(dictl)) + 1024 * wave), 16, 0, 0);
+      }
+   }
+   // the watch's samples: two columns and one value of the block's first entries (a second scalar trip, back long before
+   // the vector loads above)
+   const int q0 = min(max(k0, 0), nnz - 1), q1 = min(max(k0, 0) + 1, nnz - 1);
+   const int fc0 = p.Aj[q0], fc1 = p.Aj[q1];
+   const double fv64 = p.Aa[q0];
+   __syncthreads();
+
+   const int mylen = (re - rs - sub + W - 1) / W;
+   double sum = 0.0;
+#pragma unroll
+   for (int j = 0; j < KP; j++)
+   {
+      const unsigned code = (cw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      const unsigned li = (lw[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      {
+#pragma clang fp contract(off)                                  // no fused multiply-add: the tiled kernel rounds every product
+         const double pr = dictl[code] * xs[li];
+         if (j < mylen) { sum = sum + pr; }
+      }
+   }
+   if (W == 2) { sum += __shfl_xor(sum, 1, 64); }
+   if (tid == 0)
+   {
+      const double v0 = dictl[cw[0] & 0xffu];
+      const bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1) || rs != k0 ||
+                       (re > rs && __double_as_longlong(v0) != __double_as_longlong(p.dict_rounded ? (double) (float) fv64 : fv64));
+      if (off) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+   }
+   if (r < num_rows && sub == 0) { row_epilogue<OP>(p, r, sum, ops); }
+}
+
+// ---- slice form construction
+__global__ void sl_block_starts_kernel(const int *__restrict__ Ai, int num_rows, int R, int blocks, int *__restrict__ k0)
+{
+   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b <= blocks) { k0[b] = Ai[min((long long) b * R, (long long) num_rows)]; }
+}
+__global__ void sl_fp_kernel(const int *__restrict__ Aj, const int *__restrict__ k0, int blocks, int nnz, int *__restrict__ fp)
+{
+   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b >= blocks) { return; }
+   const int q0 = min(max(k0[b], 0), nnz - 1), q1 = min(max(k0[b], 0) + 1, nnz - 1);
+   fp[b] = (int) ((unsigned) Aj[q0] * 2654435761u + (unsigned) Aj[q1]);
+}
+template <int W>
+__global__ __launch_bounds__(SPMV_THREADS)
+void sl_pack_kernel(const int *__restrict__ Ai, const unsigned char *__restrict__ codes, const unsigned short *__restrict__ lidx,
+                    int num_rows, int kper, int wc, int wl, unsigned *__restrict__ data)
+{
+   constexpr int R = SPMV_THREADS / W;
+   const int block = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int r = block * R + tid / W, sub = tid % W;
+   const int rs = r < num_rows ? Ai[r] : 0, re = r < num_rows ? Ai[r + 1] : 0;
+   unsigned *out = data + ((size_t) (block * 4 + wave) * (size_t) (wc + wl)) * 64 + lane;
+   for (int w = 0; w < wc; w++)
+   {
+      unsigned word = 0;
+      for (int q = 0; q < 4; q++)
+      {
+         const int j = 4 * w + q, k = rs + sub + j * W;
+         if (j < kper && k < re) { word |= (unsigned) codes[k] << (8 * q); }
+      }
+      out[w * 64] = word;
+   }
+   for (int w = 0; w < wl; w++)
+   {
+      unsigned word = 0;
+      for (int q = 0; q < 2; q++)
+      {
+         const int j = 2 * w + q, k = rs + sub + j * W;
+         if (j < kper && k < re) { word |= (unsigned) lidx[k] << (16 * q); }
+      }
+      out[(wc + w) * 64] = word;
+   }
+}
+
+bool device_build_slice_form(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
+{
+   const int K = p->max_row_nnz, n = A->num_rows, nnz = A->num_nonzeros;
+   if (!p->d_codes || K < 1 || K > 32 || n < 1 || nnz < 1) { return false; }
+   const int W = K <= 8 ? 1 : 2, R = SPMV_THREADS / W;                 // (a lane with 16 entries of its own needs 80 registers)
+   const int kper = (K + W - 1) / W <= 8 ? 8 : 16, wc = kper / 4, wl = kper / 2;      // entries a lane holds: the kernel's KP
+   const long long blocks_ll = ((long long) n + R - 1) / R;
+   // rows about equally long and near 8, 16 or 32 entries: the padded form must not hold more than 1.3 x the entries
+   if ((double) blocks_ll * R * W * kper > 1.3 * (double) nnz + 4096.0 || blocks_ll > (1LL << 28)) { return false; }
+   const int blocks = (int) blocks_ll;
+   int *d_k0 = nullptr, *d_cnt = nullptr, *d_desc = nullptr, *d_fp = nullptr;
+   unsigned short *d_li = nullptr;
+   unsigned *d_data = nullptr;
+   auto fail = [&]() -> bool
+   {
+      for (void *q : {(void *) d_k0, (void *) d_cnt, (void *) d_desc, (void *) d_fp, (void *) d_li, (void *) d_data}) { if (q) { HIP_CHECK(hipFree(q)); } }
+      return false;
+   };
+   HIP_CHECK(hipMalloc((void **) &d_k0, sizeof(int) * ((size_t) blocks + 1)));
+   hipLaunchKernelGGL(sl_block_starts_kernel, dim3((blocks + 256) / 256), dim3(256), 0, s, A->i, n, R, blocks, d_k0);
+   HIP_CHECK(hipMalloc((void **) &d_cnt, sizeof(int) * (size_t) blocks));
+   HIP_CHECK(hipMalloc((void **) &d_desc, sizeof(int) * (size_t) blocks * XS_DESC));
+   const size_t nl = ((size_t) nnz + 15) & ~(size_t) 7;
+   HIP_CHECK(hipMalloc((void **) &d_li, sizeof(unsigned short) * nl));
+   HIP_CHECK(hipMemsetAsync(d_li, 0, sizeof(unsigned short) * nl, s));
+   launch_build_xs(A->j, d_k0, blocks, d_cnt, d_desc, d_li, s);      // a block's entries are at most R * K <= 4096: what the builder sorts
+   std::vector<int> cnt((size_t) blocks);
+   HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t) blocks, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   int units = 0;
+   for (int c : cnt)
+   {
+      if ((c & 0xff) == 0) { return fail(); }            // a block that cannot be staged (or holds no entry): no slice form
+      units = std::max(units, c >> 8);
+   }
+   // LDS: the staged copy and the value table; at least four workgroups per CU
+   if (16 * (size_t) units + 8 * DICT_CAP > 40 * 1024) { return fail(); }
+   const size_t words = (size_t) blocks * 4 * (size_t) (wc + wl) * 64;
+   HIP_CHECK(hipMalloc((void **) &d_data, sizeof(unsigned) * words));
+   if (W == 1) { hipLaunchKernelGGL((sl_pack_kernel<1>), dim3(blocks), dim3(SPMV_THREADS), 0, s, A->i, p->d_codes, d_li, n, kper, wc, wl, d_data); }
+   else        { hipLaunchKernelGGL((sl_pack_kernel<2>), dim3(blocks), dim3(SPMV_THREADS), 0, s, A->i, p->d_codes, d_li, n, kper, wc, wl, d_data); }
+   HIP_CHECK(hipMalloc((void **) &d_fp, sizeof(int) * (size_t) blocks));
+   hipLaunchKernelGGL(sl_fp_kernel, dim3((blocks + 255) / 256), dim3(256), 0, s, A->j, d_k0, blocks, nnz, d_fp);
+   // band-aware placement, as for the tiles (seq_mv.cpp: build_band_placement): XCD c takes the blocks of slab c
+   int *d_perm = nullptr;
+   if (p->band > 0 && blocks >= 64)
+   {
+      const int B = p->band;
+      std::vector<std::vector<int>> cls(8);
+      for (int b = 0; b < blocks; b++)
+      {
+         const int c = (int) (((long long) (((long long) b * R) % B) * 8) / B);
+         cls[(size_t) std::min(std::max(c, 0), 7)].push_back(b);
+      }
+      std::vector<int> perm((size_t) blocks, -1), leftovers;
+      std::vector<size_t> next(8, 0);
+      for (int g = 0; g < blocks; g++) { const size_t c = (size_t) (g & 7); if (next[c] < cls[c].size()) { perm[(size_t) g] = cls[c][next[c]++]; } }
+      for (size_t c = 0; c < 8; c++) { for (size_t k = next[c]; k < cls[c].size(); k++) { leftovers.push_back(cls[c][k]); } }
+      size_t lo = 0;
+      for (int g = 0; g < blocks; g++) { if (perm[(size_t) g] < 0) { perm[(size_t) g] = leftovers[lo++]; } }
+      HIP_CHECK(hipMalloc((void **) &d_perm, sizeof(int) * (size_t) blocks));
+      HIP_CHECK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t) blocks, hipMemcpyHostToDevice, s));
+   }
+   HIP_CHECK(hipStreamSynchronize(s));
+   HIP_CHECK(hipFree(d_li));
+   p->sl_w = W; p->sl_rows = R; p->sl_k = kper; p->sl_wc = wc; p->sl_wl = wl;
+   p->sl_blocks = blocks; p->sl_launch_units = units;
+   p->d_sl_cnt = d_cnt; p->d_sl_desc = d_desc; p->d_sl_k0 = d_k0; p->d_sl_fp = d_fp; p->d_sl_perm = d_perm; p->d_sl_data = d_data;
+   return true;
+}
+
+// ---------------------------------------------------------------------------
 // Wave-per-row SpMV: fallback for matrices with rows longer than SPMV_MAXROW
 // or misaligned arrays (never hit by the AMG hierarchies of the benchmark).
 // ---------------------------------------------------------------------------
@@ -1359,6 +1581,23 @@ static void launch_xs(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
                       plan->num_tiles, plan->prod_elems, rowsum_elems, rp_cap, plan->xs_launch_units);
 }
 
+template <int OP, int W, int KP>
+static void launch_sl_form(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   const int stage_elems = 2 * plan->sl_launch_units + 8;
+   const size_t lds = sizeof(double) * (size_t) (stage_elems + ((a.ndict + 1) & ~1));
+   const int grid = plan->d_sl_perm ? plan->sl_blocks : ((plan->sl_blocks + 63) / 64) * 64;
+   hipLaunchKernelGGL((spmv_sl_kernel<OP, W, KP>), dim3(grid), dim3(SPMV_THREADS), lds, s, a, plan->d_sl_cnt, plan->d_sl_desc, plan->d_sl_k0,
+                      plan->d_sl_fp, plan->d_sl_perm, plan->d_sl_data, plan->sl_blocks, plan->num_rows, plan->nnz, stage_elems);
+}
+template <int OP>
+static void launch_sl(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   if (plan->sl_w == 1) { launch_sl_form<OP, 1, 8>(plan, a, s); }
+   else if (plan->sl_k == 8) { launch_sl_form<OP, 2, 8>(plan, a, s); }
+   else { launch_sl_form<OP, 2, 16>(plan, a, s); }
+}
+
 // the x-staged kernel serves this launch: the plan carries the per-tile piece lists and x can be read in 16-byte pieces
 static inline bool takes_xs(const SpmvPlan *plan, const SpmvArgs &a)
 {
@@ -1371,7 +1610,8 @@ static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
    // x staged through LDS (variant 2, the default)
    if (takes_xs(plan, a))
    {
-      if (a.Ac8) { launch_xs<OP, VF_CODE, FILL>(plan, a, s); }
+      if (a.Ac8 && !FILL && plan->d_sl_data) { launch_sl<OP>(plan, a, s); }      // slice form: a lane per row (or half row)
+      else if (a.Ac8) { launch_xs<OP, VF_CODE, FILL>(plan, a, s); }
       else { launch_xs<OP, F32 ? VF_F32 : VF_F64, FILL>(plan, a, s); }
       return;
    }

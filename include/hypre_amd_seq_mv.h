@@ -153,6 +153,15 @@ HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int unused);
  * A caller that changes the values of a device matrix in place calls hypre_amd_CSRMatrixInvalidatePlan, as for the other
  * things a plan caches. */
 HYPRE_Int hypre_amd_SpmvSetValueCodes(HYPRE_Int on);
+/* Slice form (speed only; no reference counterpart): a coded matrix whose rows hold at most 32 entries and are about equally
+ * long (a stencil) is stored in the plan once more, a row's codes and local indices in one lane's words, and multiplied by a
+ * kernel in which every lane sums its row from registers — no products parked in LDS, no reduction.  Rows of at most 8
+ * entries give the same bits as the tiled kernel; longer ones are summed as two interleaved partial sums (what the tiled
+ * kernel does where a tile holds 65 to 128 rows), within an ulp or two of the row's absolute sum.  On by default (environment:
+ * HYPRE_AMD_SPMV_SLICE_FORM=0); on < 0: unchanged; takes effect for plans built afterwards. */
+HYPRE_Int hypre_amd_SpmvSetSliceForm(HYPRE_Int on);
+/* Lanes per row (1 or 2) of the slice form in the plan of the device matrix A; 0 when it has none. */
+HYPRE_Int hypre_amd_CSRMatrixPlanSliceForm(hypre_CSRMatrix *A);
 /* Number of distinct values in the value table of the plan of the device matrix A; 0 when A is not coded. */
 HYPRE_Int hypre_amd_CSRMatrixPlanValueCodes(hypre_CSRMatrix *A);
 /* x staging of the plan of the device matrix A: returns the number of tiles that take the LDS-staged path of the tiled

@@ -468,3 +468,97 @@ def test_values_changed_behind_a_coded_plan_are_found_out(gpu_lib, oracle):
     for o in (dx, dy):
         lib.hypre_SeqVectorDestroy(o)
     lib.hypre_CSRMatrixDestroy(dA)
+
+
+def _fixed_rows_matrix(n, K, nvals, seed, short_every=0):
+    """every row K entries (or, every `short_every`-th row, K // 2) at random columns of a band around the diagonal, the diagonal
+    first; values from a table of nvals doubles"""
+    rng = np.random.default_rng(seed)
+    table = np.concatenate([[6.0, -1.0], rng.uniform(-2, 2, max(nvals - 2, 0))])[:nvals]
+    counts = np.full(n, K, dtype=np.int64)
+    if short_every:
+        counts[::short_every] = max(K // 2, 1)
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    indptr[1:] = np.cumsum(counts)
+    indices = np.empty(indptr[-1], dtype=np.int32)
+    for r in range(n):
+        lo, hi = max(0, r - 300), min(n, r + 300)
+        others = rng.choice(np.setdiff1d(np.arange(lo, hi), [r]), counts[r] - 1, replace=False)
+        indices[indptr[r]] = r
+        indices[indptr[r] + 1:indptr[r + 1]] = others
+    data = table[rng.integers(0, len(table), indptr[-1])]
+    return sp.csr_matrix((data, indices, indptr), shape=(n, n))
+
+
+@pytest.mark.parametrize("what,lanes", [("7pt", 1), ("27pt", 2), ("K8", 1), ("K13", 2), ("K16", 2), ("K27", 2), ("K32", 2),
+                                        ("K7short", 1), ("K3", 0), ("K20", 0), ("K40", 0)])
+def test_slice_form_of_coded_stencils(gpu_lib, oracle, what, lanes):
+    """A coded matrix with short, equally long rows is multiplied by spmv_sl_kernel (a lane per row, or per half row): the
+    same products as the tiled kernel — bit for bit where both sum a row in stored order (rows of at most 8 entries), within
+    the tolerance of this file otherwise — for every epilogue of y = alpha A x + beta b; matrices the form does not fit
+    (rows much shorter than 8 / 16 / 32 entries, rows longer than 32) do not get it."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    if what == "7pt":
+        A = laplace_3d(24, 20, 18)
+    elif what == "27pt":
+        A = laplace_3d(30, 30, 30, 27)
+    elif what == "K7short":
+        A = _fixed_rows_matrix(5000, 7, 3, 5, short_every=9)
+    else:
+        A = _fixed_rows_matrix(5000, int(what[1:]), 5, int(what[1:]))
+    n = A.shape[0]
+    x, b = rand_vector(n, 1), rand_vector(n, 2)
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.hypre_amd_SpmvSetSliceForm(on)
+            dA = B.csr_from_scipy(A)
+            dx, db, dy = B.vec_from_numpy(x), B.vec_from_numpy(b), B.vec_from_numpy(np.zeros(n))
+            res = []
+            for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.7, -0.3)):
+                lib.hypre_CSRMatrixMatvecOutOfPlace(alpha, dA, dx, beta, db, dy, 0)
+                B.check()
+                res.append(B.vec_to_numpy(dy))
+            assert lib.hypre_amd_CSRMatrixPlanValueCodes(dA) > 0
+            assert lib.hypre_amd_CSRMatrixPlanSliceForm(dA) == (lanes if on else 0)
+            out[on] = res
+            for o in (dx, db, dy):
+                lib.hypre_SeqVectorDestroy(o)
+            lib.hypre_CSRMatrixDestroy(dA)
+    finally:
+        lib.hypre_amd_SpmvSetSliceForm(1)
+    for (alpha, beta), y1, y0 in zip(((1.0, 0.0), (-1.0, 1.0), (0.7, -0.3)), out[1], out[0]):
+        ref = alpha * (A @ x) + beta * b
+        assert np.all(np.abs(y1 - ref) <= _bound(A, x, alpha, beta, b))
+        if lanes == 1:
+            assert np.array_equal(y1.view(np.int64), y0.view(np.int64))
+        else:
+            assert np.all(np.abs(y1 - y0) <= _bound(A, x, alpha, beta, b))
+
+
+def test_the_slice_kernel_notices_another_matrix(gpu_lib, oracle):
+    """spmv_sl_kernel reads neither the column array nor the values: per block it compares two columns with the plan's
+    fingerprint, the first row pointer with the plan's and one decoded value with its fp64 original."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A1 = _fixed_rows_matrix(6000, 8, 4, 3)
+    perm = np.arange(6000)
+    perm[1::2], perm[0:-1:2] = np.arange(0, 5999, 2), np.arange(1, 6000, 2)          # neighbours swapped: the band stays
+    A2 = sp.csr_matrix((A1.data, perm[A1.indices].astype(np.int32), A1.indptr), shape=A1.shape)
+    x = rand_vector(6000, 3)
+    dA = B.csr_from_scipy(A1)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(6000))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert lib.hypre_amd_CSRMatrixPlanSliceForm(dA) == 1
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A1 @ x) <= _bound(A1, x, 1.0, 0.0, x))
+    _overwrite(lib, dA, A2)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    with pytest.raises(B.HypreAmdError):
+        B.check()
+    lib.HYPRE_ClearAllErrors()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A2 @ x) <= _bound(A2, x, 1.0, 0.0, x))
+    for o in (dx, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
