@@ -288,6 +288,14 @@ def main():
     ntiles = (nnz + 2047) // 2048
     vec_bytes = (nloc + 1) * 4 + nloc * 8 + nloc * 8
     spmv_streamed = nnz * ((1 if ndict else value_width) + 2) + vec_bytes + (8 * ndict * ntiles if ndict else 0)
+    # slice form (coded stencils): a lane per row (1) or per half row (2), every lane's 8 or 16 entries padded
+    sl_lanes = int(L.hypre_amd_CSRMatrixPlanSliceForm(diag))
+    if sl_lanes:
+        max_row = 27 if args.problem == "27pt" else 7
+        sl_kp = 8 if -(-max_row // sl_lanes) <= 8 else 16
+        sl_rows = 256 // sl_lanes
+        sl_blocks = -(-nloc // sl_rows)
+        spmv_streamed = sl_blocks * sl_rows * sl_lanes * sl_kp * 3 + vec_bytes + 8 * ndict * sl_blocks
     # Bytes of one cycle on this rank (every rank carries the same share: weak scaling): counted by the launch wrappers
     # over the timed cycles, so the figure follows the smoother, the value width and the levels actually run (two-stage
     # GS: residual pass + inner passes over the strict lower triangle; fp32 values: 4 instead of 8 bytes per entry).
@@ -511,12 +519,14 @@ def main():
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s, "setup_path": setup_path,
                        "matrix_generation_seconds": matrix_s},
-            "roofline": {"bound": "hbm", "kernel": "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS%s)" % (
+            "roofline": {"bound": "hbm", "kernel": ("spmv_sl_kernel<AXPBY, %d lane(s) per row> (fine-level y = A x; x staged through LDS; "
+                                                    "coded stencil in slice form: values as one-byte codes into a table of %d)" % (sl_lanes, ndict)) if sl_lanes else
+                                                   "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS%s)" % (
                              "; matrix values as one-byte codes into a table of %d" % ndict if ndict else ""),
                          "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms,
-                         "value_codes": ndict,
+                         "value_codes": ndict, "slice_form_lanes_per_row": sl_lanes,
                          "streamed_bytes_per_launch": spmv_streamed, "streamed_GBps": spmv_streamed / spmv_ms / 1e6,
                          "streamed_frac": spmv_streamed / spmv_ms / 1e6 / HBM_PEAK_GBS,
                          "note": ("achieved is SURVEY 8(d)'s CSR byte count (12 bytes per entry) over the launch time; with value "

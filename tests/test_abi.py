@@ -110,21 +110,33 @@ def test_hot_kernels_keep_full_occupancy():
         assert r["ScratchSize"] == 0 and r["VGPRs Spill"] == 0, r
 
 
-def _xs_kernel_listing(extra_flags, vf=0):
-    """instructions of spmv_xs_kernel<OP_AXPBY, value form vf (0 fp64, 2 one-byte codes), no fill> as the build's flags
-    compile it (device code only)"""
+_listing_cache = {}
+
+
+def _device_assembly(extra_flags):
+    """device assembly of spmv_kernels.hip as the build's flags compile it (one compile per set of extra flags)"""
     import subprocess
     import tempfile
-    src = os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip")
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, "k.s")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.join(ROOT, "hypre_amd", "csrc"), "-x", "hip", "-S", "--cuda-device-only", "-o", out, src] + extra_flags
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr[-2000:]
-        lines = open(out).read().splitlines()
-    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4hamd14spmv_xs_kernelILi0ELi%dELb0E" % vf) and l.rstrip().endswith(":") is False and ":" in l)
+    key = tuple(extra_flags)
+    if key not in _listing_cache:
+        src = os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip")
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "k.s")
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
+                   "-I" + os.path.join(ROOT, "hypre_amd", "csrc"), "-x", "hip", "-S", "--cuda-device-only", "-o", out, src] + list(extra_flags)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            _listing_cache[key] = open(out).read().splitlines()
+    return _listing_cache[key]
+
+
+def _xs_kernel_listing(extra_flags, vf=0, symbol=None):
+    """instructions of spmv_xs_kernel<OP_AXPBY, value form vf (0 fp64, 2 one-byte codes), no fill> — or of the kernel whose
+    mangled name starts with `symbol` — as the build's flags compile it (device code only)"""
+    lines = _device_assembly(extra_flags)
+    symbol = symbol or "_ZN4hamd14spmv_xs_kernelILi0ELi%dELb0E" % vf
+    start = next(i for i, l in enumerate(lines) if l.startswith(symbol) and l.rstrip().endswith(":") is False and ":" in l)
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     return [l.strip() for l in lines[start:end + 1] if l.startswith("\t") and not l.strip().startswith((".", ";"))]
 
@@ -174,6 +186,14 @@ def test_the_x_staged_kernel_keeps_its_load_schedule():
     assert coded["vm_waits_before_dma"] == [], coded
     assert coded["dma_loads"] == 13, coded
     assert len(coded["vm_waits_dma_to_barrier"]) == 1 and "vmcnt(0)" in coded["vm_waits_dma_to_barrier"][0], coded
+    # the slice form (a lane per row, eight entries a lane): 2 words of codes + 4 of indices per lane before the batch's wait,
+    # the same thirteen LDS-DMA loads, one wait
+    sl = _xs_schedule(_xs_kernel_listing([], symbol="_ZN4hamd14spmv_sl_kernelILi0ELi1ELi8E"))
+    assert sl["first_stream"] < sl["batch_wait"] < sl["first_dma"] < sl["first_barrier"], sl
+    assert sl["stream_loads_before_batch_wait"] >= 6, sl
+    assert sl["vm_waits_before_dma"] == [], sl
+    assert sl["dma_loads"] == 13, sl
+    assert len(sl["vm_waits_dma_to_barrier"]) == 1 and "vmcnt(0)" in sl["vm_waits_dma_to_barrier"][0], sl
 
 
 def test_option_gates_accept_the_built_branch_and_refuse_the_rest(lib):

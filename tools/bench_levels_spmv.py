@@ -41,4 +41,7 @@ for level in range(levels):
     by = nnz * 12 + (nr + 1) * 4 + nr * 16
     nt = C.c_int()
     L.hypre_amd_CSRMatrixPlanInfo(Al.contents.diag, C.byref(nt), None)
+    lanes = L.hypre_amd_CSRMatrixPlanSliceForm(Al.contents.diag)
+    if lanes:                                      # slice form: one workgroup per 256 / lanes rows
+        nt.value = -(-nr // (256 // lanes))
     print("LEVEL %d rows %d nnz %d tiles %d bytes %d : %.4f ms  %.0f GB/s" % (level, nr, nnz, nt.value, by, ms, by / ms / 1e6), flush=True)

@@ -37,7 +37,7 @@ def level_of(grid_size, wg=256):
 kernel_rows = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"]:
+        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"] or "spmv_sl_kernel" in r["Kernel_Name"]:
             lv = level_of(int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]))
             if lv is not None:
                 kernel_rows[lv].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
@@ -51,7 +51,7 @@ for lv, v in kernel_rows.items():
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"]:
+        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"] or "spmv_sl_kernel" in r["Kernel_Name"]:
             lv = level_of(int(r["Grid_Size"]))
             if lv is not None:
                 agg[lv][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -79,6 +79,7 @@ import hashlib
 with open(os.path.join("hypre_amd", "csrc", "spmv_kernels.hip"), "rb") as fh:
     kernel_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
 out = {"tag": tag, "kernel_source_sha16": kernel_sha, "value_codes": os.environ.get("HYPRE_AMD_SPMV_VALUE_CODES", "1") != "0",
+       "slice_form": os.environ.get("HYPRE_AMD_SPMV_VALUE_CODES", "1") != "0" and os.environ.get("HYPRE_AMD_SPMV_SLICE_FORM", "1") != "0",
         "command": "bash tools/pmc_levels.sh %s  (rocprofv3 --kernel-trace --stats, then one --pmc pass per counter set, "
                               "each over python3 tools/bench_levels_spmv.py 256 3 10)" % tag,
        "matrix": "levels 0-2 of the 256^3 7-pt hierarchy (PMIS, ext+i(4))",
