@@ -550,11 +550,11 @@ constexpr int XS_DESC  = 2 * XS_SEGS;       // ints per tile in the plan: first 
 #ifndef XS_TIMING
 #define XS_TIMING 0
 #endif
-// experiments (wrong products, timing only): XS_EXP_SLOTS < XS_WSEG stages only the first pieces of every wave,
-// XS_EXP_NOREDUCE replaces the row sums by one store per lane
 #ifndef XS_OPS2
-#define XS_OPS2 1
+#define XS_OPS2 1              // operands of a second row per lane fetched with the first (0: as before, for comparison)
 #endif
+// experiments (wrong products, timing only; tools/experiments/build_variant.sh): XS_EXP_SLOTS < XS_WSEG stages only the first
+// pieces of every wave, XS_EXP_NOREDUCE replaces the row sums by one store per lane
 #ifndef XS_EXP_SLOTS
 #define XS_EXP_SLOTS 1000
 #endif
