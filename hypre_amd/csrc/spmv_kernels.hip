@@ -1497,10 +1497,17 @@ bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out,
    HIP_CHECK(hipMemsetAsync(d_table, 0xff, sizeof(unsigned long long) * DICT_SLOTS, s));
    HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int) * 4, s));
    const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(Aa);
-   int grid = (int) std::min<size_t>((nnz + 255) / 256, (size_t) 8 * handle().num_cus);
-   hipLaunchKernelGGL(dict_collect_kernel, dim3(grid), dim3(256), 0, s, bits, nnz, d_table, d_count);
-   std::vector<unsigned long long> table(DICT_SLOTS);
+   // a first look at the head of the array settles the matrices that are not stencils (every thread of a full-size launch
+   // would fight over the table's 1024 slots first: half a millisecond per matrix of a hierarchy)
    int count = 0;
+   const size_t head = std::min<size_t>(nnz, 16384);
+   hipLaunchKernelGGL(dict_collect_kernel, dim3((unsigned) ((head + 255) / 256)), dim3(256), 0, s, bits, head, d_table, d_count);
+   HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   if (count > DICT_CAP) { HIP_CHECK(hipFree(d_table)); return false; }
+   int grid = (int) std::min<size_t>((nnz + 255) / 256, (size_t) 8 * handle().num_cus);
+   if (nnz > head) { hipLaunchKernelGGL(dict_collect_kernel, dim3(grid), dim3(256), 0, s, bits, nnz, d_table, d_count); }
+   std::vector<unsigned long long> table(DICT_SLOTS);
    HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipMemcpyAsync(table.data(), d_table, sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));

@@ -441,6 +441,27 @@ def test_value_codes_give_the_same_bits(gpu_lib, oracle, nvals, shape, lo, hi):
     assert np.all(np.abs(out[1] - (-0.75 * (A @ x) + 1.5 * b))[ok] <= bound[ok])
 
 
+def test_a_matrix_that_only_starts_like_a_stencil_is_not_coded(gpu_lib, oracle):
+    """The search for value codes looks at the first 16 384 values before it scans them all: a matrix whose head holds three
+    values and whose tail holds thousands must come out uncoded (and multiplied right)."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = random_csr(6000, 6000, 8, 12, seed=77)
+    rng = np.random.default_rng(78)
+    A.data[:] = rng.choice([6.0, -1.0, 0.5], A.nnz)
+    A.data[40000:] = rng.uniform(-1, 1, A.nnz - 40000)
+    x = rand_vector(6000, 5)
+    dA = B.csr_from_scipy(A)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(6000))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert lib.hypre_amd_CSRMatrixPlanValueCodes(dA) == 0
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A @ x) <= _bound(A, x, 1.0, 0.0, x))
+    for o in (dx, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
+
+
 def test_values_changed_behind_a_coded_plan_are_found_out(gpu_lib, oracle):
     """The coded kernel never reads the fp64 values: every tile compares the first value it decodes with the fp64 original,
     so values changed in place without hypre_amd_CSRMatrixInvalidatePlan raise HYPRE_ERROR_GENERIC and the synchronous
