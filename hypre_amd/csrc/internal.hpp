@@ -166,9 +166,10 @@ void bump_plan_generation();
 // caches that pre-digest a matrix and are found again by its address (colour classes: a colour-sorted COPY of the values;
 // level schedules of the hybrid sweeps: the dependency levels of the pattern): the same exposure as the SpMV plan's — the
 // caller frees the matrix with hypre's own destroy routine, the next one lands on the same addresses.
+constexpr int MATRIX_FP_WORDS = 16;       // partial fingerprints (one per workgroup of the checking launch)
 struct MatrixWatch
 {
-   unsigned long long *d_fp = nullptr;
+   unsigned long long *d_fp = nullptr;    // [MATRIX_FP_WORDS]
    int *h_stale = nullptr, *d_stale = nullptr;
 };
 void watch_record(MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hipStream_t s);

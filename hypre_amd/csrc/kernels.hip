@@ -590,16 +590,18 @@ void launch_sort_rows(const int *Ai, int *Aj, double *Aa, int n, int keep_first,
    hipLaunchKernelGGL(sort_rows_kernel, dim3(grid), dim3(64), 0, s, n, Ai, Aj, Aa, keep_first);
 }
 
-// fingerprint of a CSR matrix over 4096 positions spread over its rows and entries (MatrixWatch, internal.hpp)
+// fingerprint of a CSR matrix over 4096 positions spread over its rows and entries (MatrixWatch, internal.hpp): sixteen
+// workgroups, a position per lane, a partial fingerprint per workgroup — the positions are cold cache lines, and one
+// workgroup fetching all 12 288 of them took 26 us per check, 0.4 ms of a multicolour cycle
+constexpr int FP_BLOCKS = 16;
 __global__ __launch_bounds__(256)
 void matrix_fingerprint_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, const double *__restrict__ Aa, int n, int nnz,
                                unsigned long long *fp, int *stale, int record)
 {
    auto mix = [](unsigned long long x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; };
    unsigned long long h = 0ull;
-   for (int q = 0; q < 16; q++)
    {
-      const long long k = (long long) threadIdx.x * 16 + q;
+      const long long k = (long long) blockIdx.x * 256 + threadIdx.x;
       if (n > 0) { const int r = (int) (k * n / 4096); h ^= mix((unsigned long long) (unsigned) Ai[r + 1] + ((unsigned long long) k << 32)); }
       if (nnz > 0)
       {
@@ -619,14 +621,16 @@ void matrix_fingerprint_kernel(const int *__restrict__ Ai, const int *__restrict
    if (threadIdx.x == 0)
    {
       h = part[0] ^ part[1] ^ part[2] ^ part[3];
-      if (record) { *fp = h; }
-      else if (*fp != h) { __hip_atomic_fetch_or(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+      if (record) { fp[blockIdx.x] = h; }
+      else if (fp[blockIdx.x] != h) { __hip_atomic_fetch_or(stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
    }
 }
+// fp: MATRIX_FP_WORDS values
 void launch_matrix_fingerprint(const int *Ai, const int *Aj, const double *Aa, int n, int nnz, unsigned long long *fp, int *stale,
                                int record, hipStream_t s)
 {
-   hipLaunchKernelGGL(matrix_fingerprint_kernel, dim3(1), dim3(256), 0, s, Ai, Aj, Aa, n, nnz, fp, stale, record);
+   static_assert(FP_BLOCKS == MATRIX_FP_WORDS, "one partial fingerprint per workgroup");
+   hipLaunchKernelGGL(matrix_fingerprint_kernel, dim3(FP_BLOCKS), dim3(256), 0, s, Ai, Aj, Aa, n, nnz, fp, stale, record);
 }
 
 void launch_deinterleave(const double *in, double *out, int n, int nv, hipStream_t s)

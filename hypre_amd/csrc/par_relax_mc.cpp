@@ -38,6 +38,8 @@ struct McPlan
    int n = 0, nnz = 0;
    int num_colors = 0;
    bool small = false;                         // swept by the one-workgroup kernel: no per-colour matrices
+   int  tail_from = -1;                        // large levels: the colours from here on hold a few dozen rows each (first-fit leaves
+                                               // many such) and are swept together by the one-workgroup kernel; -1: none
    std::vector<hypre_CSRMatrix *> rows_of;     // [num_colors] device CSR views: the rows of one colour (large levels)
    std::vector<int>               count;       // rows per colour
    std::vector<int>               cstart;      // [num_colors + 1] where every colour starts in d_order
@@ -72,7 +74,8 @@ void free_mc(McPlan *m)
    delete m;
 }
 
-constexpr int MC_SMALL_NNZ = 200000;           // levels of at most this many entries are swept by one workgroup
+constexpr int MC_SMALL_NNZ = 20000;            // levels of at most this many entries are swept by one workgroup (a level of
+                                               // 77 000 entries and 25 colours: 270 us per sweep that way, 125 us as 25 launches)
 
 McPlan *get_mc(hypre_CSRMatrix *A)
 {
@@ -125,6 +128,12 @@ McPlan *get_mc(hypre_CSRMatrix *A)
    m->small = A->num_nonzeros <= MC_SMALL_NNZ;
    if (!m->small)
    {
+      // the tail of small colours: every colour from tail_from on fits one pass of the one-workgroup kernel (128 rows), and
+      // there are at least three of them (a colour there costs a chain of loads and a barrier, about 3.5 us, against the
+      // 5 - 6 us of a launch of its own)
+      int c0 = C;
+      while (c0 > 0 && m->count[(size_t) c0 - 1] <= 128) { c0--; }
+      m->tail_from = (C - c0 >= 3) ? c0 : -1;
       std::vector<int> slice0, slice_nnz;
       device_color_matrices(n, C, m->d_color, m->d_order, m->cstart, A->i, A->j, A->data, &m->d_ptr, &m->d_cj, &m->d_ca, slice0, slice_nnz, s);
       m->rows_of.assign((size_t) C, nullptr);
@@ -245,9 +254,22 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
                             ft, d, masked ? cf_marker : nullptr, relax_points, relax_weight, ud, n, dg->num_nonzeros, s);
    }
    else
-   for (int q = 0; q < C; q++)
    {
-      const int c = direction > 0 ? q : C - 1 - q;
+   // colours [0, big) by a launch each, colours [big, C) — the small ones — by the one-workgroup kernel, in sweep order
+   const int big = m->tail_from >= 0 ? m->tail_from : C;
+   auto sweep_tail = [&]()
+   {
+      if (big >= C) { return; }
+      const bool masked = relax_points != 0 && cf_marker;
+      launch_mc_small_sweep(C - big, direction, m->d_cstart + big, m->d_order, dg->i, dg->j, dg->data,
+                            handle().fp32_values ? fp32_values_of(dg) : nullptr, ft, d, masked ? cf_marker : nullptr, relax_points,
+                            relax_weight, ud, m->cstart[(size_t) C] - m->cstart[(size_t) big],
+                            (int) ((long long) (m->cstart[(size_t) C] - m->cstart[(size_t) big]) * dg->num_nonzeros / std::max(n, 1)), s);
+   };
+   if (direction <= 0) { sweep_tail(); }
+   for (int q = 0; q < big; q++)
+   {
+      const int c = direction > 0 ? q : big - 1 - q;
       hypre_CSRMatrix *M = m->rows_of[(size_t) c];
       if (M->num_rows <= 0) { continue; }
       SpmvPlan *plan = get_plan(M);
@@ -260,6 +282,8 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
       spmv_default_flags(a);
       if (!(relax_points != 0 && cf_marker)) { a.marker = nullptr; }
       launch_spmv(plan, a, OP_JACOBI_MAP, s);
+   }
+   if (direction > 0) { sweep_tail(); }
    }
    u->all_zeros = 0;
    handle().sync_compute = saved;

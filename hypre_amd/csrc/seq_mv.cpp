@@ -178,7 +178,7 @@ void watch_record(MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hi
    watch_release(w);
    w.h_stale = take_stale_slot(&w.d_stale);
    if (!w.h_stale) { return; }
-   HIP_CHECK(hipMalloc((void **) &w.d_fp, sizeof(unsigned long long)));
+   HIP_CHECK(hipMalloc((void **) &w.d_fp, sizeof(unsigned long long) * MATRIX_FP_WORDS));
    launch_matrix_fingerprint(A->i, A->j, with_values ? A->data : nullptr, A->num_rows, A->num_nonzeros, w.d_fp, w.d_stale, 1, s);
 }
 void watch_check(const MatrixWatch &w, const hypre_CSRMatrix *A, bool with_values, hipStream_t s)
