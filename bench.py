@@ -264,43 +264,60 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     dof_per_s = nglob / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel: fine-level CSR SpMV y = A x ------------------
+    # ---- kernel figures: y = A x of the fine-level operator (as launched) and of level 1 ------------------
+    # Every figure carries two byte counts, both taken from the library's own launch accounting (hypre_amd_ByteCounters
+    # around one launch): `csr` = SURVEY.md 8(d)'s count (12 bytes per entry, row pointers, vectors once) and `streamed` =
+    # what the FORMAT the launched kernel reads requires (16-bit local indices instead of columns; one-byte value codes;
+    # padded slices).  The roofline fraction is streamed bytes / time / peak — at most 1 by construction, cross-checked
+    # against PMC traffic (profiles/) —; the CSR count over the same time is reported as `effective_csr_GBps`, a rate, not
+    # a fraction of anything.
     diag = Am.diag
     nnz = diag.contents.num_nonzeros
-    x = B.vec_from_numpy(np.random.default_rng(rank).uniform(-1, 1, nloc))
-    y = B.vec_from_numpy(np.zeros(nloc))
     reps = 50
-    for _ in range(5):
-        L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
-    L.hypre_SyncComputeStream()
-    L.hypre_amd_EventTimerStart()
-    for _ in range(reps):
-        L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
-    spmv_ms = L.hypre_amd_EventTimerStopMs() / reps
-    spmv_bytes = nnz * 12 + (nloc + 1) * 4 + nloc * 8 + nloc * 8
-    spmv_gbs = spmv_bytes / spmv_ms / 1e6
-    # Value codes: a matrix with at most 256 distinct values (these stencils hold 2 - 3) is streamed as one byte per entry
-    # plus a 16-bit local index; the algorithmic (CSR) count above then overstates what the launch reads, and `achieved`
-    # can exceed the HBM peak.  Reported beside it: what the kernel is designed to stream, and the same launch with the
-    # codes switched off (fp64 values streamed: what a variable-coefficient operator of this size gets).
-    ndict = int(L.hypre_amd_CSRMatrixPlanValueCodes(diag))
+    FORMS = {0: "spmv_wave_kernel (a wave per row)", 1: "spmv_tiled_kernel (x gathered through the cache)",
+             2: "spmv_xs_kernel (2048-entry tiles, x staged through LDS, fp64 values + 16-bit local indices)",
+             3: "spmv_xs_kernel, coded (2048-entry tiles, x staged through LDS, one-byte value codes + 16-bit local indices)",
+             4: "spmv_sl_kernel (coded stencil in slice form: a lane per row or half row, codes and local indices in registers)",
+             5: "spmv_rs_kernel (row-slice form: jagged slices of fp64 values + 16-bit local indices, sums in registers)"}
+
+    def spmv_figure(M, seed):
+        """y = M x through the public entry: HIP-event time per launch, the library's two byte counts of one launch"""
+        mc = M.contents
+        xv = B.vec_from_numpy(np.random.default_rng(seed).uniform(-1, 1, mc.num_cols))
+        yv = B.vec_from_numpy(np.zeros(mc.num_rows))
+        for _ in range(5):
+            L.hypre_CSRMatrixMatvec(1.0, M, xv, 0.0, yv)
+        L.hypre_SyncComputeStream()
+        L.hypre_amd_ByteCounters(None, None, 1)
+        L.hypre_CSRMatrixMatvec(1.0, M, xv, 0.0, yv)
+        c1, s1 = C.c_double(), C.c_double()
+        L.hypre_amd_ByteCounters(C.byref(c1), C.byref(s1), 1)
+        L.hypre_SyncComputeStream()
+        L.hypre_amd_EventTimerStart()
+        for _ in range(reps):
+            L.hypre_CSRMatrixMatvec(1.0, M, xv, 0.0, yv)
+        ms = L.hypre_amd_EventTimerStopMs() / reps
+        L.hypre_SeqVectorDestroy(xv)
+        L.hypre_SeqVectorDestroy(yv)
+        B.check()
+        form = int(L.hypre_amd_CSRMatrixPlanForm(M))
+        csr_b = mc.num_nonzeros * (4 + value_width) + (mc.num_rows + 1) * 4 + mc.num_cols * 8 + mc.num_rows * 8      # SURVEY.md 8(d)
+        streamed = s1.value
+        frac = streamed / ms / 1e6 / HBM_PEAK_GBS
+        assert frac <= 1.0, "roofline fraction above 1: the byte count is not what the kernel moves"
+        return {"kernel": FORMS.get(form, "?"), "form": form, "rows": mc.num_rows, "nnz": mc.num_nonzeros, "ms_per_launch": ms,
+                "streamed_bytes_per_launch": streamed, "achieved": streamed / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": frac, "csr_bytes_per_launch": csr_b, "library_csr_count": c1.value,
+                "effective_csr_GBps": csr_b / ms / 1e6,
+                "value_codes": int(L.hypre_amd_CSRMatrixPlanValueCodes(M))}
+
     value_width = 4 if args.mixed else 8
-    ntiles = (nnz + 2047) // 2048
-    vec_bytes = (nloc + 1) * 4 + nloc * 8 + nloc * 8
-    spmv_streamed = nnz * ((1 if ndict else value_width) + 2) + vec_bytes + (8 * ndict * ntiles if ndict else 0)
-    # slice form (coded stencils): a lane per row (1) or per half row (2), every lane's 8 or 16 entries padded
-    sl_lanes = int(L.hypre_amd_CSRMatrixPlanSliceForm(diag))
-    if sl_lanes:
-        max_row = 27 if args.problem == "27pt" else 7
-        sl_kp = 8 if -(-max_row // sl_lanes) <= 8 else 16
-        sl_rows = 256 // sl_lanes
-        sl_blocks = -(-nloc // sl_rows)
-        spmv_streamed = sl_blocks * sl_rows * sl_lanes * sl_kp * 3 + vec_bytes + 8 * ndict * sl_blocks
+    fine = spmv_figure(diag, rank)
+    ndict = fine["value_codes"]
+    spmv_bytes = fine["csr_bytes_per_launch"]
     # Bytes of one cycle on this rank (every rank carries the same share: weak scaling): counted by the launch wrappers
     # over the timed cycles, so the figure follows the smoother, the value width and the levels actually run (two-stage
     # GS: residual pass + inner passes over the strict lower triangle; fp32 values: 4 instead of 8 bytes per entry).
-    # csr = SURVEY 8(d)'s CSR count, streamed = what the kernels are designed to read (8 + 2 / 4 + 2 bytes per entry of the
-    # x-staged kernel).  The setup's closed formula (l1-Jacobi V(1,1) on CSR) stays beside them as a cross-check.
     cycle_bytes = b_csr.value / args.steps
     cycle_streamed = b_str.value / args.steps
     cycle_formula = L.hypre_amd_BoomerAMGCycleBytes(s)
@@ -352,46 +369,43 @@ def main():
         L.HYPRE_ClearAllErrors()
     # ---- after the solves (dropping the plan of the fine-level matrix also drops what else the library cached for it — the
     # strictly lower copy of the two-stage sweeps, colour classes, level schedules —, which the next solve would rebuild)
-    uncoded = None
+    # the same cycle and the same fine-level launch with the value codes OFF: what a variable-coefficient operator of this
+    # size gets (fp64 values streamed by the tiled kernel) — the general-CSR figures of this run
+    fine_general, ms_per_step_codes_off = fine, ms_per_step
     if ndict:
         L.hypre_amd_SpmvSetValueCodes(0)
         L.hypre_amd_CSRMatrixInvalidatePlan(diag)
-        for _ in range(5):
-            L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
-        L.hypre_SyncComputeStream()
-        L.hypre_amd_EventTimerStart()
-        for _ in range(reps):
-            L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)
-        u_ms = L.hypre_amd_EventTimerStopMs() / reps
+        fine_general = spmv_figure(diag, rank)
+        for _ in range(warm):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if transport == "rccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        ms_per_step_codes_off = 1e3 * el / args.steps
         L.hypre_amd_SpmvSetValueCodes(1)
         L.hypre_amd_CSRMatrixInvalidatePlan(diag)
-        L.hypre_CSRMatrixMatvec(1.0, diag, x, 0.0, y)                  # the coded plan again, for what follows
-        L.hypre_SyncComputeStream()
+        step()                                                         # the coded plans again, for what follows
+        fence()
         B.check()
-        uncoded = {"ms_per_launch": u_ms, "achieved": spmv_bytes / u_ms / 1e6, "frac": spmv_bytes / u_ms / 1e6 / HBM_PEAK_GBS,
-                   "unit": "GB/s", "streamed_bytes_per_launch": nnz * (value_width + 2) + vec_bytes,
-                   "what": "the same launch with hypre_amd_SpmvSetValueCodes(0): matrix values streamed as %s" % ("fp32" if args.mixed else "fp64")}
     # the largest launch of the cycle below the fine level: y = A_1 x on this rank's block of level 1 (values all distinct)
     level1 = None
     if int(L.hypre_amd_BoomerAMGGetNumLevels(s)) > 2:
         lv1_A = C.cast(L.hypre_amd_BoomerAMGGetA(s, 1), C.POINTER(B.ParCSRMatrix)).contents.diag
-        lv1_n, lv1_nnz = lv1_A.contents.num_rows, lv1_A.contents.num_nonzeros
-        if lv1_n > 0 and lv1_nnz > 0:
-            lv1_x = B.vec_from_numpy(np.random.default_rng(rank + 7).uniform(-1, 1, lv1_A.contents.num_cols))
-            lv1_y = B.vec_from_numpy(np.zeros(lv1_n))
-            for _ in range(5):
-                L.hypre_CSRMatrixMatvec(1.0, lv1_A, lv1_x, 0.0, lv1_y)
-            L.hypre_SyncComputeStream()
-            L.hypre_amd_EventTimerStart()
-            for _ in range(reps):
-                L.hypre_CSRMatrixMatvec(1.0, lv1_A, lv1_x, 0.0, lv1_y)
-            lv1_ms = L.hypre_amd_EventTimerStopMs() / reps
-            lv1_by = lv1_nnz * (4 + value_width) + (lv1_n + 1) * 4 + lv1_A.contents.num_cols * 8 + lv1_n * 8
-            level1 = {"rows": lv1_n, "nnz": lv1_nnz, "algorithmic_bytes_per_launch": lv1_by, "ms_per_launch": lv1_ms, "achieved": lv1_by / lv1_ms / 1e6,
-                      "unit": "GB/s", "frac": lv1_by / lv1_ms / 1e6 / HBM_PEAK_GBS, "value_codes": int(L.hypre_amd_CSRMatrixPlanValueCodes(lv1_A))}
-            L.hypre_SeqVectorDestroy(lv1_x)
-            L.hypre_SeqVectorDestroy(lv1_y)
-            B.check()
+        if lv1_A.contents.num_rows > 0 and lv1_A.contents.num_nonzeros > 0:
+            level1 = spmv_figure(lv1_A, rank + 7)
+    # the kernel with the largest share of the timed cycle: each level's operator is passed over twice per V(1,1) cycle
+    # (residual, post-smoothing sweep; the pre-smoothing starts from zero), so the larger of the two launches decides
+    dominant, dominant_level = fine, 0
+    if level1 is not None and level1["ms_per_launch"] > fine["ms_per_launch"]:
+        dominant, dominant_level = level1, 1
     # HBM traffic per launch cannot be read from inside the process (PMC counters need rocprofv3 around it): the figure is
     # taken from the newest committed --pmc pass over this same kernel and matrix (profiles/, tools/pmc_levels.sh) when
     # the workload matches, and labelled as what it is: a profile-derived number of an earlier run of this kernel — with
@@ -402,13 +416,13 @@ def main():
         import hashlib
         with open(os.path.join(ROOT, "hypre_amd", "csrc", "spmv_kernels.hip"), "rb") as fh:
             kernel_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
-        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "levels_xs" in f and f.endswith("_summary.json")
-                           and (("codes" in f) == bool(ndict)))
+        pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "levels_" in f and f.endswith("_summary.json")
+                           and "gather" not in f and (("codes" in f) == bool(dominant["value_codes"])))
         if pmc_files:
             with open(os.path.join(ROOT, "profiles", pmc_files[-1])) as fh:
                 summary = json.load(fh)
-            pmc = summary["levels"]["0"]
-            if int(pmc.get("algorithmic_bytes_per_launch", -1)) == int(spmv_bytes) and "hbm_traffic_bytes_per_launch" in pmc:
+            pmc = summary["levels"][str(dominant_level)]
+            if int(pmc.get("algorithmic_bytes_per_launch", -1)) == int(dominant["csr_bytes_per_launch"]) and "hbm_traffic_bytes_per_launch" in pmc:
                 traffic = pmc["hbm_traffic_bytes_per_launch"]
                 same = summary.get("kernel_source_sha16") == kernel_sha
                 traffic_src = "profile-derived, not of this run: profiles/%s (%s)" % (
@@ -519,26 +533,26 @@ def main():
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s, "setup_path": setup_path,
                        "matrix_generation_seconds": matrix_s},
-            "roofline": {"bound": "hbm", "kernel": ("spmv_sl_kernel<AXPBY, %d lane(s) per row> (fine-level y = A x; x staged through LDS; "
-                                                    "coded stencil in slice form: values as one-byte codes into a table of %d)" % (sl_lanes, ndict)) if sl_lanes else
-                                                   "spmv_xs_kernel<AXPBY> (fine-level y = A x; x staged through LDS%s)" % (
-                             "; matrix values as one-byte codes into a table of %d" % ndict if ndict else ""),
-                         "achieved": spmv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+            # the kernel with the largest share of the timed cycle; frac = streamed bytes / time / peak (<= 1 by construction)
+            "roofline": {"bound": "hbm", "kernel": "y = A_%d x: %s" % (dominant_level, dominant["kernel"]), "level": dominant_level,
+                         "achieved": dominant["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dominant["frac"],
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": spmv_bytes, "ms_per_launch": spmv_ms,
-                         "value_codes": ndict, "slice_form_lanes_per_row": sl_lanes,
-                         "streamed_bytes_per_launch": spmv_streamed, "streamed_GBps": spmv_streamed / spmv_ms / 1e6,
-                         "streamed_frac": spmv_streamed / spmv_ms / 1e6 / HBM_PEAK_GBS,
-                         "note": ("achieved is SURVEY 8(d)'s CSR byte count (12 bytes per entry) over the launch time; with value "
-                                  "codes the launch reads 3 bytes per entry, so achieved may exceed the HBM peak: the launch is "
-                                  "bounded by its streamed bytes (streamed_frac) and by instruction issue, not by the CSR count"
-                                  if ndict else None),
-                         "uncoded": uncoded, "level1": level1,
+                         "bytes_per_launch": dominant["streamed_bytes_per_launch"], "ms_per_launch": dominant["ms_per_launch"],
+                         "bytes_are": "what the launched kernel's format requires (library accounting of one launch), not the CSR count",
+                         "effective_csr_GBps": dominant["effective_csr_GBps"], "csr_bytes_per_launch": dominant["csr_bytes_per_launch"],
+                         "share_of_cycle": 2.0 * dominant["ms_per_launch"] / ms_per_step,
                          "device_copy_GBps_this_box": copy_gbs},
-            "vcycle": {"algorithmic_bytes": cycle_bytes, "achieved_GBps": cycle_bytes / ms_per_step / 1e6,
-                       "frac_of_hbm_peak": cycle_bytes / ms_per_step / 1e6 / HBM_PEAK_GBS,
-                       "streamed_bytes": cycle_streamed, "streamed_GBps": cycle_streamed / ms_per_step / 1e6,
-                       "streamed_frac_of_hbm_peak": cycle_streamed / ms_per_step / 1e6 / HBM_PEAK_GBS,
+            # top-level so that a parser that keeps only first-level keys keeps them: the fine-level operator as launched
+            # (coded stencil), the same operator as general CSR (codes off: fp64 values), level 1, the cycle with codes off
+            "spmv_fine_as_launched": fine,
+            "spmv_fine_general_csr": fine_general,
+            "spmv_level1": level1,
+            "ms_per_step_codes_off": ms_per_step_codes_off,
+            "value_codes_off_DOF_per_s": nglob / (ms_per_step_codes_off * 1e-3),
+            "vcycle": {"streamed_bytes": cycle_streamed, "achieved_GBps": cycle_streamed / ms_per_step / 1e6,
+                       "frac_of_hbm_peak": cycle_streamed / ms_per_step / 1e6 / HBM_PEAK_GBS,
+                       "bytes_are": "what the launched kernels' formats require; the CSR count is effective_csr_*",
+                       "effective_csr_bytes": cycle_bytes, "effective_csr_GBps": cycle_bytes / ms_per_step / 1e6,
                        "per": "GPU (rank 0's launches; every rank carries the same share)",
                        "counted_by": "the library's launch wrappers over the timed cycles (hypre_amd_ByteCounters)",
                        "jacobi_csr_formula_bytes": cycle_formula},

@@ -188,6 +188,13 @@ PROTOTYPES = {
     "hypre_CSRMatrixMatvecDevice": (Int, [Int, Real, CSRp, Vecp, Real, Vecp, Vecp, Int]),
     "hypre_CSRMatrixSpMVDevice": (Int, [Int, Real, CSRp, Vecp, Real, Vecp, Int]),
     "hypre_amd_CSRMatrixInvalidatePlan": (Int, [CSRp]),
+    "hypre_amd_CSRMatrixVerifyPlan": (Int, [CSRp]),
+    "hypre_amd_CSRMatrixSetImmutable": (Int, [CSRp, Int]),
+    "hypre_amd_CSRMatrixPlanForm": (Int, [CSRp]),
+    "hypre_amd_PlanTestFailAlloc": (Int, [Int, Int]),
+    "hypre_amd_SetMixedPrecisionValues": (Int, [Int]),
+    "hypre_amd_SpmvSetRowSlices": (Int, [Int]),
+    "hypre_amd_CSRMatrixPlanRowSlices": (Int, [CSRp, IntP, IntP]),
     "hypre_amd_CSRMatrixSortRows": (Int, [CSRp, Int]),
     "hypre_amd_SpmvSetBandPolicy": (Int, [Int, Int, Int]),
     "hypre_amd_SpmvSetVariant": (Int, [Int, Int]),

@@ -140,6 +140,24 @@ struct SpmvPlan
    int      *d_sl_k0 = nullptr, *d_sl_fp = nullptr;       // per block: position of its first entry; fingerprint of two of its columns
    int      *d_sl_perm = nullptr;                          // workgroup -> block (band-aware placement), or null
    unsigned *d_sl_data = nullptr;                          // [sl_blocks][4 waves][sl_wc + sl_wl][64 lanes]
+   // Row-slice form (spmv_rs_kernel): matrices that cannot change behind their plans (owned) and are not coded — the Galerkin
+   // operators of the coarse levels, 30 - 90 entries per row, every value distinct — are stored once more as JAGGED SLICES:
+   // a workgroup takes rs_rows = 256 / rs_w consecutive rows, rs_w lanes per row (lane `sub` takes entries sub, sub + rs_w,
+   // ... of its row); the 64 lane-tasks of a wave are sorted by their entry counts, and entry c of every task that has one
+   // is stored side by side (jagged diagonals: chunk c of a wave holds as many entries as tasks are longer than c) — fp64
+   // value and 16-bit staged position (byte offset) in two arrays at the same positions, NO padding: 10 bytes per entry
+   // and no row pointers.  Every lane multiplies and adds its entries in stored order out of registers, the rs_w partial
+   // sums of a row meet in LDS (added in lane order by the lane that finishes the row): no products parked, no tree.
+   int             rs_w = 0, rs_rows = 0, rs_kp = 0;     // lanes per row; rows per workgroup; most entries a lane holds (8, 16, 24, 32: the kernel's KP)
+   int             rs_blocks = 0, rs_units = 0;          // workgroups; longest staged copy of x (2-column units)
+   int            *d_rs_desc = nullptr;                  // per block: x piece descriptors, as d_xs_desc per tile
+   int            *d_rs_perm = nullptr;                  // workgroup -> block (band-aware placement), or null
+   int            *d_rs_hdr = nullptr;                   // per wave 16 ints: position of its first entry, chunks, active lanes per chunk (bytes)
+   unsigned       *d_rs_meta = nullptr;                  // per lane: slot of its partial sum | (entries << 10)
+   double         *d_rs_val = nullptr;                   // [nnz] values in slice order
+   float          *d_rs_val32 = nullptr;                 // the same in fp32 (mixed precision; made at the first such launch)
+   unsigned       *d_rs_idx = nullptr;                   // staged positions (byte offsets) of the entries' columns, two to a word: per wave and
+                                                         // pair of chunks 2p, 2p + 1 one word for every lane that has an entry of chunk 2p
    // x staging (spmv_xs_kernel): per tile the number of column segments that cover its entries (0: they do not fit, gather
    // instead) and their descriptors (2 * SPMV_XS_SEGS ints per tile); per entry the index of its column in the tile's
    // staged copy
@@ -159,7 +177,42 @@ struct SpmvPlan
    int            *d_tile_fp = nullptr;  // [num_tiles]
    int            *h_stale = nullptr;    // pinned, mapped
    int            *d_stale = nullptr;    // the same word as the device sees it
+   // Launch counter: the kernels that multiply by a private copy of the values (value codes, slice form) compare a ROTATING
+   // sample of the copy with the caller's fp64 array — eight consecutive entries per wave, at a position that moves with
+   // this counter — so that ANY in-place edit of a coefficient is found within a bounded number of launches (64 for the
+   // tiled kernel, 128 for the slice kernel), not only a wholesale replacement.
+   unsigned        launches = 0;
+   // 64-bit checksum of the arrays the plan was built from (row pointers, columns, value bit patterns), taken when the plan
+   // is built for a matrix the library does not own: plan_verify() recomputes it (one pass over the CSR arrays) — called
+   // where a solve begins and by hypre_amd_CSRMatrixVerifyPlan.
+   unsigned long long checksum = 0;
+   bool            has_checksum = false;
+   // The matrix cannot change behind the plan: the library made it (hierarchy levels below the finest, interpolation and
+   // restriction operators, triangles, colour classes, cached transposes), or the caller said so
+   // (hypre_amd_CSRMatrixSetImmutable).  Only such matrices get forms that keep a private copy of fp64 values (the row-slice
+   // form); their launches carry no watch.
+   bool            owned = false;
 };
+// library-owned / caller-declared immutable matrices (see SpmvPlan::owned); forgotten when the matrix is destroyed
+void mark_owned(const hypre_CSRMatrix *A, bool on = true);
+bool is_owned(const hypre_CSRMatrix *A);
+// recompute the checksum of A's arrays and compare it with the one its plan was built with; a plan that fails is dropped
+// (the next product builds a fresh one) and false returned.  No plan, or no checksum: true.
+bool plan_verify(hypre_CSRMatrix *A);
+// checked device allocation of the plan builders (seq_mv.cpp): false — nothing allocated, no HIP error left behind — when the
+// memory is not to be had, when the request exceeds half of what is free, or when a test armed this site
+enum PlanAllocSite { PLAN_SITE_TILES = 1, PLAN_SITE_XS = 2, PLAN_SITE_CODES = 3, PLAN_SITE_SLICE = 4, PLAN_SITE_ROWSLICE = 5 };
+bool plan_alloc(void **ptr, size_t bytes, int site);
+void plan_free(void *ptr);
+// where a solve begins: the plans of the caller's matrix are verified against its arrays (plan_verify) — a plan that
+// fails is dropped silently, nothing has used it since
+inline void verify_par_plans(hypre_ParCSRMatrix *A)
+{
+   if (!A) { return; }
+   if (A->diag && A->diag->memory_location == HYPRE_MEMORY_DEVICE) { (void) plan_verify(A->diag); }
+   if (A->offd && A->offd->memory_location == HYPRE_MEMORY_DEVICE) { (void) plan_verify(A->offd); }
+}
+unsigned long long device_csr_checksum(const int *Ai, const int *Aj, const double *Aa, int n, int nnz, hipStream_t s);
 void bump_plan_generation();
 // A sampled fingerprint of a device CSR matrix — row pointers, columns and, if asked, values at 4096 positions spread over
 // it — kept on the device, and a pinned flag that a checking launch raises when the matrix no longer matches.  For the
@@ -230,6 +283,9 @@ struct SpmvArgs
    const int           *rowmap;      // epilogue row indirection (multicolour sweeps: row r of the matrix is row rowmap[r] of
                                      // the vectors b, d, x, y, marker), or null
    int                  variant;     // 0: x gathered through the cache; 2: x staged through LDS from the plan's chunk lists
+   int                  use_rs;      // the row-slice kernel serves this launch (decided by launch_spmv)
+   unsigned             rot;         // launch counter of the plan (filled by launch_spmv): position of the rotating value check
+   int                  nnz;         // entries of the matrix (filled by launch_spmv)
 };
 void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 
@@ -241,6 +297,9 @@ bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out,
                         hipStream_t s);
 // slice form of a coded matrix (false: not applicable — long or very unequal rows, a block that cannot be staged)
 bool device_build_slice_form(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s);
+// row-slice form of an owned, uncoded matrix (false: not applicable, or a table was not to be had: the tiles serve)
+bool device_build_row_slices(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s);
+int  &spmv_row_slices();              // 0 off, 1 matrices the library owns (default), 2 every matrix (tests); HYPRE_AMD_SPMV_ROW_SLICES
 bool &spmv_slice_form();               // plans built from now on get the slice form where it applies (default: on; HYPRE_AMD_SPMV_SLICE_FORM=0)
 bool &spmv_value_codes();              // plans built from now on look for value codes (default: on; HYPRE_AMD_SPMV_VALUE_CODES=0)
 void launch_build_tiles(const HYPRE_Int *Ai, int num_rows, int nnz, int num_tiles, int *d_tile_row,

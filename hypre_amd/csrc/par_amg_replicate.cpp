@@ -274,11 +274,15 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
       for (int l = 0; l < TL; l++)
       {
          hypre_ParCSRMatrixMigrate(t->A_array[l], HYPRE_MEMORY_DEVICE);
-         if (tail_lower[(size_t) l]) { set_strict_lower(t->A_array[l]->diag, tail_lower[(size_t) l]); }
+         // the tail is the library's own copy of these levels: its matrices cannot change behind their plans
+         auto own = [](hypre_ParCSRMatrix *M) { for (hypre_CSRMatrix *B : {M->diag, M->offd, M->diagT, M->offdT}) { if (B) { mark_owned(B); } } };
+         own(t->A_array[l]);
+         if (tail_lower[(size_t) l]) { mark_owned(tail_lower[(size_t) l]); set_strict_lower(t->A_array[l]->diag, tail_lower[(size_t) l]); }
          if (t->P_array[l])
          {
             hypre_amd_ParCSRMatrixKeepTranspose(t->P_array[l]);
             hypre_ParCSRMatrixMigrate(t->P_array[l], HYPRE_MEMORY_DEVICE);
+            own(t->P_array[l]);
          }
          hypre_ParVectorMigrate(t->F_array[l], HYPRE_MEMORY_DEVICE);
          hypre_ParVectorMigrate(t->U_array[l], HYPRE_MEMORY_DEVICE);

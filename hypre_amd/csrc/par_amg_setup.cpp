@@ -1867,6 +1867,13 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    if (!d) { hypre_error_in_arg(1); return hypre_error_flag; }
    AmgPrivate *pv = (AmgPrivate *) d->amd_private;
    amg_free_hierarchy(d);
+   // A (re-)setup is the caller telling the library that the matrix is what it is NOW: whatever earlier products cached for
+   // its two blocks — tile tables, staged column pattern, value codes and slice form, triangles, colour classes, level
+   // schedules — is dropped before anything else, so that the hypre idiom "HYPRE_IJMatrixSetValues on the same pattern,
+   // then HYPRE_BoomerAMGSetup again" works on the new values on every level, the finest included
+   // (the reference reads the caller's arrays in every product: seq_mv/csr_matvec.c:860-901).
+   if (A->diag) { drop_plan(A->diag); }
+   if (A->offd) { drop_plan(A->offd); }
    MPI_Comm comm = A->comm;
    const HYPRE_MemoryLocation target = d->memory_location;
    if (target == HYPRE_MEMORY_DEVICE && !ensure_device())
@@ -2305,6 +2312,18 @@ HYPRE_Int hypre_BoomerAMGSetup(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
       }
       // the kernels' per-matrix plans (tile bounds, placement tables, x-staging descriptors and local indices) are part of
       // the setup: built here, not inside the first cycle
+      // what the setup made cannot change behind its plans (SpmvPlan::owned): every level below the finest, every
+      // interpolation operator and its stored transpose; the finest level stays the caller's
+      for (int l = 0; l < num_levels; l++)
+      {
+         auto own = [](hypre_ParCSRMatrix *M)
+         {
+            if (!M) { return; }
+            for (hypre_CSRMatrix *B : {M->diag, M->offd, M->diagT, M->offdT}) { if (B && B->memory_location == HYPRE_MEMORY_DEVICE) { mark_owned(B); } }
+         };
+         if (l > 0) { own(d->A_array[l]); }
+         if (l < num_levels - 1) { own(d->P_array[l]); }
+      }
       for (int l = 0; l < num_levels; l++)
       {
          auto plan_of = [](hypre_CSRMatrix *M) { if (M && M->memory_location == HYPRE_MEMORY_DEVICE && M->num_nonzeros > 0) { (void) get_plan(M); } };

@@ -121,6 +121,7 @@ HYPRE_Int HYPRE_ParCSRGMRESSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPR
    d->converged = 0;
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
+   verify_par_plans(A);                    // a solve never starts from a plan its matrix has moved away from
    auto leave = [&]() { handle().sync_compute = saved_sync; maybe_sync(); return hypre_error_flag; };
    auto precond = [&](hypre_ParVector *rhs, hypre_ParVector *sol)
    {

@@ -223,7 +223,7 @@ extern "C" HYPRE_Int hypre_BoomerAMGRelaxHybridGaussSeidelDevice(hypre_ParCSRMat
    const bool zero_guess = u->all_zeros != 0;
    hypre_ParCSRCommHandle *ch = (nprocs > 1 && !zero_guess) ? dev_halo_begin(A, ud) : nullptr;
    GsSchedule *g = get_schedule(diag, std::max(1, std::min(handle().gs_threads, n)));
-   watch_check(g->watch, diag, false, s);
+   if (!is_owned(diag)) { watch_check(g->watch, diag, false, s); }
    dev_halo_end(ch);
 
    GsArgs a{};

@@ -145,6 +145,7 @@ McPlan *get_mc(hypre_CSRMatrix *A)
          M->data = m->d_ca + slice0[(size_t) c];
          M->memory_location = HYPRE_MEMORY_DEVICE;
          M->owns_data = 0;
+         mark_owned(M);                    // a view into the library's own colour-sorted copy
          m->rows_of[(size_t) c] = M;
          if (M->num_rows > 0 && M->num_nonzeros > 0) { (void) get_plan(M); }    // the colour's SpMV plan: part of the setup
       }
@@ -230,7 +231,9 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
    const bool zero_guess = u->all_zeros != 0;
    hypre_ParCSRCommHandle *ch = (nprocs > 1 && !zero_guess) ? dev_halo_begin(A, ud) : nullptr;
    McPlan *m = get_mc(dg);
-   watch_check(m->watch, dg, true, s);          // (a mismatch is reported by the next call that asks for the classes)
+   // (a mismatch is reported by the next call that asks for the classes; a matrix the library made itself cannot change
+   // behind its classes: no launch spent on it)
+   if (!is_owned(dg)) { watch_check(m->watch, dg, true, s); }
    dev_halo_end(ch);
    // right-hand side with the ghost couplings folded in: ft = f - A_offd u_ghost
    const double *ft = fd;

@@ -867,6 +867,10 @@ HYPRE_Int hypre_BoomerAMGSolve(void *amg_vdata, hypre_ParCSRMatrix *A, hypre_Par
    const HYPRE_Real tol = d->tol;
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
+   // stand-alone solver (more than one cycle allowed): the fine-level plans are verified against the caller's arrays once
+   // per solve (one pass over the CSR arrays; a Krylov method that applies one cycle per iteration does it itself, once per
+   // solve — HYPRE_ParCSRPCGSolve / GMRESSolve)
+   if (d->max_iter > 1) { verify_par_plans(A); }
    d->A_array[0] = A; d->F_array[0] = f; d->U_array[0] = u;
    hypre_ParVector *Vtemp = d->Vtemp;
    hypre_ParVectorSetLocalSize(Vtemp, A->diag->num_rows);
@@ -1059,6 +1063,7 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
    }
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
+   verify_par_plans(A);                    // a solve never starts from a plan its matrix has moved away from
    auto precond = [&](hypre_ParVector *rhs, hypre_ParVector *sol)
    {
       hypre_ParVectorSetZeros(sol);       // ClearVector: all_zeros = 1 (par_vector.c:335-340)

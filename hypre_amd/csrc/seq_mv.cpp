@@ -10,6 +10,7 @@
 //   seq_mv/vector.c / vector_device.c             BLAS-1
 #include "internal.hpp"
 #include <unordered_map>
+#include <unordered_set>
 #include <omp.h>
 #include <algorithm>
 
@@ -82,6 +83,41 @@ static BandPolicy &band_policy()
    return bp;
 }
 
+// ---- checked allocations of the plan builders.  A plan is an accelerator, never a necessity: every table it holds has a
+// form below it that does without (slice form -> coded tiles -> fp64 stream with staged x -> x gathered through the cache ->
+// a wave per row, which needs nothing).  So an allocation that fails — no memory, more than the plan's share of what is
+// free, or a test's request (hypre_amd_PlanTestFailAlloc) — frees what its step had obtained, leaves no HIP error behind
+// and the plan goes on one form lower.
+int g_fail_site = 0, g_fail_nth = 0;
+bool plan_alloc(void **ptr, size_t bytes, int site)
+{
+   *ptr = nullptr;
+   if (g_fail_site == site && g_fail_nth > 0 && --g_fail_nth == 0) { g_fail_site = 0; return false; }
+   // no single table of a plan may take more than half of what is free (a plan lives beside the matrix it serves)
+   size_t free_b = 0, total_b = 0;
+   if (bytes > ((size_t) 64 << 20))
+   {
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); return false; }
+      if (bytes > free_b / 2) { return false; }
+   }
+   if (hipMalloc(ptr, bytes ? bytes : 16) != hipSuccess) { (void) hipGetLastError(); *ptr = nullptr; return false; }
+   return true;
+}
+void plan_free(void *ptr) { if (ptr) { HIP_CHECK(hipFree(ptr)); } }
+
+// ---- matrices that cannot change behind their plans (SpmvPlan::owned)
+static std::unordered_set<const hypre_CSRMatrix *> &owned_table()
+{
+   static std::unordered_set<const hypre_CSRMatrix *> t;
+   return t;
+}
+void mark_owned(const hypre_CSRMatrix *A, bool on)
+{
+   if (!A) { return; }
+   if (on) { owned_table().insert(A); } else { owned_table().erase(A); }
+}
+bool is_owned(const hypre_CSRMatrix *A) { return A && owned_table().count(A) != 0; }
+
 static void build_band_placement(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
 {
    const BandPolicy &bp = band_policy();
@@ -119,7 +155,7 @@ static void build_band_placement(SpmvPlan *p, const hypre_CSRMatrix *A, hipStrea
    for (size_t c = 0; c < 8; c++) { for (size_t k = next[c]; k < cls[c].size(); k++) { leftovers.push_back(cls[c][k]); } }
    size_t lo = 0;
    for (int g = 0; g < p->num_tiles; g++) { if (perm[(size_t) g] < 0) { perm[(size_t) g] = leftovers[lo++]; } }
-   HIP_CHECK(hipMalloc((void **) &p->d_tile_perm, sizeof(int) * (size_t) p->num_tiles));
+   if (!plan_alloc((void **) &p->d_tile_perm, sizeof(int) * (size_t) p->num_tiles, PLAN_SITE_TILES)) { return; }     // speed only: runs of 8 instead
    HIP_CHECK(hipMemcpyAsync(p->d_tile_perm, perm.data(), sizeof(int) * (size_t) p->num_tiles, hipMemcpyHostToDevice, s));
    HIP_CHECK(hipStreamSynchronize(s));
    p->band = B;
@@ -215,6 +251,8 @@ static void free_plan(SpmvPlan *p)
    if (p->d_sl_fp) { HIP_CHECK(hipFree(p->d_sl_fp)); }
    if (p->d_sl_perm) { HIP_CHECK(hipFree(p->d_sl_perm)); }
    if (p->d_sl_data) { HIP_CHECK(hipFree(p->d_sl_data)); }
+   for (void *q : {(void *) p->d_rs_desc, (void *) p->d_rs_perm, (void *) p->d_rs_hdr, (void *) p->d_rs_meta, (void *) p->d_rs_val,
+                   (void *) p->d_rs_val32, (void *) p->d_rs_idx}) { plan_free(q); }
    if (p->AT) { hypre_CSRMatrixDestroy(p->AT); }
    if (p->Lstrict) { hypre_CSRMatrixDestroy(p->Lstrict); }
    delete p;
@@ -234,6 +272,107 @@ void drop_plan(hypre_CSRMatrix *A)
       free_plan(it->second);
       t.erase(it);
    }
+}
+
+// tile bounds of the tiled kernel family (PLAN_SITE_TILES).  false: the tables are not to be had; a wave per row serves.
+static bool build_tile_tables(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
+{
+   p->num_tiles = (int) (((long long) A->num_nonzeros + SPMV_TILE - 1) / SPMV_TILE);
+   if (!plan_alloc((void **) &p->d_tile_row, sizeof(int) * (size_t) (p->num_tiles + 1), PLAN_SITE_TILES) ||
+       !plan_alloc((void **) &p->d_tile_k, sizeof(int) * (size_t) (p->num_tiles + 1), PLAN_SITE_TILES))
+   {
+      plan_free(p->d_tile_row); plan_free(p->d_tile_k);
+      p->d_tile_row = p->d_tile_k = nullptr;
+      p->num_tiles = 0;
+      return false;
+   }
+   p->prod_elems = SPMV_TILE + ((p->max_row_nnz + 3) & ~3) + 8;
+   launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
+   p->max_tile_rows = device_max_row_nnz(p->d_tile_row, p->num_tiles, s);     // max over tiles of tile_row[b+1] - tile_row[b]
+   // staleness flag (see SpmvPlan): a word of pinned host memory, or — none to be had — somewhere for the kernels to write
+   p->h_stale = stale_slots().take();
+   if (p->h_stale && hipHostGetDevicePointer((void **) &p->d_stale, p->h_stale, 0) != hipSuccess) { (void) hipGetLastError(); p->d_stale = nullptr; }
+   if (!p->d_stale)
+   {
+      static int *sink = nullptr;
+      if (!sink && hipMalloc((void **) &sink, sizeof(int)) != hipSuccess) { (void) hipGetLastError(); sink = nullptr; }
+      if (sink) { HIP_CHECK(hipMemsetAsync(sink, 0, sizeof(int), s)); }
+      p->d_stale = sink;
+      stale_slots().give(p->h_stale); p->h_stale = nullptr;
+   }
+   return true;
+}
+
+// x staging of the tiled kernel (PLAN_SITE_XS: fingerprints, piece lists, local indices), then — each with a site of its
+// own, each optional — value codes and the slice form.  On failure the plan keeps what the step below needs: without the
+// staging tables the tiles gather x through the cache.
+static void build_staging(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
+{
+   // value codes first: a coded matrix (a stencil) has better forms than any fp64 one, and the table the codes stage is
+   // part of the launch's LDS, which decides how much x a launch stages
+   if (spmv_value_codes() && p->d_stale) { device_value_codes(A->data, (size_t) A->num_nonzeros, &p->d_codes, &p->d_dict, &p->d_dict32, &p->ndict, s); }
+   // a matrix that cannot change behind its plan and is not coded: row slices (a private copy of the fp64 values); the
+   // launches the form does not serve (triangular fills, an unaligned x) gather x through the cache from the tile tables
+   const int rs_mode = spmv_row_slices();
+   if (!p->d_codes && (rs_mode >= 2 || (rs_mode == 1 && p->owned)) && device_build_row_slices(p, A, s)) { return; }
+   if (!p->d_stale) { plan_free(p->d_codes); plan_free(p->d_dict); p->d_codes = nullptr; p->d_dict = p->d_dict32 = nullptr; p->ndict = 0; return; }   // the x-staged kernels write their verdict somewhere
+   const size_t nl = ((size_t) A->num_nonzeros + 15) & ~(size_t) 7;
+   if (!plan_alloc((void **) &p->d_tile_fp, sizeof(int) * (size_t) p->num_tiles, PLAN_SITE_XS) ||
+       !plan_alloc((void **) &p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles, PLAN_SITE_XS) ||
+       !plan_alloc((void **) &p->d_xs_desc, sizeof(int) * (size_t) p->num_tiles * 2 * SPMV_XS_SEGS, PLAN_SITE_XS) ||
+       !plan_alloc((void **) &p->d_lidx, sizeof(unsigned short) * nl, PLAN_SITE_XS))
+   {
+      plan_free(p->d_tile_fp); plan_free(p->d_xs_cnt); plan_free(p->d_xs_desc); plan_free(p->d_lidx);
+      p->d_tile_fp = nullptr; p->d_xs_cnt = nullptr; p->d_xs_desc = nullptr; p->d_lidx = nullptr;
+      plan_free(p->d_codes); plan_free(p->d_dict);           // (only the x-staged kernels read codes)
+      p->d_codes = nullptr; p->d_dict = p->d_dict32 = nullptr; p->ndict = 0;
+      return;
+   }
+   launch_build_fp(A->j, A->num_nonzeros, p->num_tiles, p->d_tile_fp, s);
+   HIP_CHECK(hipMemsetAsync(p->d_lidx, 0, sizeof(unsigned short) * nl, s));
+   launch_build_xs(A->j, p->d_tile_k, p->num_tiles, p->d_xs_cnt, p->d_xs_desc, p->d_lidx, s);
+   // the product area doubles as the staging area: size it by the longest staged copy of this matrix
+   std::vector<int> cnt((size_t) p->num_tiles);
+   HIP_CHECK(hipMemcpyAsync(cnt.data(), p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles, hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   std::vector<int> cov;
+   cov.reserve(cnt.size());
+   for (int c : cnt) { if (c & 0xff) { p->xs_tiles++; p->xs_max_units = std::max(p->xs_max_units, c >> 8); cov.push_back(c >> 8); } }
+   // LDS per workgroup decides how many tiles a CU holds (160 KB): stage what 99 % of the tiles need, rounded up
+   // to the next occupancy step; the few tiles above that gather through the cache
+   if (!cov.empty())
+   {
+      std::sort(cov.begin(), cov.end());
+      static int pct = -1, verbose = 0;
+      if (pct < 0)
+      {
+         const char *e = getenv("HYPRE_AMD_SPMV_XS_PCT");
+         pct = e ? std::min(100, std::max(1, atoi(e))) : 99;
+         verbose = getenv("HYPRE_AMD_PLAN_VERBOSE") != nullptr;
+      }
+      const int need = cov[(size_t) ((cov.size() - 1) * (size_t) pct / 100)];
+      // what the launch puts beside the products (tiled_lds_bytes / launch_xs of spmv_kernels.hip): row sums and row pointers
+      // for the most rows a tile of THIS matrix holds, and the value table of a coded matrix
+      const int rows = p->max_tile_rows > 0 ? std::min(p->max_tile_rows, RP_CAP_HOST) : RP_CAP_HOST;
+      const int other = 8 * (p->max_row_nnz > 12 ? ((std::min(rows, SPMV_THREADS) + 1) & ~1) : 0) + 4 * (rows + 4) + 64 +
+                        (p->d_codes ? 8 * ((p->ndict + 1) & ~1) + 16 : 0);
+      int units = p->xs_max_units;
+      for (int wgs = 8; wgs >= 3; wgs--)
+      {
+         const int room = ((160 * 1024) / wgs) / 1280 * 1280;           // LDS is handed out in blocks (1280 bytes on gfx950)
+         const int fit = (room - other) / 16;                           // units (16 bytes) that leave room for wgs workgroups
+         if (fit >= need) { units = std::min(fit, p->xs_max_units); break; }
+      }
+      p->xs_launch_units = std::max(units, need);
+      if (verbose)
+      {
+         fprintf(stderr, "[plan] %d x %d, %d tiles: staged units p50 %d p90 %d p99 %d max %d -> launch %d (%d bytes of LDS)\n",
+                 A->num_rows, A->num_cols, p->num_tiles, cov[cov.size() / 2], cov[(cov.size() - 1) * 9 / 10],
+                 cov[(cov.size() - 1) * 99 / 100], cov.back(), p->xs_launch_units, 16 * p->xs_launch_units + other);
+      }
+   }
+   p->prod_elems = std::max(p->prod_elems, 2 * p->xs_launch_units + 8);
+   if (p->d_codes && spmv_slice_form()) { device_build_slice_form(p, A, s); }
 }
 
 SpmvPlan *get_plan(hypre_CSRMatrix *A)
@@ -263,90 +402,41 @@ SpmvPlan *get_plan(hypre_CSRMatrix *A)
    SpmvPlan *p = new SpmvPlan();
    p->i = A->i; p->j = A->j; p->a = A->data;
    p->num_rows = A->num_rows; p->num_cols = A->num_cols; p->nnz = A->num_nonzeros;
+   p->owned = is_owned(A);
    hipStream_t s = stream();
    if (A->num_rows > 0 && A->num_nonzeros > 0)
    {
       p->max_row_nnz = device_max_row_nnz(A->i, A->num_rows, s);
       const bool aligned = (((uintptr_t) A->j) & 15) == 0 && (((uintptr_t) A->data) & 15) == 0;
-      p->tiled = aligned && p->max_row_nnz <= SPMV_MAXROW;
+      p->tiled = aligned && p->max_row_nnz <= SPMV_MAXROW && build_tile_tables(p, A, s);     // false: a wave per row
       if (p->tiled)
       {
-         p->num_tiles = (int) (((long long) A->num_nonzeros + SPMV_TILE - 1) / SPMV_TILE);
-         HIP_CHECK(hipMalloc((void **) &p->d_tile_row, sizeof(int) * (size_t) (p->num_tiles + 1)));
-         HIP_CHECK(hipMalloc((void **) &p->d_tile_k, sizeof(int) * (size_t) (p->num_tiles + 1)));
-         p->prod_elems = SPMV_TILE + ((p->max_row_nnz + 3) & ~3) + 8;
-         launch_build_tiles(A->i, A->num_rows, A->num_nonzeros, p->num_tiles, p->d_tile_row, p->d_tile_k, s);
-         p->max_tile_rows = device_max_row_nnz(p->d_tile_row, p->num_tiles, s);     // max over tiles of tile_row[b+1] - tile_row[b]
-         // staleness watch (see SpmvPlan)
-         p->h_stale = stale_slots().take();
-         if (p->h_stale && hipHostGetDevicePointer((void **) &p->d_stale, p->h_stale, 0) != hipSuccess) { (void) hipGetLastError(); p->d_stale = nullptr; }
-         if (!p->d_stale)
-         {
-            // no pinned word to be had: the kernels still need somewhere to write (nobody reads it)
-            static int *sink = nullptr;
-            if (!sink) { HIP_CHECK(hipMalloc((void **) &sink, sizeof(int))); HIP_CHECK(hipMemsetAsync(sink, 0, sizeof(int), s)); }
-            p->d_stale = sink;
-            stale_slots().give(p->h_stale); p->h_stale = nullptr;
-         }
-         HIP_CHECK(hipMalloc((void **) &p->d_tile_fp, sizeof(int) * (size_t) p->num_tiles));
-         launch_build_fp(A->j, A->num_nonzeros, p->num_tiles, p->d_tile_fp, s);
          build_band_placement(p, A, s);
-         if (spmv_variant().variant == 2)
-         {
-            // x staging: segment lists and local column indices (one pass over the column array, device side)
-            const size_t nl = ((size_t) A->num_nonzeros + 15) & ~(size_t) 7;
-            HIP_CHECK(hipMalloc((void **) &p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles));
-            HIP_CHECK(hipMalloc((void **) &p->d_xs_desc, sizeof(int) * (size_t) p->num_tiles * 2 * SPMV_XS_SEGS));
-            HIP_CHECK(hipMalloc((void **) &p->d_lidx, sizeof(unsigned short) * nl));
-            HIP_CHECK(hipMemsetAsync(p->d_lidx, 0, sizeof(unsigned short) * nl, s));
-            launch_build_xs(A->j, p->d_tile_k, p->num_tiles, p->d_xs_cnt, p->d_xs_desc, p->d_lidx, s);
-            // the product area doubles as the staging area: size it by the longest staged copy of this matrix
-            std::vector<int> cnt((size_t) p->num_tiles);
-            HIP_CHECK(hipMemcpyAsync(cnt.data(), p->d_xs_cnt, sizeof(int) * (size_t) p->num_tiles, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-            std::vector<int> cov;
-            cov.reserve(cnt.size());
-            for (int c : cnt) { if (c & 0xff) { p->xs_tiles++; p->xs_max_units = std::max(p->xs_max_units, c >> 8); cov.push_back(c >> 8); } }
-            // LDS per workgroup decides how many tiles a CU holds (160 KB): stage what 99 % of the tiles need, rounded up
-            // to the next occupancy step; the few tiles above that gather through the cache
-            if (!cov.empty())
-            {
-               std::sort(cov.begin(), cov.end());
-               static int pct = -1, verbose = 0;
-               if (pct < 0)
-               {
-                  const char *e = getenv("HYPRE_AMD_SPMV_XS_PCT");
-                  pct = e ? std::min(100, std::max(1, atoi(e))) : 99;
-                  verbose = getenv("HYPRE_AMD_PLAN_VERBOSE") != nullptr;
-               }
-               const int need = cov[(size_t) ((cov.size() - 1) * (size_t) pct / 100)];
-               // what the launch puts beside the products (tiled_lds_bytes of spmv_kernels.hip): row sums and row pointers for
-               // the most rows a tile of THIS matrix holds
-               const int rows = p->max_tile_rows > 0 ? std::min(p->max_tile_rows, RP_CAP_HOST) : RP_CAP_HOST;
-               const int other = 8 * (p->max_row_nnz > 12 ? ((std::min(rows, SPMV_THREADS) + 1) & ~1) : 0) + 4 * (rows + 4) + 64;
-               int units = p->xs_max_units;
-               for (int wgs = 8; wgs >= 3; wgs--)
-               {
-                  const int room = ((160 * 1024) / wgs) / 1280 * 1280;           // LDS is handed out in blocks (1280 bytes on gfx950)
-                  const int fit = (room - other) / 16;                           // units (16 bytes) that leave room for wgs workgroups
-                  if (fit >= need) { units = std::min(fit, p->xs_max_units); break; }
-               }
-               p->xs_launch_units = std::max(units, need);
-               if (verbose)
-               {
-                  fprintf(stderr, "[plan] %d x %d, %d tiles: staged units p50 %d p90 %d p99 %d max %d -> launch %d (%d bytes of LDS)\n",
-                          A->num_rows, A->num_cols, p->num_tiles, cov[cov.size() / 2], cov[(cov.size() - 1) * 9 / 10],
-                          cov[(cov.size() - 1) * 99 / 100], cov.back(), p->xs_launch_units, 16 * p->xs_launch_units + other);
-               }
-            }
-            p->prod_elems = std::max(p->prod_elems, 2 * p->xs_launch_units + 8);
-            if (spmv_value_codes()) { device_value_codes(A->data, (size_t) A->num_nonzeros, &p->d_codes, &p->d_dict, &p->d_dict32, &p->ndict, s); }
-            if (p->d_codes && spmv_slice_form()) { device_build_slice_form(p, A, s); }
-         }
+         if (spmv_variant().variant == 2) { build_staging(p, A, s); }
+      }
+      // a matrix somebody else may write to: the checksum its plan can be verified against (plan_verify)
+      if (p->tiled && !p->owned)
+      {
+         p->checksum = device_csr_checksum(A->i, A->j, A->data, A->num_rows, A->num_nonzeros, s);
+         p->has_checksum = true;
       }
    }
    t[A] = p;
    return p;
+}
+
+bool plan_verify(hypre_CSRMatrix *A)
+{
+   auto &t = plan_table();
+   auto it = t.find(A);
+   if (it == t.end()) { return true; }
+   SpmvPlan *p = it->second;
+   if (!p->has_checksum) { return true; }
+   const bool same_arrays = p->i == A->i && p->j == A->j && p->a == A->data && p->nnz == A->num_nonzeros &&
+                            p->num_rows == A->num_rows && p->num_cols == A->num_cols;
+   if (same_arrays && device_csr_checksum(A->i, A->j, A->data, A->num_rows, A->num_nonzeros, stream()) == p->checksum) { return true; }
+   drop_plan(A);
+   return false;
 }
 
 bool &spmv_slice_form()
@@ -409,6 +499,7 @@ hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A)
    hypre_CSRMatrixInitialize_v2(L, 0, HYPRE_MEMORY_DEVICE);
    hypre_TMemcpy(L->i, off.data(), HYPRE_Int, (size_t) n + 1, HYPRE_MEMORY_DEVICE, HYPRE_MEMORY_HOST);
    if (off[(size_t) n] > 0) { launch_fill_lower(A->i, A->j, A->data, L->i, L->j, L->data, n, s); }
+   if (plan->owned) { mark_owned(L); }            // a copy of a matrix that cannot change (a copy of the caller's matrix is watched with it)
    plan->Lstrict = L;
    return L;
 }
@@ -451,6 +542,27 @@ extern "C" HYPRE_Int hypre_amd_SpmvSetSliceForm(HYPRE_Int on)
 {
    if (on >= 0) { hamd::spmv_slice_form() = on != 0; }
    return hypre_error_flag;
+}
+
+// Row-slice form for the plans built from now on: 0 off, 1 matrices the library owns or the caller declared immutable
+// (default), 2 every matrix (tests: the caller then owes hypre_amd_CSRMatrixInvalidatePlan after any change).  Speed only.
+extern "C" HYPRE_Int hypre_amd_SpmvSetRowSlices(HYPRE_Int mode)
+{
+   if (mode >= 0) { hamd::spmv_row_slices() = mode; }
+   return hypre_error_flag;
+}
+// lanes per row of the row-slice form in A's plan (built on demand), the rows of a block and the entries a lane holds at
+// most; 0: the matrix has none
+extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanRowSlices(hypre_CSRMatrix *A, HYPRE_Int *rows_per_block, HYPRE_Int *entries_per_lane)
+{
+   if (rows_per_block) { *rows_per_block = 0; }
+   if (entries_per_lane) { *entries_per_lane = 0; }
+   if (!A || A->memory_location != HYPRE_MEMORY_DEVICE) { return 0; }
+   hamd::SpmvPlan *p = hamd::get_plan(A);
+   if (!p->d_rs_val) { return 0; }
+   if (rows_per_block) { *rows_per_block = p->rs_rows; }
+   if (entries_per_lane) { *entries_per_lane = p->rs_kp; }
+   return p->rs_w;
 }
 
 // lanes per row (1 or 2) of the slice form in A's plan (built on demand); 0: the matrix has none
@@ -515,6 +627,59 @@ extern "C" HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A)
    return hypre_error_flag;
 }
 
+// 1: the arrays of A are what its plan was built from (checksum over row pointers, columns and value bit patterns: one pass
+// over the CSR arrays); 0: they are not — the plan has been dropped, the next product builds a fresh one, nothing is raised
+// (no product has used the stale plan since this call).  A matrix without a plan, or one the library owns: 1.
+extern "C" HYPRE_Int hypre_amd_CSRMatrixVerifyPlan(hypre_CSRMatrix *A)
+{
+   if (!A || A->memory_location != HYPRE_MEMORY_DEVICE) { return 1; }
+   return hamd::plan_verify(A) ? 1 : 0;
+}
+
+// The caller's promise that the arrays of A do not change until it calls hypre_amd_CSRMatrixInvalidatePlan (or this function
+// with on = 0) or destroys A: the plan may then keep private copies of the values in whatever form multiplies fastest (the
+// row-slice form), and its launches carry no watch.  The library sets this itself for the matrices it makes (the levels of
+// a hierarchy below the finest, interpolation and restriction operators).  Changing the promise drops the plan.
+extern "C" HYPRE_Int hypre_amd_CSRMatrixSetImmutable(hypre_CSRMatrix *A, HYPRE_Int on)
+{
+   if (!A) { hypre_error_in_arg(1); return hypre_error_flag; }
+   if (hamd::is_owned(A) != (on != 0)) { drop_plan(A); hamd::mark_owned(A, on != 0); }
+   return hypre_error_flag;
+}
+
+// Test hook: the nth allocation (1 = the next) that a plan builder makes at `site` fails, once — 1 tile tables, 2 x-staging
+// tables, 3 value codes, 4 slice form, 5 row-slice form.  nth <= 0 disarms.  Returns what was still pending of the request
+// before (0: it happened, or nothing was armed).
+extern "C" HYPRE_Int hypre_amd_PlanTestFailAlloc(HYPRE_Int site, HYPRE_Int nth)
+{
+   const HYPRE_Int pending = hamd::g_fail_site ? hamd::g_fail_nth : 0;      // > 0: the failure armed before has not happened
+   hamd::g_fail_site = nth > 0 ? site : 0;
+   hamd::g_fail_nth = nth > 0 ? nth : 0;
+   return pending;
+}
+
+// Mixed precision for the products called directly (the AMG cycle sets this from its solver: hypre_amd_BoomerAMGSetMixedPrecision):
+// from now on the SpMV-class kernels stream an fp32 copy of the matrix values, vectors and sums stay fp64.
+extern "C" HYPRE_Int hypre_amd_SetMixedPrecisionValues(HYPRE_Int on)
+{
+   hamd::handle().fp32_values = on != 0;
+   return hypre_error_flag;
+}
+
+// which kernel form the plan of the device matrix A (built on demand) multiplies with: 0 a wave per row, 1 tiles with x
+// gathered through the cache, 2 tiles with x staged through LDS, 3 coded tiles, 4 slice form of a coded stencil, 5 row-slice form
+extern "C" HYPRE_Int hypre_amd_CSRMatrixPlanForm(hypre_CSRMatrix *A)
+{
+   if (!A || A->memory_location != HYPRE_MEMORY_DEVICE) { return -1; }
+   hamd::SpmvPlan *p = hamd::get_plan(A);
+   if (!p->tiled) { return 0; }
+   if (p->d_rs_val) { return 5; }
+   if (!p->d_lidx) { return 1; }
+   if (p->d_sl_data) { return 4; }
+   if (p->d_codes) { return 3; }
+   return 2;
+}
+
 // ===========================================================================
 // CSR matrix object
 // ===========================================================================
@@ -557,6 +722,7 @@ HYPRE_Int hypre_CSRMatrixDestroy(hypre_CSRMatrix *m)
 {
    if (!m) { return hypre_error_flag; }
    drop_plan(m);
+   mark_owned(m, false);
    const HYPRE_MemoryLocation loc = m->memory_location;
    hypre_Free(m->rownnz, loc);
    if (m->owns_data)
@@ -909,7 +1075,7 @@ HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypr
    if (trans)
    {
       SpmvPlan *plan = get_plan(A);
-      if (!plan->AT) { hypre_CSRMatrixTranspose(A, &plan->AT, 1); }
+      if (!plan->AT) { hypre_CSRMatrixTranspose(A, &plan->AT, 1); if (plan->owned) { mark_owned(plan->AT); } }
       M = plan->AT;
    }
    hypre_Vector *x_tmp = nullptr;
@@ -934,9 +1100,15 @@ HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypr
    {
       // synchronous public product: a plan the kernels found out of date is rebuilt (get_plan raises the error) and the
       // product repeated, so that what the caller reads is right.  (Without the end-of-call synchronisation the flag is
-      // seen by the next call that asks for the plan.)
+      // seen by the next call that asks for the plan.)  In place with beta != 0 (hypre_CSRMatrixMatvec: b is y) the first,
+      // wrong product has already overwritten the operand the repeat would need: then nothing is repeated, the error is
+      // raised here and y is NOT valid.
       HIP_CHECK(hipStreamSynchronize(stream()));
-      if (plan_is_stale(M))
+      if (plan_is_stale(M) && b->data == y->data && beta != 0.0)
+      {
+         (void) get_plan(M);                 // raises HYPRE_ERROR_GENERIC, rebuilds the plan for the next call
+      }
+      else if (plan_is_stale(M))
       {
          for (HYPRE_Int v = 0; v < x->num_vectors; v++)
          {
@@ -994,7 +1166,7 @@ HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_
    if (trans)
    {
       SpmvPlan *plan = get_plan(B);
-      if (!plan->AT) { hypre_CSRMatrixTranspose(B, &plan->AT, 1); }
+      if (!plan->AT) { hypre_CSRMatrixTranspose(B, &plan->AT, 1); if (plan->owned) { mark_owned(plan->AT); } }
       M = plan->AT;
    }
    for (HYPRE_Int v = 0; v < x->num_vectors; v++)

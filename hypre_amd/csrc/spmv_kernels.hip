@@ -656,15 +656,25 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
    const int qs0 = min(ka + 5, p.last_quad), qs1 = min(ka + 1029, p.last_quad);
    const int fp_plan = p.tile_fp[tile];
    const int fc0 = p.Aj[qs0], fc1 = p.Aj[qs1];
-   double fv64 = 0.0;
-   float  fv32 = 0.0f;
-   if (F32) { fv64 = p.Aa[qs0]; fv32 = p.Aa32[qs0]; }
-   if (CODED) { fv64 = p.Aa[min(ka, p.last_quad)]; }      // the first entry lane 0 streams: compared once it is decoded
+   // value codes: the kernel multiplies by a private copy of the values, so every launch compares a ROTATING sample of the
+   // copy with the caller's array — eight consecutive entries per wave (one 64-byte request), at a position that moves with
+   // the plan's launch counter: the four waves of a tile cover its 2048 entries in 64 launches, so any coefficient edited
+   // in place is found within 64 products, whichever it is.  Loaded here, in the tile's one trip; compared once the table
+   // has landed.
+   // (mixed precision: the fp32 copy of the values is checked the same way)
+   double   ckv = 0.0;
+   unsigned ckc = 0;
+   float    ckf = 0.0f;
+   if (CODED || F32)
+   {
+      const int ck = min(ka + 8 * (int) ((4u * p.rot + (unsigned) wave) & 255u) + (lane & 7), p.nnz - 1);
+      ckv = p.Aa[ck];
+      if (CODED) { ckc = p.Ac8[ck]; } else { ckf = p.Aa32[ck]; }
+   }
    asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aa32), "s"(p.Aj), "s"(p.tile_fp), "s"(p.Ac8) : "memory");
    if (r1 <= r0) { return; }
    {
-      bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1);
-      if (F32) { off = off || ((float) fv64 != fv32); }
+      const bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1);
       if (off && tid == 0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
    }
    if (CODED)
@@ -726,7 +736,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
          __syncthreads();
          S.vA01.x = dictl[cdA & 0xff]; S.vA01.y = dictl[(cdA >> 8) & 0xff]; S.vA23.x = dictl[(cdA >> 16) & 0xff]; S.vA23.y = dictl[cdA >> 24];
          S.vB01.x = dictl[cdB & 0xff]; S.vB01.y = dictl[(cdB >> 8) & 0xff]; S.vB23.x = dictl[(cdB >> 16) & 0xff]; S.vB23.y = dictl[cdB >> 24];
-         if (tid == 0 && __double_as_longlong(dictl[cdA & 0xff]) != __double_as_longlong(p.dict_rounded ? (double) (float) fv64 : fv64))
+         if (__double_as_longlong(dictl[ckc]) != __double_as_longlong(p.dict_rounded ? (double) (float) ckv : ckv))
          {
             __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
          }
@@ -734,6 +744,7 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       }
       stream_consume_gt<F32>(p, k0, k1, ka, S, prod);
       __syncthreads();
+      if (F32 && (float) ckv != ckf) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       tile_reduce<OP, HASFILL>(p, r0, nrows, k0, k1, ka, prod, rowsum, rp, rp_cap, ops);
       return;
    }
@@ -791,13 +802,14 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
       lo0.x = dictl[cdA & 0xff] * xa0; lo0.y = dictl[(cdA >> 8) & 0xff] * xa1; hi0.x = dictl[(cdA >> 16) & 0xff] * xa2; hi0.y = dictl[cdA >> 24] * xa3;
       lo1.x = dictl[cdB & 0xff] * xb0; lo1.y = dictl[(cdB >> 8) & 0xff] * xb1; hi1.x = dictl[(cdB >> 16) & 0xff] * xb2; hi1.y = dictl[cdB >> 24] * xb3;
       S.vC = dictl[cdC];
-      if (tid == 0 && __double_as_longlong(dictl[cdA & 0xff]) != __double_as_longlong(p.dict_rounded ? (double) (float) fv64 : fv64))
+      if (__double_as_longlong(dictl[ckc]) != __double_as_longlong(p.dict_rounded ? (double) (float) ckv : ckv))
       {
          __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
    }
    else if (F32)
    {
+      if ((float) ckv != ckf) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       lo0.x = (double) S.fA.x * xa0; lo0.y = (double) S.fA.y * xa1; hi0.x = (double) S.fA.z * xa2; hi0.y = (double) S.fA.w * xa3;
       lo1.x = (double) S.fB.x * xb0; lo1.y = (double) S.fB.y * xb1; hi1.x = (double) S.fB.z * xb2; hi1.y = (double) S.fB.w * xb3;
    }
@@ -853,7 +865,8 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
 // their concatenation.  One workgroup per tile.  Columns are handled in units of two (16 bytes of x): sort the units
 // (bitonic, LDS), keep the distinct ones, cut where the gap to the next unit exceeds a threshold T — the smallest power
 // of two that leaves at most 32 segments — and give up on the tile if the segments hold more than the staging capacity.
-constexpr int XS_SORT  = 4096;              // >= SPMV_TILE + SPMV_MAXROW entries of a tile, power of two
+constexpr int XS_SORT  = 8192;              // >= SPMV_TILE + SPMV_MAXROW entries of a tile, power of two (a row-slice block: up to 8192)
+constexpr int XS_SORT_BITS = 13;
 constexpr int XS_UNITS = XS_CAP / 2;        // distinct 2-column units a staged tile can hold at most
 __global__ __launch_bounds__(SPMV_THREADS)
 void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k, int num_tiles,
@@ -877,7 +890,7 @@ void build_xs_kernel(const int *__restrict__ Aj, const int *__restrict__ tile_k,
    for (int i = tid; i < m; i += SPMV_THREADS)
    {
       const int q = Aj[k0 + i] >> 1;
-      unsigned h = ((unsigned) q * 2654435761u) >> 20;            // 12 bits: XS_SORT slots
+      unsigned h = ((unsigned) q * 2654435761u) >> (32 - XS_SORT_BITS);
       while (true)
       {
          const int old = atomicCAS(&key[h & (XS_SORT - 1)], EMPTY, q);
@@ -1109,7 +1122,7 @@ void spmv_sl_kernel(SpmvArgs p, const int *__restrict__ sl_cnt, const int *__res
    int seg_start[XS_WSEG], seg_ol[XS_WSEG];
 #pragma unroll
    for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
-   const int k0 = sl_k0[block], fp_plan = sl_fp[block];
+   const int k0 = sl_k0[block], k1b = sl_k0[block + 1], fp_plan = sl_fp[block];
    asm volatile("" :: "s"(sl_desc), "s"(sl_k0), "s"(sl_fp), "s"(sl_data), "s"(p.Ai) : "memory");
 #pragma unroll
    for (int j = 0; j < XS_WSEG; j++)
@@ -1133,7 +1146,11 @@ void spmv_sl_kernel(SpmvArgs p, const int *__restrict__ sl_cnt, const int *__res
    // the vector loads above)
    const int q0 = min(max(k0, 0), nnz - 1), q1 = min(max(k0, 0) + 1, nnz - 1);
    const int fc0 = p.Aj[q0], fc1 = p.Aj[q1];
-   const double fv64 = p.Aa[q0];
+   // the rotating value check (see spmv_xs_kernel): eight consecutive entries of the block per wave, through the code array
+   // the slices were packed from; a block holds at most 4096 entries, so four waves cover it within 128 launches
+   const int ck = min(max(min(k0 + 8 * (int) ((4u * p.rot + (unsigned) wave) & 511u) + (lane & 7), k1b - 1), 0), nnz - 1);
+   const double ckv = p.Aa[ck];
+   const unsigned ckc = p.Ac8[ck];
    __syncthreads();
 
    const int mylen = (re - rs - sub + W - 1) / W;
@@ -1150,11 +1167,9 @@ void spmv_sl_kernel(SpmvArgs p, const int *__restrict__ sl_cnt, const int *__res
       }
    }
    if (W == 2) { sum += __shfl_xor(sum, 1, 64); }
-   if (tid == 0)
    {
-      const double v0 = dictl[cw[0] & 0xffu];
-      const bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1) || rs != k0 ||
-                       (re > rs && __double_as_longlong(v0) != __double_as_longlong(p.dict_rounded ? (double) (float) fv64 : fv64));
+      bool off = __double_as_longlong(dictl[ckc]) != __double_as_longlong(p.dict_rounded ? (double) (float) ckv : ckv);
+      if (tid == 0) { off = off || fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1) || rs != k0; }
       if (off) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
    }
    if (r < num_rows && sub == 0) { row_epilogue<OP>(p, r, sum, ops); }
@@ -1215,20 +1230,22 @@ bool device_build_slice_form(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t 
    // rows about equally long and near 8, 16 or 32 entries: the padded form must not hold more than 1.3 x the entries
    if ((double) blocks_ll * R * W * kper > 1.3 * (double) nnz + 4096.0 || blocks_ll > (1LL << 28)) { return false; }
    const int blocks = (int) blocks_ll;
-   int *d_k0 = nullptr, *d_cnt = nullptr, *d_desc = nullptr, *d_fp = nullptr;
+   int *d_k0 = nullptr, *d_cnt = nullptr, *d_desc = nullptr, *d_fp = nullptr, *d_perm = nullptr;
    unsigned short *d_li = nullptr;
    unsigned *d_data = nullptr;
+   // every allocation is checked (PLAN_SITE_SLICE): on failure what was obtained is freed and the matrix keeps the coded tiles
    auto fail = [&]() -> bool
    {
-      for (void *q : {(void *) d_k0, (void *) d_cnt, (void *) d_desc, (void *) d_fp, (void *) d_li, (void *) d_data}) { if (q) { HIP_CHECK(hipFree(q)); } }
+      HIP_CHECK(hipStreamSynchronize(s));
+      for (void *q : {(void *) d_k0, (void *) d_cnt, (void *) d_desc, (void *) d_fp, (void *) d_li, (void *) d_data, (void *) d_perm}) { plan_free(q); }
       return false;
    };
-   HIP_CHECK(hipMalloc((void **) &d_k0, sizeof(int) * ((size_t) blocks + 1)));
-   hipLaunchKernelGGL(sl_block_starts_kernel, dim3((blocks + 256) / 256), dim3(256), 0, s, A->i, n, R, blocks, d_k0);
-   HIP_CHECK(hipMalloc((void **) &d_cnt, sizeof(int) * (size_t) blocks));
-   HIP_CHECK(hipMalloc((void **) &d_desc, sizeof(int) * (size_t) blocks * XS_DESC));
    const size_t nl = ((size_t) nnz + 15) & ~(size_t) 7;
-   HIP_CHECK(hipMalloc((void **) &d_li, sizeof(unsigned short) * nl));
+   if (!plan_alloc((void **) &d_k0, sizeof(int) * ((size_t) blocks + 1), PLAN_SITE_SLICE) ||
+       !plan_alloc((void **) &d_cnt, sizeof(int) * (size_t) blocks, PLAN_SITE_SLICE) ||
+       !plan_alloc((void **) &d_desc, sizeof(int) * (size_t) blocks * XS_DESC, PLAN_SITE_SLICE) ||
+       !plan_alloc((void **) &d_li, sizeof(unsigned short) * nl, PLAN_SITE_SLICE)) { return fail(); }
+   hipLaunchKernelGGL(sl_block_starts_kernel, dim3((blocks + 256) / 256), dim3(256), 0, s, A->i, n, R, blocks, d_k0);
    HIP_CHECK(hipMemsetAsync(d_li, 0, sizeof(unsigned short) * nl, s));
    launch_build_xs(A->j, d_k0, blocks, d_cnt, d_desc, d_li, s);      // a block's entries are at most R * K <= 4096: what the builder sorts
    std::vector<int> cnt((size_t) blocks);
@@ -1243,14 +1260,14 @@ bool device_build_slice_form(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t 
    // LDS: the staged copy and the value table; at least four workgroups per CU
    if (16 * (size_t) units + 8 * DICT_CAP > 40 * 1024) { return fail(); }
    const size_t words = (size_t) blocks * 4 * (size_t) (wc + wl) * 64;
-   HIP_CHECK(hipMalloc((void **) &d_data, sizeof(unsigned) * words));
+   if (!plan_alloc((void **) &d_data, sizeof(unsigned) * words, PLAN_SITE_SLICE) ||
+       !plan_alloc((void **) &d_fp, sizeof(int) * (size_t) blocks, PLAN_SITE_SLICE)) { return fail(); }
    if (W == 1) { hipLaunchKernelGGL((sl_pack_kernel<1>), dim3(blocks), dim3(SPMV_THREADS), 0, s, A->i, p->d_codes, d_li, n, kper, wc, wl, d_data); }
    else        { hipLaunchKernelGGL((sl_pack_kernel<2>), dim3(blocks), dim3(SPMV_THREADS), 0, s, A->i, p->d_codes, d_li, n, kper, wc, wl, d_data); }
-   HIP_CHECK(hipMalloc((void **) &d_fp, sizeof(int) * (size_t) blocks));
    hipLaunchKernelGGL(sl_fp_kernel, dim3((blocks + 255) / 256), dim3(256), 0, s, A->j, d_k0, blocks, nnz, d_fp);
    // band-aware placement, as for the tiles (seq_mv.cpp: build_band_placement): XCD c takes the blocks of slab c
-   int *d_perm = nullptr;
-   if (p->band > 0 && blocks >= 64)
+   // (speed only: without the table the blocks go to the XCDs in runs of 8)
+   if (p->band > 0 && blocks >= 64 && plan_alloc((void **) &d_perm, sizeof(int) * (size_t) blocks, PLAN_SITE_SLICE))
    {
       const int B = p->band;
       std::vector<std::vector<int>> cls(8);
@@ -1265,15 +1282,316 @@ bool device_build_slice_form(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t 
       for (size_t c = 0; c < 8; c++) { for (size_t k = next[c]; k < cls[c].size(); k++) { leftovers.push_back(cls[c][k]); } }
       size_t lo = 0;
       for (int g = 0; g < blocks; g++) { if (perm[(size_t) g] < 0) { perm[(size_t) g] = leftovers[lo++]; } }
-      HIP_CHECK(hipMalloc((void **) &d_perm, sizeof(int) * (size_t) blocks));
       HIP_CHECK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t) blocks, hipMemcpyHostToDevice, s));
+      HIP_CHECK(hipStreamSynchronize(s));
    }
    HIP_CHECK(hipStreamSynchronize(s));
-   HIP_CHECK(hipFree(d_li));
+   plan_free(d_li);
    p->sl_w = W; p->sl_rows = R; p->sl_k = kper; p->sl_wc = wc; p->sl_wl = wl;
    p->sl_blocks = blocks; p->sl_launch_units = units;
    p->d_sl_cnt = d_cnt; p->d_sl_desc = d_desc; p->d_sl_k0 = d_k0; p->d_sl_fp = d_fp; p->d_sl_perm = d_perm; p->d_sl_data = d_data;
    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Row-slice form of owned, uncoded matrices (SpmvPlan::d_rs_val): the coarse-level operators.
+//
+// What the tiled kernel costs on them (level 1 of the benchmark hierarchy, 29 entries per
+// row, every value distinct): 550 instructions per wave and tile, half of them to park 2048 products in LDS and to sum them up
+// again with a lane tree — the level runs at 0.65 of the HBM peak with 52 % of its LDS-active cycles lost to bank conflicts.
+// The slice form of coded stencils showed the way out (a lane owns a row, sums from registers); these rows are neither
+// short nor equally long, so the slices are JAGGED: a workgroup takes R = 256 / W consecutive rows with W lanes per row, lane
+// `sub` of a row owns its entries sub, sub + W, ...; the 64 lane-tasks of a wave are sorted by their entry counts and entry c
+// of every task that has one lies side by side — chunk c of a wave holds exactly as many entries as it has tasks longer than
+// c.  No padding at all: 8 + 2 bytes per entry (fp64 value, 16-bit staged position of its column as a byte offset), no row
+// pointers, no column array; what a wave needs to find its chunks — the position of its first entry and the number of
+// active lanes per chunk — are 16 scalars.  Every lane multiplies and adds its entries in stored order out of registers
+// (one LDS read and one fused multiply-add per entry), writes ONE partial sum to LDS, and the lane that finishes a row adds
+// its W partial sums in lane order: no products parked, no tree, one barrier after the loads and one before the epilogue.
+// x is staged exactly as in spmv_xs_kernel (same builder over the blocks' entries, same descriptors, same LDS-DMA trip).
+// Only matrices that cannot change behind their plans get the form (it keeps a private copy of the values): no watch.
+// Reference counterpart: seq_mv/csr_spmv_device.c:149-260 (K lanes per row from the matrix-wide mean row length, shuffle
+// tree, x through the cache).
+// ---------------------------------------------------------------------------
+constexpr int RS_HDR = 16;          // ints per wave: [0] position of its first entry, [1] chunks, [4 + c / 4] byte c & 3: active lanes of chunk c
+// (A persistent form — a workgroup walking blocks v, v + G, ... with the NEXT block's header and descriptors requested behind
+// the current block's vector loads, so that no block waits for a cold scalar round trip — was built and measured: level 1
+// of the benchmark hierarchy 0.377 ms against 0.332 ms, whatever the number of workgroups; the doubled scalars spill.  Removed.)
+template <int OP, int KP, bool F32>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_rs_kernel(SpmvArgs p, const int *__restrict__ rs_desc, const int *__restrict__ rs_perm, const int *__restrict__ rs_hdr,
+                    const unsigned *__restrict__ rs_meta, const double *__restrict__ rs_val, const float *__restrict__ rs_val32,
+                    const unsigned *__restrict__ rs_idx, int blocks, int num_rows, int R, int W, int stage_elems)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *xs = reinterpret_cast<double *>(smem_raw);
+   double *part = xs + stage_elems;                 // [SPMV_THREADS] partial sums, lane-of-the-row major
+
+   int block = (int) blockIdx.x;
+   if (rs_perm)
+   {
+      if (block >= blocks) { return; }
+      block = rs_perm[block];
+   }
+   else { const int g = block >> 3, c = block & 7; block = (g >> 3) * 64 + c * 8 + (g & 7); }     // runs of 8 blocks per XCD
+   if ((unsigned) block >= (unsigned) blocks) { return; }
+
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   // known before anything about the block is: this lane's entry count and slot, the operands of the row it will finish
+   const unsigned meta = rs_meta[(size_t) block * SPMV_THREADS + tid];
+   const int r = block * R + tid;
+   const RowOps ops = load_row_ops<OP>(p, max(min(r, num_rows - 1), 0));
+   // wave-uniform, through the scalar cache: the wave's header and its piece descriptors
+   constexpr int NH = 4 + KP / 4;
+   const int *hdr = rs_hdr + (size_t) (block * 4 + wave) * RS_HDR;
+   int h[NH];
+#pragma unroll
+   for (int i = 0; i < NH; i++) { h[i] = hdr[i]; }
+   const int *dsc = rs_desc + (size_t) block * XS_DESC + XS_WSEG * wave;
+   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
+#pragma unroll
+   for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
+   asm volatile("" :: "s"(rs_desc), "s"(rs_hdr), "s"(rs_meta) : "memory");
+   const int nch = h[1];
+   // The stream, in groups of four chunks (a group the wave has none of is skipped: wave-uniform): chunk c of this wave
+   // starts where chunk c - 1 ended; lanes past a chunk's last entry — and chunks past the wave's last one inside a group —
+   // re-read the entry in front (same cache line, no traffic), so that every load of a group is unconditional.  The 16-bit
+   // positions come in pairs, one 32-bit word per lane for chunks 2p and 2p + 1 (as many words as chunk 2p has lanes): no
+   // 16-bit loads — those are widened on arrival, i.e. waited for where they are issued.
+   const double *wv = rs_val + h[0];
+   const float *wf = rs_val32 + h[0];
+   const unsigned *wi = rs_idx + h[2];
+   double   vv[KP];
+   float    vf[KP];
+   unsigned iw[KP / 2];                  // staged positions (byte offsets) of the lane's entries of chunks 2p (low half) and 2p + 1
+   {
+      int off = 0, offi = 0;
+#pragma unroll
+      for (int g = 0; g < KP / 4; g++)
+      {
+         if (4 * g < nch)
+         {
+#pragma unroll
+            for (int c = 4 * g; c < 4 * g + 4; c++)
+            {
+               const int na = (h[4 + (c >> 2)] >> (8 * (c & 3))) & 0xff;
+               const unsigned q = (unsigned) (off + min(lane, na - 1));
+               if (F32) { vf[c] = wf[q]; } else { vv[c] = wv[q]; }
+               if ((c & 1) == 0) { iw[c >> 1] = wi[(unsigned) (offi + min(lane, na - 1))]; offi += na; }
+               off += na;
+            }
+         }
+      }
+   }
+   // the x pieces, straight into LDS (see spmv_xs_kernel)
+#pragma unroll
+   for (int j = 0; j < XS_WSEG; j++)
+   {
+      const unsigned offb = (unsigned) seg_ol[j] >> 16, lanes = (unsigned) seg_ol[j] & 0xffffu;
+      if ((unsigned) lane < lanes)
+      {
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + (size_t) (unsigned) seg_start[j] + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(xs) + offb), 16, 0, 0);
+      }
+   }
+   __syncthreads();
+
+   // a lane's sum, four entries at a time: the LDS reads of a group in flight together, then the multiply-adds in stored
+   // order; an entry the lane does not have leaves the sum as it is (a select on the result: its x may be anything)
+   const int cnt = (int) (meta >> 10);          // (not byte-aligned on purpose: a byte would be folded into an SDWA compare against a
+                                                // REGISTER, and the constants 1 ... KP - 1 would then live in 31 VGPRs)
+   const char *xb = reinterpret_cast<const char *>(xs);
+   double sum = 0.0;
+#pragma unroll
+   for (int g = 0; g < KP / 4; g++)
+   {
+      if (4 * g < nch)
+      {
+         double xv[4];
+#pragma unroll
+         for (int j = 0; j < 4; j++)
+         {
+            const int c = 4 * g + j;
+            const unsigned pos = (c & 1) ? (iw[c >> 1] >> 16) : (iw[c >> 1] & 0xffffu);
+            xv[j] = *reinterpret_cast<const double *>(xb + pos);
+         }
+#pragma unroll
+         for (int j = 0; j < 4; j++)
+         {
+            const int c = 4 * g + j;
+            const double a = F32 ? (double) vf[c] : vv[c];
+            const double t = __fma_rn(a, xv[j], sum);
+            sum = (c < cnt) ? t : sum;
+         }
+      }
+   }
+   part[meta & 0x3ffu] = sum;
+   lds_barrier();
+   if (tid < R && r < num_rows)
+   {
+      double total = part[tid];
+      for (int j = 1; j < W; j++) { total += part[j * R + tid]; }
+      row_epilogue<OP>(p, r, total, ops);
+   }
+}
+
+// ---- row-slice construction: one workgroup per block
+__global__ __launch_bounds__(SPMV_THREADS)
+void rs_pack_kernel(const int *__restrict__ Ai, const double *__restrict__ Aa, const unsigned short *__restrict__ lidx, int n, int R, int W,
+                    int kp, int *__restrict__ hdr, unsigned *__restrict__ meta, double *__restrict__ val, unsigned *__restrict__ idx,
+                    int *__restrict__ fail)
+{
+   const int block = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int RW = R >> 2;                                   // rows of a wave (R >= 4)
+   const int q = wave * RW + lane / W, sub = lane % W;      // this thread's task: row q of the block, lane sub of the row
+   const int r = block * R + q;
+   const int s = r < n ? Ai[r] : 0, e = r < n ? Ai[r + 1] : 0, len = e - s;
+   int cnt = len > sub ? (len - sub + W - 1) / W : 0;
+   if (cnt > kp) { atomicExch(fail, 1); cnt = kp; }         // (the builder chose kp from the longest row: cannot happen)
+   // position of the task in its wave: entry counts descending, ties in task order
+   int rank = 0, above = 0;
+   for (int vv = kp; vv >= 0; vv--)
+   {
+      const unsigned long long m = __ballot(cnt == vv);
+      if (cnt == vv) { rank = above + __popcll(m & ((1ull << lane) - 1ull)); }
+      above += __popcll(m);
+   }
+   const int first = Ai[min(block * R + wave * RW, n)];     // position of the wave's first entry
+   // position of the wave's first word of staged positions: a wave with T entries holds between T / 2 and T / 2 + 32 words
+   // (one per lane and pair of chunks, as many as the even chunk has lanes), so waves 33 words apart beyond half their first
+   // entry never overlap
+   const int firsti = (first >> 1) + 33 * (block * 4 + wave);
+   int *hw = hdr + (size_t) (block * 4 + wave) * RS_HDR;
+   int off = 0, offi = 0, nch = 0, word = 0;
+   for (int c = 0; c < kp; c += 2)
+   {
+      const int na0 = __popcll(__ballot(cnt > c)), na1 = __popcll(__ballot(cnt > c + 1));
+      if (c < cnt)
+      {
+         const int k = s + sub + c * W;
+         val[(size_t) first + off + rank] = Aa[k];
+         unsigned w2 = 8u * lidx[k];
+         if (c + 1 < cnt)
+         {
+            val[(size_t) first + off + na0 + rank] = Aa[k + W];
+            w2 |= (8u * lidx[k + W]) << 16;
+         }
+         idx[(size_t) firsti + offi + rank] = w2;
+      }
+      if (na0 > 0) { nch = c + 1; }
+      if (na1 > 0) { nch = c + 2; }
+      word |= (na0 << (8 * (c & 3))) | (na1 << (8 * ((c + 1) & 3)));
+      if ((c & 3) == 2 || c + 2 >= kp) { if (lane == 0) { hw[4 + (c >> 2)] = word; } word = 0; }
+      off += na0 + na1;
+      offi += na0;
+   }
+   if (lane == 0) { hw[0] = first; hw[1] = nch; hw[2] = firsti; hw[3] = 0; }
+   meta[(size_t) block * SPMV_THREADS + wave * 64 + rank] = (unsigned) (sub * R + q) | ((unsigned) cnt << 10);
+}
+
+int &spmv_row_slices()
+{
+   static int mode = [] { const char *e = getenv("HYPRE_AMD_SPMV_ROW_SLICES"); return e ? atoi(e) : 1; }();
+   return mode;
+}
+
+bool device_build_row_slices(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t s)
+{
+   const int n = A->num_rows, nnz = A->num_nonzeros, K = p->max_row_nnz;
+   if (n < 1 || nnz < 1 || K < 1) { return false; }
+   static const int force_w = [] { const char *e = getenv("HYPRE_AMD_SPMV_RS_W"); return e ? atoi(e) : 0; }();
+   const double mean = (double) nnz / (double) n;
+   // lanes per row: a lane holds at most 32 entries; a block's entries are what the staging builder sorts (8192 at most:
+   // a mean of 6144 or less); the more rows a block holds the more of the x it stages is shared between them
+   int W = 1;
+   while (W < 64 && (K + W - 1) / W > 32) { W <<= 1; }
+   while (W < 64 && mean * (SPMV_THREADS / W) > 6144.0) { W <<= 1; }
+   if (force_w > 0) { W = force_w; }
+   for (; W <= 64; W <<= 1)
+   {
+      const int R = SPMV_THREADS / W;
+      const int per = (K + W - 1) / W;
+      if (per > 32) { continue; }
+      // blocks worth their overhead: a thousand entries or more on average
+      if (mean * R < 1024.0 && force_w <= 0) { return false; }
+      const int kp = per <= 8 ? 8 : (per <= 16 ? 16 : (per <= 24 ? 24 : 32));
+      const long long blocks_ll = ((long long) n + R - 1) / R;
+      if (blocks_ll > (1LL << 28)) { return false; }
+      const int blocks = (int) blocks_ll;
+      int *d_k0 = nullptr, *d_cnt = nullptr, *d_desc = nullptr, *d_hdr = nullptr, *d_perm = nullptr, *d_fail = nullptr;
+      unsigned *d_meta = nullptr;
+      unsigned short *d_li = nullptr;
+      unsigned *d_idx = nullptr;
+      double *d_val = nullptr;
+      auto release = [&]()
+      {
+         HIP_CHECK(hipStreamSynchronize(s));
+         for (void *q : {(void *) d_k0, (void *) d_cnt, (void *) d_desc, (void *) d_hdr, (void *) d_perm, (void *) d_fail, (void *) d_meta,
+                         (void *) d_li, (void *) d_idx, (void *) d_val}) { plan_free(q); }
+      };
+      const size_t nl = ((size_t) nnz + 15) & ~(size_t) 7;
+      if (!plan_alloc((void **) &d_k0, sizeof(int) * ((size_t) blocks + 1), PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_cnt, sizeof(int) * (size_t) blocks, PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_desc, sizeof(int) * (size_t) blocks * XS_DESC, PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_li, sizeof(unsigned short) * nl, PLAN_SITE_ROWSLICE)) { release(); return false; }
+      hipLaunchKernelGGL(sl_block_starts_kernel, dim3((blocks + 256) / 256), dim3(256), 0, s, A->i, n, R, blocks, d_k0);
+      HIP_CHECK(hipMemsetAsync(d_li, 0, sizeof(unsigned short) * nl, s));
+      launch_build_xs(A->j, d_k0, blocks, d_cnt, d_desc, d_li, s);
+      std::vector<int> cnt((size_t) blocks), k0((size_t) blocks + 1);
+      HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t) blocks, hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipMemcpyAsync(k0.data(), d_k0, sizeof(int) * ((size_t) blocks + 1), hipMemcpyDeviceToHost, s));
+      HIP_CHECK(hipStreamSynchronize(s));
+      int units = 0;
+      bool staged = true;
+      for (int b = 0; b < blocks; b++)
+      {
+         const int c = cnt[(size_t) b];
+         if ((c & 0xff) == 0 && k0[(size_t) b + 1] > k0[(size_t) b]) { staged = false; break; }     // (a block without entries stages nothing)
+         units = std::max(units, c >> 8);
+      }
+      // every block must be staged (the kernel has no gathering path), in at most 40 KB of LDS (four workgroups per CU)
+      if (!staged || 16 * (size_t) units + 8 * SPMV_THREADS > 40 * 1024)
+      {
+         release();
+         if (force_w > 0) { return false; }
+         continue;                                  // shorter blocks: more lanes per row
+      }
+      if (!plan_alloc((void **) &d_hdr, sizeof(int) * (size_t) blocks * 4 * RS_HDR, PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_meta, sizeof(unsigned) * (size_t) blocks * SPMV_THREADS, PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_val, sizeof(double) * ((size_t) nnz + 64), PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_idx, sizeof(unsigned) * ((size_t) nnz / 2 + 33 * 4 * (size_t) blocks + 128), PLAN_SITE_ROWSLICE) ||
+          !plan_alloc((void **) &d_fail, sizeof(int), PLAN_SITE_ROWSLICE)) { release(); return false; }
+      HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(int), s));
+      hipLaunchKernelGGL(rs_pack_kernel, dim3(blocks), dim3(SPMV_THREADS), 0, s, A->i, A->data, d_li, n, R, W, kp, d_hdr, d_meta, d_val, d_idx, d_fail);
+      int failed = 0;
+      HIP_CHECK(hipMemcpyAsync(&failed, d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
+      // band-aware placement, as for the tiles (speed only)
+      if (p->band > 0 && blocks >= 64 && plan_alloc((void **) &d_perm, sizeof(int) * (size_t) blocks, PLAN_SITE_ROWSLICE))
+      {
+         const int B = p->band;
+         std::vector<std::vector<int>> cls(8);
+         for (int b = 0; b < blocks; b++)
+         {
+            const int c = (int) (((long long) (((long long) b * R) % B) * 8) / B);
+            cls[(size_t) std::min(std::max(c, 0), 7)].push_back(b);
+         }
+         std::vector<int> perm((size_t) blocks, -1), leftovers;
+         std::vector<size_t> next(8, 0);
+         for (int g = 0; g < blocks; g++) { const size_t c = (size_t) (g & 7); if (next[c] < cls[c].size()) { perm[(size_t) g] = cls[c][next[c]++]; } }
+         for (size_t c = 0; c < 8; c++) { for (size_t k = next[c]; k < cls[c].size(); k++) { leftovers.push_back(cls[c][k]); } }
+         size_t lo = 0;
+         for (int g = 0; g < blocks; g++) { if (perm[(size_t) g] < 0) { perm[(size_t) g] = leftovers[lo++]; } }
+         HIP_CHECK(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * (size_t) blocks, hipMemcpyHostToDevice, s));
+      }
+      HIP_CHECK(hipStreamSynchronize(s));
+      if (failed) { release(); return false; }
+      plan_free(d_li); plan_free(d_k0); plan_free(d_cnt); plan_free(d_fail);
+      p->rs_w = W; p->rs_rows = R; p->rs_kp = kp; p->rs_blocks = blocks; p->rs_units = units;
+      p->d_rs_desc = d_desc; p->d_rs_perm = d_perm; p->d_rs_hdr = d_hdr; p->d_rs_meta = d_meta; p->d_rs_val = d_val; p->d_rs_idx = d_idx;
+      return true;
+   }
+   return false;
 }
 
 // ---------------------------------------------------------------------------
@@ -1405,12 +1723,10 @@ __global__ void sample_row_bands_kernel(const HYPRE_Int *__restrict__ Ai, const 
 
 void sample_row_bands(const HYPRE_Int *Ai, const HYPRE_Int *Aj, int num_rows, int nsamples, int *host_out, hipStream_t s)
 {
-   int *d_out = nullptr;
-   HIP_CHECK(hipMalloc((void **) &d_out, sizeof(int) * (size_t) nsamples));
+   int *d_out = reinterpret_cast<int *>(reduce_scratch(((size_t) nsamples + 1) / 2));
    hipLaunchKernelGGL(sample_row_bands_kernel, dim3((nsamples + 255) / 256), dim3(256), 0, s, Ai, Aj, num_rows, nsamples, d_out);
    HIP_CHECK(hipMemcpyAsync(host_out, d_out, sizeof(int) * (size_t) nsamples, hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
-   HIP_CHECK(hipFree(d_out));
 }
 
 int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
@@ -1423,6 +1739,41 @@ int device_max_row_nnz(const HYPRE_Int *Ai, int num_rows, hipStream_t s)
    hipLaunchKernelGGL(max_row_nnz_kernel, dim3(grid), dim3(256), 0, s, Ai, num_rows, d_out);
    int h = 0;
    HIP_CHECK(hipMemcpyAsync(&h, d_out, sizeof(int), hipMemcpyDeviceToHost, s));
+   HIP_CHECK(hipStreamSynchronize(s));
+   return h;
+}
+
+// ---- checksum of a CSR matrix's arrays (SpmvPlan::checksum): a sum (mod 2^64, so the order of the additions does not
+// matter) of a mixed word per row pointer and per entry — position, column and the value's bit pattern.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+   return x;
+}
+__global__ __launch_bounds__(256)
+void csr_checksum_kernel(const int *__restrict__ Ai, const int *__restrict__ Aj, const unsigned long long *__restrict__ Aa,
+                         int n, int nnz, unsigned long long *out)
+{
+   unsigned long long acc = 0;
+   const size_t stride = (size_t) gridDim.x * blockDim.x, t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+   for (size_t r = t; r <= (size_t) n; r += stride) { acc += mix64(((unsigned long long) r << 32) ^ (unsigned) Ai[r] ^ 0x9e3779b97f4a7c15ull); }
+   for (size_t k = t; k < (size_t) nnz; k += stride)
+   {
+      acc += mix64(Aa[k] ^ mix64(((unsigned long long) k << 32) | (unsigned) Aj[k]));
+   }
+#pragma unroll
+   for (int off = 32; off > 0; off >>= 1) { acc += __shfl_xor(acc, off, 64); }
+   if ((threadIdx.x & 63) == 0) { atomicAdd(out, acc); }
+}
+unsigned long long device_csr_checksum(const int *Ai, const int *Aj, const double *Aa, int n, int nnz, hipStream_t s)
+{
+   unsigned long long *d_out = reinterpret_cast<unsigned long long *>(reduce_scratch(2));
+   HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), s));
+   const size_t work = (size_t) std::max(nnz, n + 1);
+   const int grid = (int) std::min<size_t>((work + 255) / 256, (size_t) 16 * handle().num_cus);
+   hipLaunchKernelGGL(csr_checksum_kernel, dim3(std::max(grid, 1)), dim3(256), 0, s, Ai, Aj, reinterpret_cast<const unsigned long long *>(Aa), n, nnz, d_out);
+   unsigned long long h = 0;
+   HIP_CHECK(hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
    return h;
 }
@@ -1489,11 +1840,11 @@ bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out,
                         hipStream_t s)
 {
    *codes_out = nullptr; *dict_out = nullptr; *dict32_out = nullptr; *ndict_out = 0;
-   if (nnz == 0) { return false; }
+   if (nnz < 8) { return false; }           // (the kernels' rotating check reads eight consecutive entries)
+   // every allocation is checked (PLAN_SITE_CODES): on failure the matrix is simply not coded
    unsigned long long *d_table = nullptr;
-   int *d_count = nullptr;
-   HIP_CHECK(hipMalloc((void **) &d_table, sizeof(unsigned long long) * DICT_SLOTS + sizeof(int) * 4));
-   d_count = reinterpret_cast<int *>(d_table + DICT_SLOTS);
+   if (!plan_alloc((void **) &d_table, sizeof(unsigned long long) * DICT_SLOTS + sizeof(int) * 4, PLAN_SITE_CODES)) { return false; }
+   int *d_count = reinterpret_cast<int *>(d_table + DICT_SLOTS);
    HIP_CHECK(hipMemsetAsync(d_table, 0xff, sizeof(unsigned long long) * DICT_SLOTS, s));
    HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int) * 4, s));
    const unsigned long long *bits = reinterpret_cast<const unsigned long long *>(Aa);
@@ -1504,19 +1855,19 @@ bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out,
    hipLaunchKernelGGL(dict_collect_kernel, dim3((unsigned) ((head + 255) / 256)), dim3(256), 0, s, bits, head, d_table, d_count);
    HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
-   if (count > DICT_CAP) { HIP_CHECK(hipFree(d_table)); return false; }
+   if (count > DICT_CAP) { plan_free(d_table); return false; }
    int grid = (int) std::min<size_t>((nnz + 255) / 256, (size_t) 8 * handle().num_cus);
    if (nnz > head) { hipLaunchKernelGGL(dict_collect_kernel, dim3(grid), dim3(256), 0, s, bits, nnz, d_table, d_count); }
    std::vector<unsigned long long> table(DICT_SLOTS);
    HIP_CHECK(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipMemcpyAsync(table.data(), d_table, sizeof(unsigned long long) * DICT_SLOTS, hipMemcpyDeviceToHost, s));
    HIP_CHECK(hipStreamSynchronize(s));
-   if (count > DICT_CAP || count <= 0) { HIP_CHECK(hipFree(d_table)); return false; }
+   if (count > DICT_CAP || count <= 0) { plan_free(d_table); return false; }
    // codes in the order of the bit patterns: the same matrix gets the same codes whatever order the table filled in
    std::vector<unsigned long long> vals;
    for (unsigned long long v : table) { if (v != DICT_EMPTY) { vals.push_back(v); } }
    std::sort(vals.begin(), vals.end());
-   if ((int) vals.size() != count) { HIP_CHECK(hipFree(d_table)); hypre_error_w_msg(HYPRE_ERROR_GENERIC, "value table: count and contents disagree"); return false; }
+   if ((int) vals.size() != count) { plan_free(d_table); hypre_error_w_msg(HYPRE_ERROR_GENERIC, "value table: count and contents disagree"); return false; }
    std::vector<unsigned char> code_of_slot(DICT_SLOTS, 0);
    for (int i = 0; i < DICT_SLOTS; i++)
    {
@@ -1531,9 +1882,12 @@ bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out,
    unsigned char *d_cos = nullptr, *d_codes = nullptr;
    double *d_dict = nullptr;
    const size_t ncodes = (nnz + 31) & ~(size_t) 15;
-   HIP_CHECK(hipMalloc((void **) &d_cos, DICT_SLOTS));
-   HIP_CHECK(hipMalloc((void **) &d_codes, ncodes));
-   HIP_CHECK(hipMalloc((void **) &d_dict, sizeof(double) * 2 * DICT_CAP));
+   if (!plan_alloc((void **) &d_cos, DICT_SLOTS, PLAN_SITE_CODES) || !plan_alloc((void **) &d_codes, ncodes, PLAN_SITE_CODES) ||
+       !plan_alloc((void **) &d_dict, sizeof(double) * 2 * DICT_CAP, PLAN_SITE_CODES))
+   {
+      plan_free(d_cos); plan_free(d_codes); plan_free(d_dict); plan_free(d_table);
+      return false;
+   }
    HIP_CHECK(hipMemcpyAsync(d_cos, code_of_slot.data(), DICT_SLOTS, hipMemcpyHostToDevice, s));
    HIP_CHECK(hipMemcpyAsync(d_dict, dict.data(), sizeof(double) * DICT_CAP, hipMemcpyHostToDevice, s));
    HIP_CHECK(hipMemcpyAsync(d_dict + DICT_CAP, dict32.data(), sizeof(double) * DICT_CAP, hipMemcpyHostToDevice, s));
@@ -1541,8 +1895,8 @@ bool device_value_codes(const double *Aa, size_t nnz, unsigned char **codes_out,
    grid = (int) std::min<size_t>((nnz + 255) / 256, (size_t) 16 * handle().num_cus);
    hipLaunchKernelGGL(dict_encode_kernel, dim3(grid), dim3(256), 0, s, bits, nnz, d_table, d_cos, d_codes);
    HIP_CHECK(hipStreamSynchronize(s));
-   HIP_CHECK(hipFree(d_cos));
-   HIP_CHECK(hipFree(d_table));
+   plan_free(d_cos);
+   plan_free(d_table);
    *codes_out = d_codes; *dict_out = d_dict; *dict32_out = d_dict + DICT_CAP; *ndict_out = count;
    return true;
 }
@@ -1605,6 +1959,33 @@ static void launch_sl(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
    else { launch_sl_form<OP, 2, 16>(plan, a, s); }
 }
 
+template <int OP, int KP, bool F32>
+static void launch_rs_form(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   const int stage_elems = 2 * plan->rs_units + 8;
+   const size_t lds = sizeof(double) * (size_t) (stage_elems + SPMV_THREADS);
+   const int grid = plan->d_rs_perm ? plan->rs_blocks : ((plan->rs_blocks + 63) / 64) * 64;
+   hipLaunchKernelGGL((spmv_rs_kernel<OP, KP, F32>), dim3(grid), dim3(SPMV_THREADS), lds, s, a, plan->d_rs_desc, plan->d_rs_perm, plan->d_rs_hdr,
+                      plan->d_rs_meta, plan->d_rs_val, plan->d_rs_val32, plan->d_rs_idx, plan->rs_blocks, plan->num_rows, plan->rs_rows, plan->rs_w,
+                      stage_elems);
+}
+template <int OP, bool F32>
+static void launch_rs(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
+{
+   switch (plan->rs_kp)
+   {
+      case 8:  launch_rs_form<OP, 8, F32>(plan, a, s); break;
+      case 16: launch_rs_form<OP, 16, F32>(plan, a, s); break;
+      case 24: launch_rs_form<OP, 24, F32>(plan, a, s); break;
+      default: launch_rs_form<OP, 32, F32>(plan, a, s); break;
+   }
+}
+// the row-slice kernel serves this launch: the plan has the form, the whole matrix is multiplied, x can be read in 16-byte pieces
+static inline bool takes_rs(const SpmvPlan *plan, const SpmvArgs &a)
+{
+   return plan->d_rs_val && a.variant == 2 && a.fill == HYPRE_SPMV_FILL_WHOLE && (((uintptr_t) a.x) & 15) == 0;
+}
+
 // the x-staged kernel serves this launch: the plan carries the per-tile piece lists and x can be read in 16-byte pieces
 static inline bool takes_xs(const SpmvPlan *plan, const SpmvArgs &a)
 {
@@ -1614,6 +1995,7 @@ static inline bool takes_xs(const SpmvPlan *plan, const SpmvArgs &a)
 template <int OP, bool F32, bool FILL>
 static void launch_tiled(const SpmvPlan *plan, const SpmvArgs &a, hipStream_t s)
 {
+   if (!FILL && a.use_rs) { launch_rs<OP, F32>(plan, a, s); return; }
    // x staged through LDS (variant 2, the default)
    if (takes_xs(plan, a))
    {
@@ -1664,6 +2046,8 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    a.tile_perm = plan->d_tile_perm;
    a.tile_fp = plan->d_tile_fp;
    a.stale = plan->d_stale;
+   a.nnz = plan->nnz;
+   a.rot = const_cast<SpmvPlan *>(plan)->launches++;
    // value codes (the x-staged kernel only): one byte per entry and the table of the matrix's values
    a.Ac8 = nullptr; a.dict = nullptr; a.ndict = 0; a.dict_rounded = 0;
    if (plan->d_codes && takes_xs(plan, a))
@@ -1672,6 +2056,18 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       a.Ac8 = plan->d_codes; a.ndict = plan->ndict;
       a.dict = rounded ? plan->d_dict32 : plan->d_dict;
       a.dict_rounded = rounded ? 1 : 0;
+   }
+   a.use_rs = takes_rs(plan, a) ? 1 : 0;
+   if (a.use_rs && (handle().fp32_values || a.Aa32))
+   {
+      // mixed precision on a row-slice matrix: the fp32 copy of the values in slice order (same positions), made once;
+      // Aa32 only selects the fp32 kernel (the row-slice kernel reads the plan's copy)
+      SpmvPlan *mp = const_cast<SpmvPlan *>(plan);
+      if (!mp->d_rs_val32 && plan_alloc((void **) &mp->d_rs_val32, sizeof(float) * ((size_t) plan->nnz + 64), PLAN_SITE_ROWSLICE))
+      {
+         launch_f64_to_f32(plan->d_rs_val, mp->d_rs_val32, (size_t) plan->nnz, s);
+      }
+      if (mp->d_rs_val32) { a.Aa32 = mp->d_rs_val32; } else { a.use_rs = 0; }
    }
    if (handle().fp32_values && !a.Aa32 && !a.Ac8 && plan->nnz > 0)
    {
@@ -1701,8 +2097,26 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
          case OP_TSGS:       rowb = 32.0; break;                                              // d, z', u read and write
       }
       const double rows_b = 4.0 * (nr + 1.0) + rowb * nr + xcols;
-      const bool staged = plan->tiled && a.variant == 2 && plan->d_lidx != nullptr;
-      account_bytes(nz * (vw + 4.0) + rows_b, nz * ((a.Ac8 ? 1.0 : vw) + (staged ? 2.0 : 4.0)) + rows_b + (a.Ac8 ? 8.0 * a.ndict * plan->num_tiles : 0.0));
+      // what the format of the kernel that serves this launch requires: the matrix stream, the per-tile (per-block) tables
+      // — bounds, piece descriptors, fingerprint —, the value table and the rotating value check of a coded matrix
+      const bool staged = takes_xs(plan, a);
+      const bool slice = staged && a.Ac8 && a.fill == HYPRE_SPMV_FILL_WHOLE && plan->d_sl_data != nullptr;
+      double streamed;
+      if (a.use_rs)
+      {
+         // row slices: value + 16-bit position per entry, no row pointers; per block the wave headers, lane words and descriptors
+         streamed = nz * (vw + 2.0) + (double) plan->rs_blocks * (4.0 * (4 * RS_HDR + SPMV_THREADS + XS_DESC)) + rowb * nr + xcols;
+      }
+      else if (slice)
+      {
+         streamed = (double) plan->sl_blocks * ((double) SPMV_THREADS * plan->sl_k * 3.0 + 4.0 * (XS_DESC + 4) + 8.0 * a.ndict + 4.0 * 72.0) + rows_b;
+      }
+      else if (staged)
+      {
+         streamed = nz * ((a.Ac8 ? 1.0 : vw) + 2.0) + rows_b + (double) plan->num_tiles * (4.0 * (XS_DESC + 6) + (a.Ac8 ? 8.0 * a.ndict : 0.0) + ((a.Ac8 || a.Aa32) ? 4.0 * 72.0 : 0.0));
+      }
+      else { streamed = nz * (vw + 4.0) + rows_b + (plan->tiled ? 8.0 * plan->num_tiles : 0.0); }
+      account_bytes(nz * (vw + 4.0) + rows_b, streamed);
    }
    switch (op)
    {

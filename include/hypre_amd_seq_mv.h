@@ -132,6 +132,41 @@ HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_
  * Call after changing i/j/data in place or before freeing arrays that the
  * library does not own. */
 HYPRE_Int hypre_amd_CSRMatrixInvalidatePlan(hypre_CSRMatrix *A);
+/* What protects a caller who does NOT call it (the reference's hypre_CSRMatrixMatvec, seq_mv/csr_matvec.c:860-901, reads the
+ * caller's arrays on every call; a plan caches things derived from them):
+ *  - HYPRE_BoomerAMGSetup drops the plans of the matrix it is handed before anything else: a re-setup after
+ *    HYPRE_IJMatrixSetValues on the same pattern works on the new values on every level;
+ *  - the kernels that multiply by a private copy of the VALUES (value codes, slice form, fp32 copy) compare a rotating
+ *    sample of the copy with the fp64 array in every launch — eight consecutive entries per wave at a position that moves
+ *    with the plan's launch counter — so ANY coefficient edited in place is found within 64 (tiled kernel) or 128 (slice
+ *    kernel) products of that matrix: the pinned flag is raised, the next call raises HYPRE_ERROR_GENERIC and rebuilds the
+ *    plan, and a synchronous out-of-place product (or an in-place one with beta == 0) repeats itself with the fresh plan
+ *    so that the caller reads the right result.  An in-place product with beta != 0 (hypre_CSRMatrixMatvec) cannot be
+ *    repeated — its operand is already overwritten: the error is raised and y is NOT valid;
+ *  - the column PATTERN is sampled at two fixed positions per tile (found out: another matrix on the same addresses);
+ *  - hypre_amd_CSRMatrixVerifyPlan compares a 64-bit checksum of all three arrays with the one taken when the plan was
+ *    built (one pass over the CSR arrays) and silently drops a plan that fails; HYPRE_ParCSRPCGSolve / GMRESSolve and a
+ *    stand-alone HYPRE_BoomerAMGSolve (max_iter > 1) call it for the matrix they are handed, so a solve never STARTS from
+ *    stale values.  Returns 1 (the plan stands, or there is none) or 0 (dropped). */
+HYPRE_Int hypre_amd_CSRMatrixVerifyPlan(hypre_CSRMatrix *A);
+/* The caller's promise that the arrays of the device matrix A stay as they are until hypre_amd_CSRMatrixInvalidatePlan,
+ * hypre_amd_CSRMatrixSetImmutable(A, 0) or hypre_CSRMatrixDestroy: the plan may then keep a private copy of the fp64 values
+ * in the layout that multiplies fastest (the row-slice form) and its launches carry no watch.  The library sets this for
+ * the matrices it makes itself (hierarchy levels below the finest, interpolation / restriction operators, triangles,
+ * colour classes).  Changing the promise drops the plan.  No reference counterpart. */
+HYPRE_Int hypre_amd_CSRMatrixSetImmutable(hypre_CSRMatrix *A, HYPRE_Int on);
+/* Mixed precision for products called directly (the AMG cycle sets it from its solver, hypre_amd_BoomerAMGSetMixedPrecision):
+ * from now on the SpMV-class kernels stream an fp32 copy of the matrix values; vectors and sums stay fp64. */
+HYPRE_Int hypre_amd_SetMixedPrecisionValues(HYPRE_Int on);
+/* Which kernel form the plan of the device matrix A (built on demand) multiplies with: 0 a wave per row, 1 tiles with x
+ * gathered through the cache, 2 tiles with x staged through LDS, 3 coded tiles, 4 slice form of a coded stencil, 5 row-slice
+ * form; -1: not a device matrix. */
+HYPRE_Int hypre_amd_CSRMatrixPlanForm(hypre_CSRMatrix *A);
+/* Test hook: the nth allocation (1 = the next one) a plan builder makes at `site` fails, once — 1 tile tables, 2 x-staging
+ * tables, 3 value codes, 4 slice form, 5 row-slice form; nth <= 0 disarms.  A plan is an accelerator: the builder frees
+ * what the step had obtained, leaves no error behind and the matrix is multiplied one form lower.  Returns what was still
+ * pending of the request before (0: that failure happened, or nothing was armed). */
+HYPRE_Int hypre_amd_PlanTestFailAlloc(HYPRE_Int site, HYPRE_Int nth);
 /* Columns ascending inside every row of a device matrix, in place (keep_first != 0: a row's first entry — the diagonal of a
  * square block, seq_mv/csr_matop.c:1536-1604 — stays in front); the plan is dropped.  A utility (the reference's
  * hypre_CSRMatrixSortRow, seq_mv/csr_matop.c, for device matrices); nothing on the solve path needs sorted rows. */
@@ -151,7 +186,7 @@ HYPRE_Int hypre_amd_SpmvSetVariant(HYPRE_Int variant, HYPRE_Int unused);
  * value up in a table each tile keeps in LDS (1 + 2 bytes per entry instead of 8 + 2).  Found when the plan is built; on by
  * default (environment: HYPRE_AMD_SPMV_VALUE_CODES=0).  on < 0: unchanged.  Takes effect for plans built afterwards.
  * A caller that changes the values of a device matrix in place calls hypre_amd_CSRMatrixInvalidatePlan, as for the other
- * things a plan caches. */
+ * things a plan caches; one that does not is found out by the rotating value check (see hypre_amd_CSRMatrixInvalidatePlan). */
 HYPRE_Int hypre_amd_SpmvSetValueCodes(HYPRE_Int on);
 /* Slice form (speed only; no reference counterpart): a coded matrix whose rows hold at most 32 entries and are about equally
  * long (a stencil) is stored in the plan once more, a row's codes and local indices in one lane's words, and multiplied by a
@@ -160,6 +195,18 @@ HYPRE_Int hypre_amd_SpmvSetValueCodes(HYPRE_Int on);
  * kernel does where a tile holds 65 to 128 rows), within an ulp or two of the row's absolute sum.  On by default (environment:
  * HYPRE_AMD_SPMV_SLICE_FORM=0); on < 0: unchanged; takes effect for plans built afterwards. */
 HYPRE_Int hypre_amd_SpmvSetSliceForm(HYPRE_Int on);
+/* Row-slice form (speed only; no reference counterpart — the reference multiplies every matrix with K lanes per row and a
+ * shuffle tree, seq_mv/csr_spmv_device.c:149-260): a matrix that cannot change behind its plan (made by the library, or
+ * declared by hypre_amd_CSRMatrixSetImmutable) and is not coded is stored in the plan as jagged slices — 256 / W rows per
+ * workgroup, W lanes per row, the entries of the 64 lane-tasks of a wave side by side with no padding: fp64 value + 16-bit
+ * staged position per entry — and multiplied by a kernel in which a lane sums its entries in stored order from registers and
+ * the W partial sums of a row are added in lane order: within a few ulps of the row's absolute sum of any other summation
+ * order.  mode 0 off, 1 owned / immutable matrices (default; environment HYPRE_AMD_SPMV_ROW_SLICES), 2 every matrix (the
+ * caller then owes hypre_amd_CSRMatrixInvalidatePlan after any change of the arrays); < 0 unchanged.  Plans built afterwards. */
+HYPRE_Int hypre_amd_SpmvSetRowSlices(HYPRE_Int mode);
+/* Lanes per row of the row-slice form in the plan of the device matrix A (0: none); fills the rows of a block and the most
+ * entries a lane holds. */
+HYPRE_Int hypre_amd_CSRMatrixPlanRowSlices(hypre_CSRMatrix *A, HYPRE_Int *rows_per_block, HYPRE_Int *entries_per_lane);
 /* Lanes per row (1 or 2) of the slice form in the plan of the device matrix A; 0 when it has none. */
 HYPRE_Int hypre_amd_CSRMatrixPlanSliceForm(hypre_CSRMatrix *A);
 /* Number of distinct values in the value table of the plan of the device matrix A; 0 when A is not coded. */

@@ -721,9 +721,11 @@ def test_graphs_of_two_hierarchies_keep_their_own_diagonal_buffers(gpu_lib, orac
 
 
 def test_values_changed_under_a_mixed_precision_hierarchy_are_noticed(gpu_lib):
-    """Mixed precision streams an fp32 copy of the matrix values cached in the plan.  Values changed in place without
-    hypre_amd_CSRMatrixInvalidatePlan leave that copy behind; every tile compares one fp64 value with its fp32 copy, so
-    the next solve raises HYPRE_ERROR_GENERIC instead of silently preconditioning with the old operator."""
+    """Mixed precision multiplies by an fp32 copy (or an fp32-rounded table) of the matrix values kept in the plan.  Values
+    changed in place without hypre_amd_CSRMatrixInvalidatePlan leave that copy behind.  A stand-alone solve (more than one
+    cycle allowed) verifies the fine-level plans against the caller's arrays where it begins — the stale plan is replaced
+    silently and the solve is the new matrix's; a preconditioner call (one cycle, no verification) is found out by the
+    kernels' rotating value check: HYPRE_ERROR_GENERIC instead of silently preconditioning with the old operator."""
     from hypre_amd import binding as B
     lib = gpu_lib
     opt, A, s = _setup(lib, n=(30, 30, 30), coarsen_type=8, relax_type=18)
@@ -734,12 +736,79 @@ def test_values_changed_under_a_mixed_precision_hierarchy_are_noticed(gpu_lib):
     du, df = B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(np.ones(n))
     lib.HYPRE_BoomerAMGSolve(s, A, df, du)
     lib.HYPRE_ClearAllErrors()                            # (max_iter reached: expected)
+    u_old = B.parvec_to_numpy(du)
     d = A.contents.diag.contents
     vals = B.fetch(d.data, d.num_nonzeros, np.float64, d.memory_location) * 3.0
     lib.hypre_Memcpy(C.cast(d.data, C.c_void_p), vals.ctypes.data_as(C.c_void_p), vals.nbytes, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+    # stand-alone solve: verified where it begins, nothing raised, and the fine-level operator is the new one (3 A: the
+    # hierarchy below is the old one's, so the iterate is not u_old / 3 exactly — but the residual it reports is 3 A's)
+    lib.hypre_ParVectorSetZeros(du)
     lib.HYPRE_BoomerAMGSolve(s, A, df, du)
     lib.hypre_SyncComputeStream()
+    assert not (lib.HYPRE_GetError() & 1)
+    lib.HYPRE_ClearAllErrors()
+    assert lib.hypre_amd_CSRMatrixVerifyPlan(A.contents.diag) == 1
+    assert np.max(np.abs(B.parvec_to_numpy(du) - u_old)) > 1e-3 * np.max(np.abs(u_old))
+    # preconditioner call (one cycle): the kernels notice
+    vals = vals / 3.0
+    lib.hypre_Memcpy(C.cast(d.data, C.c_void_p), vals.ctypes.data_as(C.c_void_p), vals.nbytes, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    lib.hypre_ParVectorSetZeros(du)
+    lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+    lib.hypre_SyncComputeStream()
+    lib.hypre_ParVectorSetZeros(du)
     lib.HYPRE_BoomerAMGSolve(s, A, df, du)                # (the flag is read when the plan is next asked for)
     assert lib.HYPRE_GetError() & 1           # HYPRE_ERROR_GENERIC: "a kernel found its SpMV plan out of date"
     lib.HYPRE_BoomerAMGDestroy(s)
     lib.HYPRE_ClearAllErrors()
+
+
+@pytest.mark.parametrize("edit", ["one coefficient in the middle of a tile", "one row scaled"])
+@pytest.mark.parametrize("relax_type", [18, 11])
+def test_a_new_setup_after_an_in_place_edit_works_on_the_new_values(gpu_lib, oracle, edit, relax_type):
+    """The hypre idiom: change some coefficients of the matrix in place (HYPRE_IJMatrixSetValues on the same pattern), call
+    HYPRE_BoomerAMGSetup again, solve.  The fine-level operator of these stencils is multiplied from value codes in slice
+    form — a private copy of the values — and the setup drops the plans of the matrix it is handed before anything else: with
+    NO call to hypre_amd_CSRMatrixInvalidatePlan, one cycle after the new setup is the oracle's cycle on the new matrix
+    (hierarchy and fine level alike), and nothing is raised."""
+    from hypre_amd import binding as B, ij
+    lib = gpu_lib
+    opt = ij.IJOptions(n=(24, 22, 20), coarsen_type=8, relax_type=relax_type)
+    A = ij.build_matrix(opt)
+    lib.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+    s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
+    lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    n = 24 * 22 * 20
+    f = rand_vector(n, 5)
+    df, du = B.parvec_from_numpy(f), B.parvec_from_numpy(np.zeros(n))
+
+    def one_cycle():
+        lib.HYPRE_BoomerAMGSetup(s, A, None, None)
+        B.check()
+        lib.hypre_ParVectorSetZeros(du)
+        lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+        B.check()
+        u = B.parvec_to_numpy(du)
+        amg = oracle.amg_from_solvers([s])
+        ur = np.zeros(n)
+        amg.cycle(f, ur, u_all_zeros=True)
+        return u, ur
+
+    u, ur = one_cycle()
+    assert np.max(np.abs(u - ur)) <= 1e-11 * np.max(np.abs(ur))
+    d = A.contents.diag.contents
+    assert lib.hypre_amd_CSRMatrixPlanForm(A.contents.diag) == 4          # coded, slice form: the values are a private copy
+    vals = B.fetch(d.data, d.num_nonzeros, np.float64, d.memory_location).copy()
+    rowptr = B.fetch(d.i, d.num_rows + 1, np.int32, d.memory_location)
+    if edit.startswith("one coefficient"):
+        vals[2048 * 7 + 1001] *= 1.25
+    else:
+        r = n // 2 + 3
+        vals[rowptr[r]:rowptr[r + 1]] *= 1.5
+    lib.hypre_Memcpy(C.cast(d.data, C.c_void_p), vals.ctypes.data_as(C.c_void_p), vals.nbytes, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+    u2, ur2 = one_cycle()
+    assert np.max(np.abs(ur2 - ur)) > 1e-6 * np.max(np.abs(ur))            # the edit matters ...
+    assert np.max(np.abs(u2 - ur2)) <= 1e-11 * np.max(np.abs(ur2))         # ... and the device cycle is the new matrix's
+    lib.HYPRE_BoomerAMGDestroy(s)
+    B.check()

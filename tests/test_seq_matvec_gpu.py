@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from util import laplace_3d, random_csr, rand_vector
+from util import banded_csr, laplace_3d, random_csr, rand_vector
 
 pytestmark = pytest.mark.gpu
 
@@ -355,7 +355,7 @@ def test_a_plan_that_outlived_its_matrix_is_found_out(gpu_lib, oracle, how):
 def test_sort_rows_and_byte_counters(gpu_lib, oracle):
     """hypre_amd_CSRMatrixSortRows: columns ascending inside every row, a row's first entry kept in front, the product
     unchanged up to the order of a row's sum.  hypre_amd_ByteCounters: one product accounts for the SURVEY 8(d) count of its
-    matrix (12 bytes per entry, row pointers, x once, y once) and for 2 bytes less per entry streamed where x is staged."""
+    matrix (12 bytes per entry, row pointers, x once, y once) and, as streamed, for what the launched kernel's format requires."""
     import ctypes as C
     from hypre_amd import binding as B
     lib = gpu_lib
@@ -370,7 +370,10 @@ def test_sort_rows_and_byte_counters(gpu_lib, oracle):
     lib.hypre_amd_ByteCounters(C.byref(csr), C.byref(streamed), 1)
     nnz, n = A.nnz, 7000
     assert csr.value == nnz * 12 + (n + 1) * 4 + n * 8 + n * 8
-    assert streamed.value in (csr.value, csr.value - 2 * nnz)
+    # streamed: what the launched kernel's format requires — 2 bytes less per entry where x is staged (16-bit local indices,
+    # no column array), plus the per-tile tables (bounds, 96 piece descriptors, fingerprint: 408 bytes per 2048-entry tile)
+    tiles = (nnz + 2047) // 2048
+    assert streamed.value in (csr.value + 8 * tiles, csr.value - 2 * nnz + 408 * tiles)
     y0 = B.vec_to_numpy(dy)
     lib.hypre_amd_CSRMatrixSortRows(dA, 1)
     B.check()
@@ -583,3 +586,262 @@ def test_the_slice_kernel_notices_another_matrix(gpu_lib, oracle):
     for o in (dx, dy):
         lib.hypre_SeqVectorDestroy(o)
     lib.hypre_CSRMatrixDestroy(dA)
+
+
+def _poke(lib, dA, positions, values):
+    """entries `positions` of the device value array of dA now hold `values`: an in-place edit of some coefficients, the
+    hypre idiom (HYPRE_IJMatrixSetValues on the same pattern) — nothing is told to the library"""
+    import ctypes as C
+    from hypre_amd import binding as B
+    base = C.cast(dA.contents.data, C.c_void_p).value
+    for k, v in zip(positions, values):
+        src = np.array([v], dtype=np.float64)
+        lib.hypre_Memcpy(C.c_void_p(base + 8 * int(k)), src.ctypes.data_as(C.c_void_p), 8, B.HYPRE_MEMORY_DEVICE, B.HYPRE_MEMORY_HOST)
+
+
+@pytest.mark.parametrize("form,bound", [("slice", 128), ("coded tiles", 64), ("fp32 copy", 64)])
+@pytest.mark.parametrize("edit", ["one coefficient in the middle of a tile", "one row scaled"])
+def test_any_coefficient_edited_in_place_is_found_within_the_bound(gpu_lib, oracle, form, bound, edit):
+    """The kernels that multiply by a private copy of the values — value codes, the slice form, the fp32 copy of the mixed-
+    precision mode — compare a ROTATING sample of the copy with the caller's fp64 array: eight consecutive entries per wave
+    at a position that moves with the plan's launch counter.  So ONE coefficient changed in place, anywhere, without
+    hypre_amd_CSRMatrixInvalidatePlan, is found within 64 (tiled kernel) or 128 (slice kernel) products: HYPRE_ERROR_GENERIC
+    is raised, the plan rebuilt, and the synchronous product repeats itself so that the caller reads the NEW matrix's
+    product.  (Round 3 sampled one fixed entry per tile: only a wholesale replacement was noticed.)"""
+    import ctypes as C
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = laplace_3d(24, 22, 20).tocsr()
+    A.sort_indices()
+    n = A.shape[0]
+    x = rand_vector(n, 9)
+    if edit.startswith("one coefficient"):
+        ks = [2048 * 7 + 1001]                               # the middle of tile 7
+        new = [0.375]
+    else:
+        r = n // 2 + 3
+        ks = list(range(A.indptr[r], A.indptr[r + 1]))
+        new = list(1.5 * A.data[ks])
+    A2 = A.copy()
+    A2.data[ks] = new
+    try:
+        lib.hypre_amd_SpmvSetSliceForm(1 if form == "slice" else 0)
+        dA = B.csr_from_scipy(A)
+        dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(n))
+        if form == "fp32 copy":
+            lib.hypre_amd_SpmvSetValueCodes(0)
+            lib.hypre_amd_SetMixedPrecisionValues(1)
+        lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+        B.check()
+        assert lib.hypre_amd_CSRMatrixPlanForm(dA) == {"slice": 4, "coded tiles": 3, "fp32 copy": 2}[form]
+        _poke(lib, dA, ks, new)
+        found = None
+        for launch in range(1, bound + 1):
+            lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+            if lib.HYPRE_GetError():
+                found = launch
+                break
+        assert found is not None, "an edited coefficient went unnoticed for %d products" % bound
+        lib.HYPRE_ClearAllErrors()
+        tol = _bound(A2, x, 1.0, 0.0, x) if form != "fp32 copy" else 1e-6 * (abs(A2) @ np.abs(x))
+        assert np.all(np.abs(B.vec_to_numpy(dy) - A2 @ x) <= tol)          # the repeated product is the new matrix's
+        lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+        B.check()                                                          # the rebuilt plan stands
+        for o in (dx, dy):
+            lib.hypre_SeqVectorDestroy(o)
+        lib.hypre_CSRMatrixDestroy(dA)
+    finally:
+        lib.hypre_amd_SpmvSetSliceForm(1)
+        lib.hypre_amd_SpmvSetValueCodes(1)
+        lib.hypre_amd_SetMixedPrecisionValues(0)
+
+
+def test_an_in_place_product_with_beta_is_not_repeated(gpu_lib, oracle):
+    """hypre_CSRMatrixMatvec(alpha, A, x, beta, y) with beta != 0 overwrites the operand a repeat would need: when the kernels
+    find the plan out of date the error is raised, the plan rebuilt — and y is documented as NOT valid (the next call is right)."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A1 = laplace_3d(20, 20, 20)
+    A2 = sp.csr_matrix((A1.data * 0.5, A1.indices, A1.indptr), shape=A1.shape)
+    n = A1.shape[0]
+    x, y0 = rand_vector(n, 3), rand_vector(n, 4)
+    dA = B.csr_from_scipy(A1)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(y0)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.5, dy)
+    B.check()
+    y1 = B.vec_to_numpy(dy)
+    assert np.all(np.abs(y1 - (A1 @ x + 0.5 * y0)) <= _bound(A1, x, 1.0, 0.5, y0))
+    _overwrite(lib, dA, A2)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.5, dy)
+    with pytest.raises(B.HypreAmdError):
+        B.check()
+    lib.HYPRE_ClearAllErrors()
+    # y now holds alpha A1 x + beta y1 (the stale product): reported, not repaired; the next call multiplies by A2
+    dz = B.vec_from_numpy(y0)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.5, dz)
+    B.check()
+    assert np.all(np.abs(B.vec_to_numpy(dz) - (A2 @ x + 0.5 * y0)) <= _bound(A2, x, 1.0, 0.5, y0))
+    for o in (dx, dy, dz):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
+
+
+def test_verify_plan_finds_any_edit_at_once(gpu_lib, oracle):
+    """hypre_amd_CSRMatrixVerifyPlan: the checksum of row pointers, columns and value bit patterns taken when the plan was
+    built against the arrays as they are now — one changed coefficient, one changed column: the plan is dropped silently and
+    the next product is the new matrix's, with no error raised."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = random_csr(5000, 5000, 5, 40, seed=11)
+    x = rand_vector(5000, 1)
+    dA = B.csr_from_scipy(A)
+    dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(np.zeros(5000))
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert lib.hypre_amd_CSRMatrixVerifyPlan(dA) == 1
+    A2 = A.copy()
+    A2.data[12345] *= 1.0 + 2.0 ** -40                      # a few ulps
+    _overwrite(lib, dA, A2)
+    assert lib.hypre_amd_CSRMatrixVerifyPlan(dA) == 0
+    assert lib.hypre_amd_CSRMatrixVerifyPlan(dA) == 1       # no plan left to object to
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A2 @ x) <= _bound(A2, x, 1.0, 0.0, x))
+    A3 = A2.copy()
+    A3.indices[777] = (A3.indices[777] + 1) % 5000 if (A3.indices[777] + 1) % 5000 not in A3.indices[A3.indptr[np.searchsorted(A3.indptr, 777, side="right") - 1]:A3.indptr[np.searchsorted(A3.indptr, 777, side="right")]] else A3.indices[777]
+    _overwrite(lib, dA, A3)
+    changed = not np.array_equal(A3.indices, A2.indices)
+    assert lib.hypre_amd_CSRMatrixVerifyPlan(dA) == (0 if changed else 1)
+    lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dy)
+    B.check()
+    assert np.all(np.abs(B.vec_to_numpy(dy) - A3 @ x) <= _bound(A3, x, 1.0, 0.0, x))
+    for o in (dx, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
+
+
+@pytest.mark.parametrize("site,lowest", [(1, 0), (2, 1), (3, 2), (4, 3)])
+@pytest.mark.parametrize("nth", [1, 2, 3, 4, 5, 6])
+def test_a_failed_plan_allocation_falls_back_one_form(gpu_lib, oracle, site, lowest, nth):
+    """Every allocation a plan builder makes is checked: with the nth allocation of a site made to fail — tile tables,
+    x-staging tables, value codes, slice form — the builder frees what the step had obtained, leaves hypre_error_flag clean
+    and the matrix is multiplied by the form below (a wave per row, tiles gathering x, uncoded tiles, coded tiles)."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = laplace_3d(22, 20, 18)
+    n = A.shape[0]
+    x, b = rand_vector(n, 2), rand_vector(n, 3)
+    dA = B.csr_from_scipy(A)
+    dx, db, dy = B.vec_from_numpy(x), B.vec_from_numpy(b), B.vec_from_numpy(np.zeros(n))
+    try:
+        lib.hypre_amd_PlanTestFailAlloc(site, nth)
+        lib.hypre_CSRMatrixMatvecOutOfPlace(-0.5, dA, dx, 2.0, db, dy, 0)
+        B.check()                                            # nothing raised
+        form = lib.hypre_amd_CSRMatrixPlanForm(dA)
+        happened = lib.hypre_amd_PlanTestFailAlloc(0, 0) == 0     # (a site makes two to seven allocations for this matrix)
+        assert nth > 2 or happened
+        assert (form <= lowest) if happened else (form == 4), (form, lowest, happened)
+        assert np.all(np.abs(B.vec_to_numpy(dy) - (-0.5 * (A @ x) + 2.0 * b)) <= _bound(A, x, -0.5, 2.0, b))
+        # the next plan of the same matrix gets everything again
+        lib.hypre_amd_CSRMatrixInvalidatePlan(dA)
+        lib.hypre_CSRMatrixMatvecOutOfPlace(-0.5, dA, dx, 2.0, db, dy, 0)
+        B.check()
+        assert lib.hypre_amd_CSRMatrixPlanForm(dA) == 4
+        assert np.all(np.abs(B.vec_to_numpy(dy) - (-0.5 * (A @ x) + 2.0 * b)) <= _bound(A, x, -0.5, 2.0, b))
+    finally:
+        lib.hypre_amd_PlanTestFailAlloc(0, 0)
+    for o in (dx, db, dy):
+        lib.hypre_SeqVectorDestroy(o)
+    lib.hypre_CSRMatrixDestroy(dA)
+
+
+@pytest.mark.parametrize("lo,hi,n,lanes", [(4, 12, 6000, 1), (13, 48, 5000, 2), (20, 40, 9000, 2), (49, 160, 3000, 8), (60, 90, 2500, 4),
+                                           (200, 900, 1500, 32), (0, 30, 4000, 1), (1, 3, 6000, 0), (33, 64, 2000, 4), (5, 8, 300, 1)])
+def test_row_slice_form(gpu_lib, oracle, lo, hi, n, lanes):
+    """An uncoded matrix that cannot change behind its plan is multiplied from jagged row slices (spmv_rs_kernel: 256 / W rows a
+    workgroup, W lanes a row, a lane's entries summed in stored order from registers, the W partial sums of a row added in
+    lane order): every epilogue of y = alpha A x + beta b against scipy within the tolerance of this file and against the
+    tiled kernel's result; every width W = 1 ... 32 and every register form (8 ... 32 entries a lane); empty rows; rows too
+    short for the form to pay keep the tiles.  The form is for matrices the library owns (coarse levels) or the caller
+    declared immutable: here hypre_amd_CSRMatrixSetImmutable."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = banded_csr(n, n - 100, lo, hi, max(hi + 100, 500), seed=hi + n, empty_frac=0.02 if lo == 0 else 0.0)
+    x, b = rand_vector(n - 100, 1), rand_vector(n, 2)
+    out = {}
+    for immutable in (1, 0):
+        dA = B.csr_from_scipy(A)
+        lib.hypre_amd_CSRMatrixSetImmutable(dA, immutable)
+        dx, db, dy = B.vec_from_numpy(x), B.vec_from_numpy(b), B.vec_from_numpy(np.zeros(n))
+        res = []
+        for alpha, beta in ((1.0, 0.0), (-1.0, 1.0), (0.7, -0.3)):
+            lib.hypre_CSRMatrixMatvecOutOfPlace(alpha, dA, dx, beta, db, dy, 0)
+            B.check()
+            res.append(B.vec_to_numpy(dy))
+        rows, per = C.c_int(), C.c_int()
+        w = lib.hypre_amd_CSRMatrixPlanRowSlices(dA, C.byref(rows), C.byref(per))
+        form = lib.hypre_amd_CSRMatrixPlanForm(dA)
+        if immutable and lanes:
+            assert form == 5 and w == lanes, (form, w)
+            assert rows.value == 256 // w and per.value in (8, 16, 24, 32) and per.value * w >= np.diff(A.indptr).max()
+        else:
+            assert form == 2 and w == 0
+        out[immutable] = res
+        for o in (dx, db, dy):
+            lib.hypre_SeqVectorDestroy(o)
+        lib.hypre_CSRMatrixDestroy(dA)
+    for (alpha, beta), y1, y0 in zip(((1.0, 0.0), (-1.0, 1.0), (0.7, -0.3)), out[1], out[0]):
+        ref = alpha * (A @ x) + beta * b
+        assert np.all(np.abs(y1 - ref) <= _bound(A, x, alpha, beta, b))
+        assert np.all(np.abs(y1 - y0) <= _bound(A, x, alpha, beta, b))
+
+
+def test_row_slices_of_every_matrix_and_their_fallbacks(gpu_lib, oracle):
+    """hypre_amd_SpmvSetRowSlices(2): every uncoded matrix gets the form (the caller then owes InvalidatePlan after a change);
+    a failed allocation of the form's tables (site 5) leaves the tiles; a coded matrix keeps its codes; in-place products and
+    the transposed product go through it; mixed precision multiplies by the fp32 copy of the slices."""
+    import ctypes as C
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A = banded_csr(7000, 7000, 15, 45, 400, seed=5)
+    x, y0 = rand_vector(7000, 1), rand_vector(7000, 2)
+    try:
+        lib.hypre_amd_SpmvSetRowSlices(2)
+        for nth in (0, 1, 4, 5, 7):
+            dA = B.csr_from_scipy(A)
+            dx, dy = B.vec_from_numpy(x), B.vec_from_numpy(y0)
+            lib.hypre_amd_PlanTestFailAlloc(5, nth)
+            lib.hypre_CSRMatrixMatvec(-0.5, dA, dx, 1.5, dy)
+            B.check()
+            happened = nth > 0 and lib.hypre_amd_PlanTestFailAlloc(0, 0) == 0
+            assert lib.hypre_amd_CSRMatrixPlanForm(dA) == (2 if happened else 5), (nth, happened)
+            assert np.all(np.abs(B.vec_to_numpy(dy) - (-0.5 * (A @ x) + 1.5 * y0)) <= _bound(A, x, -0.5, 1.5, y0))
+            # the transposed product: the cached transpose is a matrix of its own
+            dz = B.vec_from_numpy(np.zeros(7000))
+            lib.hypre_CSRMatrixMatvecT(1.0, dA, dx, 0.0, dz)
+            B.check()
+            assert np.all(np.abs(B.vec_to_numpy(dz) - A.T @ x) <= _bound(A.T.tocsr(), x, 1.0, 0.0, x))
+            # mixed precision: the values rounded through fp32
+            lib.hypre_amd_SetMixedPrecisionValues(1)
+            lib.hypre_CSRMatrixMatvec(1.0, dA, dx, 0.0, dz)
+            lib.hypre_amd_SetMixedPrecisionValues(0)
+            B.check()
+            A32 = sp.csr_matrix((A.data.astype(np.float32).astype(np.float64), A.indices, A.indptr), shape=A.shape)
+            assert np.all(np.abs(B.vec_to_numpy(dz) - A32 @ x) <= _bound(A32, x, 1.0, 0.0, x))
+            for o in (dx, dy, dz):
+                lib.hypre_SeqVectorDestroy(o)
+            lib.hypre_CSRMatrixDestroy(dA)
+        S = laplace_3d(16, 16, 16)
+        dS = B.csr_from_scipy(S)
+        xs_, ys_ = B.vec_from_numpy(rand_vector(4096, 3)), B.vec_from_numpy(np.zeros(4096))
+        lib.hypre_CSRMatrixMatvec(1.0, dS, xs_, 0.0, ys_)
+        B.check()
+        assert lib.hypre_amd_CSRMatrixPlanForm(dS) == 4          # a stencil: codes in slice form, not row slices
+        for o in (xs_, ys_):
+            lib.hypre_SeqVectorDestroy(o)
+        lib.hypre_CSRMatrixDestroy(dS)
+    finally:
+        lib.hypre_amd_SpmvSetRowSlices(1)
+        lib.hypre_amd_PlanTestFailAlloc(0, 0)
+        lib.hypre_amd_SetMixedPrecisionValues(0)

@@ -64,3 +64,25 @@ def random_csr(nrows, ncols, min_nnz, max_nnz, seed=0, empty_frac=0.0):
         indices[indptr[r]:indptr[r + 1]] = rng.choice(ncols, counts[r], replace=False)
     data = rng.uniform(-1, 1, indptr[-1])
     return sp.csr_matrix((data, indices, indptr), shape=(nrows, ncols))
+
+
+def banded_csr(nrows, ncols, min_nnz, max_nnz, band, seed=0, empty_frac=0.0):
+    """Rows with a uniformly random number of entries in [min_nnz, max_nnz] at random, unsorted columns within `band` of the
+    row's own position (scaled to the column range): the locality of an operator on a mesh, all values distinct."""
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(min_nnz, max_nnz + 1, nrows)
+    if empty_frac > 0:
+        counts[rng.random(nrows) < empty_frac] = 0
+    indptr = np.zeros(nrows + 1, dtype=np.int32)
+    lo = np.empty(nrows, dtype=np.int64)
+    hi = np.empty(nrows, dtype=np.int64)
+    for r in range(nrows):
+        c = int(r * (ncols - 1) / max(nrows - 1, 1))
+        lo[r], hi[r] = max(0, c - band), min(ncols, c + band + 1)
+        counts[r] = min(counts[r], hi[r] - lo[r])
+    indptr[1:] = np.cumsum(counts)
+    indices = np.empty(indptr[-1], dtype=np.int32)
+    for r in range(nrows):
+        indices[indptr[r]:indptr[r + 1]] = lo[r] + rng.choice(hi[r] - lo[r], counts[r], replace=False)
+    data = rng.uniform(-1, 1, indptr[-1])
+    return sp.csr_matrix((data, indices, indptr), shape=(nrows, ncols))
