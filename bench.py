@@ -142,7 +142,7 @@ def main():
             if int(flag.item()) == 0:
                 # loud, and recorded in the JSON line: halo traffic staged over the host instead of xGMI
                 print("rank %d: falling back to the host-staged gloo transport" % rank, file=sys.stderr, flush=True)
-                transport = "gloo-fallback"
+                transport = "gloo-fallback (RCCL self-test failed)"
                 comm = distributed.create_stream_staged_comm(dist, rank, world)
 
     P, Q, R = proc_grid(world)
@@ -259,6 +259,39 @@ def main():
             row.update(P_neighbours=ns.value, P_send_bytes=8 * se.value, PT_send_bytes=8 * re_.value,
                        exchanges=4, bytes_sent=2 * row["A_send_bytes"] + 8 * se.value + 8 * re_.value)
             exchange_plan.append(row)
+    # ---- how much of every exchange the interior work hid (N > 1): a few more cycles with timing events on every
+    # exchange — buffer packed, transfers done, compute stream about to wait for them — read out per AMG level: the EXPOSED
+    # time is what the compute stream spent waiting at the halo event.  Rank 0's figures; per cycle.
+    overlap = None
+    if world > 1:
+        MT = 32
+        kd = max(1, min(args.steps, 5))
+        L.hypre_amd_CommSetTiming(1)
+        for _ in range(kd):
+            step()
+        fence()
+        ex, ar = (C.c_int * MT)(), (C.c_int * MT)()
+        eu, tu, hu = (C.c_double * MT)(), (C.c_double * MT)(), (C.c_double * MT)()
+        L.hypre_amd_CommExposedTimes(MT, ex, ar, eu, tu, hu)
+        L.hypre_amd_CommSetTiming(0)
+        B.check()
+        planned = {row["level"] for row in exchange_plan}
+        for row in exchange_plan:
+            l = row["level"]
+            row.update(timed_exchanges=ex[l] / kd, exposed_us=eu[l] / kd, transfer_us=tu[l] / kd, host_in_transport_us=hu[l] / kd)
+        others = [{"level": (l if l < MT - 1 else "outside a cycle"), "exchanges": ex[l] / kd, "allreduces": ar[l] / kd,
+                   "exposed_us": eu[l] / kd, "transfer_us": tu[l] / kd, "host_in_transport_us": hu[l] / kd}
+                  for l in range(MT) if l not in planned and (ex[l] or ar[l])]
+        overlap = {"cycles_timed": kd, "exposed_us_per_cycle": sum(eu) / kd, "transfer_us_per_cycle": sum(tu) / kd,
+                   "host_in_transport_us_per_cycle": sum(hu) / kd,
+                   "exchanges_per_cycle": sum(ex) / kd, "allreduces_per_cycle": sum(ar) / kd,
+                   "levels_without_a_package_row": others,
+                   "what": "exposed = compute stream waiting at the halo event (not hidden behind the interior product / sweep); "
+                           "transfer = send buffer packed -> transfers done on the communication stream; host_in_transport = "
+                           "wall-clock time of the host inside the transport's calls (RCCL: an enqueue; a host-staged transport "
+                           "blocks there for the whole transfer and enqueues nothing meanwhile: the compute stream then runs dry "
+                           "without waiting at an event, so ms_per_step - single-rank ms ~ exposed + host_in_transport there); "
+                           "the first sweep of a cycle starts from zero and exchanges nothing (3 of the 4 planned on level 0); rank 0"}
     g_level, g_nodes = C.c_int(), C.c_int()
     L.hypre_amd_BoomerAMGGetGraphInfo(s, C.byref(g_level), C.byref(g_nodes))
     ms_per_step = 1e3 * elapsed / args.steps
@@ -458,6 +491,22 @@ def main():
             b1, u1 = B.parvec_from_numpy(np.ones(n_cpu)), B.parvec_from_numpy(np.zeros(n_cpu))
             L.HYPRE_BoomerAMGSetTol(s1, 0.0)
             L.HYPRE_BoomerAMGSetMaxIter(s1, 1)
+        if world > 1:
+            # the same per-GPU block as ONE rank's job: what a cycle costs without any exchange (the other ranks wait)
+            def step1():
+                L.hypre_ParVectorSetZeros(u1)
+                L.HYPRE_BoomerAMGSolve(s1, A1, b1, u1)
+            for _ in range(warm):
+                step1()
+            L.hypre_SyncComputeStream()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step1()
+            L.hypre_SyncComputeStream()
+            single_rank_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+            if overlap is not None:
+                overlap["single_rank_ms_per_step_same_block"] = single_rank_ms
+                overlap["ms_per_step_minus_single_rank_ms"] = ms_per_step - single_rank_ms
         amg = O.amg_from_solvers([s1], mixed_precision=args.mixed)
         f = np.ones(n_cpu)
         ur = np.zeros(n_cpu)
@@ -528,7 +577,8 @@ def main():
                        "replicated_from_level": int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)),
                        "halo_exchanges_per_cycle": n_exch.value / args.steps, "allreduces_per_cycle": n_allr.value / args.steps,
                        "halo_bytes_sent_per_cycle": x_bytes.value / args.steps, "allreduce_bytes_per_cycle": r_bytes.value / args.steps,
-                       "exchanges_by_level": exchange_plan,
+                       "exchanges_by_level": exchange_plan, "overlap": overlap,
+                       "rccl_self_test": (None if world == 1 else ("passed" if transport == "rccl" else "not run (transport %s)" % transport)),
                        "coarse_tail_graph_from_level": g_level.value, "coarse_tail_graph_nodes": g_nodes.value,
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s, "setup_path": setup_path,

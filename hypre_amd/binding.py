@@ -162,6 +162,9 @@ PROTOTYPES = {
     "hypre_amd_CommSelfTest": (Int, [Int, Int]),
     "hypre_MPI_Barrier": (Int, [Int]),
     "hypre_amd_CommCounters": (Int, [BigIntP, BigIntP, Int]),
+    "hypre_amd_CommSetTiming": (Int, [Int]),
+    "hypre_amd_CommSetTag": (Int, [Int]),
+    "hypre_amd_CommExposedTimes": (Int, [Int, IntP, IntP, RealP, RealP, RealP]),
     "hypre_amd_CommBytes": (Int, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "hypre_amd_ParCSRMatrixHaloInfo": (Int, [ParCSRp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     # seq_mv

@@ -568,6 +568,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    while (not_finished)
    {
       const int n = A[level]->diag->num_rows;
+      hypre_amd_CommSetTag(level);             // (diagnosis: exchanges from here on belong to this level)
       // the tail: replay, or record on the second visit
       bool replayed = false;
       if (gl >= 0 && level == gl && arrived_down)
@@ -843,6 +844,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    d->cycle_op_count = cycle_op_count;
    (void) ztemp;
    handle().fp32_values = saved_fp32;
+   hypre_amd_CommSetTag(-1);
    handle().gs_threads = saved_gs_threads;
    handle().sync_compute = saved_sync;
    maybe_sync();

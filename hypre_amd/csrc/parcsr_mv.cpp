@@ -17,6 +17,7 @@
 //   compute stream : wait ev_halo ; y += alpha*offd*x_ghost
 #include "internal.hpp"
 #include <algorithm>
+#include <omp.h>
 
 using namespace hamd;
 
@@ -68,10 +69,30 @@ namespace {
 // flight owns a pair (handed out round-robin from a pool deep enough for the few a cycle can have open at once,
 // and remembered in its hypre_ParCSRCommHandle): `pack` is recorded on the compute stream when the send buffer is
 // ready, `halo` on the communication stream when the transfers have been enqueued.
-struct EventPair { hipEvent_t pack = nullptr, halo = nullptr; };
+struct EventPair
+{
+   hipEvent_t pack = nullptr, halo = nullptr;
+   // diagnosis (hypre_amd_CommSetTiming): `ready` is recorded on the compute stream where it is about to wait for `halo` —
+   // what lies between the two is the time the exchange was NOT hidden behind the interior work
+   hipEvent_t ready = nullptr;
+   int tag = -1, reduce = 0;
+   double host_us = 0.0;        // wall-clock time the HOST spent inside the transport's call (RCCL: an enqueue; a host-staged
+                                // transport: the whole transfer, during which it enqueues nothing else)
+};
 constexpr int EVENT_POOL = 16;
+// Diagnosis mode: every exchange (and device all-reduce) gets timing events of its own, kept until they are read out.
+int g_comm_timing = 0, g_comm_tag = -1;
+std::vector<EventPair *> g_timed;
 EventPair *next_event_pair()
 {
+   if (g_comm_timing)
+   {
+      EventPair *e = new EventPair();
+      HIP_CHECK(hipEventCreate(&e->pack)); HIP_CHECK(hipEventCreate(&e->halo)); HIP_CHECK(hipEventCreate(&e->ready));
+      e->tag = g_comm_tag;
+      g_timed.push_back(e);
+      return e;
+   }
    static EventPair pool[EVENT_POOL];
    static int next = 0;
    EventPair *e = &pool[next];
@@ -85,6 +106,53 @@ EventPair *next_event_pair()
 }
 
 }  // namespace
+
+// Diagnosis of the overlap (bench.py --gpus N): with timing on, every device-buffer exchange and device all-reduce from now
+// on carries timing events — buffer packed (compute stream), transfers done (communication stream), compute stream about
+// to wait for them — tagged with the AMG level the cycle is on (hypre_amd_CommSetTag; -1 outside a cycle).
+extern "C" HYPRE_Int hypre_amd_CommSetTiming(HYPRE_Int on)
+{
+   g_comm_timing = on != 0;
+   return hypre_error_flag;
+}
+extern "C" HYPRE_Int hypre_amd_CommSetTag(HYPRE_Int tag)
+{
+   g_comm_tag = tag;
+   return hypre_error_flag;
+}
+// Reads out and forgets the timed exchanges since the last call: per tag t in [0, max_tags) (tag -1 and tags beyond go to
+// the last slot) the number of exchanges, of all-reduces, the EXPOSED time — compute stream waiting at the halo event: the
+// part of the transfer that the interior product / sweep did not hide — and the whole time from "send buffer packed" to
+// "transfers done", and the wall-clock time the host spent inside the transport's calls (an enqueue for RCCL; the whole
+// transfer for a host-staged transport, which enqueues nothing meanwhile), in microseconds.  Synchronises both streams.
+extern "C" HYPRE_Int hypre_amd_CommExposedTimes(HYPRE_Int max_tags, HYPRE_Int *exchanges, HYPRE_Int *allreduces, HYPRE_Real *exposed_us,
+                                                HYPRE_Real *transfer_us, HYPRE_Real *host_us)
+{
+   Handle &hd = handle();
+   if (hd.compute_stream) { HIP_CHECK(hipStreamSynchronize(hd.compute_stream)); }
+   if (hd.comm_stream) { HIP_CHECK(hipStreamSynchronize(hd.comm_stream)); }
+   for (HYPRE_Int t = 0; t < max_tags; t++) { exchanges[t] = 0; allreduces[t] = 0; exposed_us[t] = 0.0; transfer_us[t] = 0.0; if (host_us) { host_us[t] = 0.0; } }
+   for (EventPair *e : g_timed)
+   {
+      const int t = (e->tag >= 0 && e->tag < max_tags - 1) ? e->tag : max_tags - 1;
+      float gap = 0.f, whole = 0.f;
+      const bool have_ready = hipEventQuery(e->ready) == hipSuccess;     // (an exchange whose handle was never destroyed has none)
+      (void) hipGetLastError();
+      if (max_tags > 0)
+      {
+         if (have_ready && hipEventElapsedTime(&gap, e->ready, e->halo) != hipSuccess) { (void) hipGetLastError(); gap = 0.f; }
+         if (hipEventElapsedTime(&whole, e->pack, e->halo) != hipSuccess) { (void) hipGetLastError(); whole = 0.f; }
+         if (e->reduce) { allreduces[t]++; } else { exchanges[t]++; }
+         exposed_us[t] += 1e3 * (gap > 0.f ? gap : 0.f);
+         transfer_us[t] += 1e3 * (whole > 0.f ? whole : 0.f);
+         if (host_us) { host_us[t] += e->host_us; }
+      }
+      HIP_CHECK(hipEventDestroy(e->pack)); HIP_CHECK(hipEventDestroy(e->halo)); HIP_CHECK(hipEventDestroy(e->ready));
+      delete e;
+   }
+   g_timed.clear();
+   return hypre_error_flag;
+}
 
 namespace hamd {
 // In-place sum over the ranks of `comm` of n doubles in DEVICE memory, ordered behind the work already queued on the
@@ -103,8 +171,11 @@ void dev_allreduce_sum(MPI_Comm comm, double *d_buf, int n)
       EventPair *ev = next_event_pair();
       HIP_CHECK(hipEventRecord(ev->pack, hd.compute_stream));
       HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, ev->pack, 0));
+      const double t_host = ev->ready ? omp_get_wtime() : 0.0;
       o->allreduce_sum(o->ctx, d_buf, n, 1, (void *) hd.comm_stream);
+      if (ev->ready) { ev->host_us = 1e6 * (omp_get_wtime() - t_host); }
       HIP_CHECK(hipEventRecord(ev->halo, hd.comm_stream));
+      if (ev->ready) { ev->reduce = 1; HIP_CHECK(hipEventRecord(ev->ready, hd.compute_stream)); }
       HIP_CHECK(hipStreamWaitEvent(hd.compute_stream, ev->halo, 0));
    }
    else
@@ -627,8 +698,10 @@ hypre_ParCSRCommHandle *hypre_ParCSRCommHandleCreate_v2(HYPRE_Int job, hypre_Par
       Handle &hd = handle();
       HIP_CHECK(hipEventRecord(ev->pack, hd.compute_stream));
       HIP_CHECK(hipStreamWaitEvent(hd.comm_stream, ev->pack, 0));
+      const double t_host = ev->ready ? omp_get_wtime() : 0.0;
       o->exchange(o->ctx, ns, sprocs, sb.data(), sbytes.data(), nr, rprocs, rb.data(), rbytes.data(), 1,
                   (void *) hd.comm_stream);
+      if (ev->ready) { ev->host_us = 1e6 * (omp_get_wtime() - t_host); }
       HIP_CHECK(hipEventRecord(ev->halo, hd.comm_stream));
       h->num_requests = 1;   // marks "device exchange in flight"
       h->requests = ev;      // ... and the event pair that belongs to it
@@ -655,7 +728,9 @@ HYPRE_Int hypre_ParCSRCommHandleDestroy(hypre_ParCSRCommHandle *h)
    if (!h) { return hypre_error_flag; }
    if (h->num_requests && h->requests)
    {
-      HIP_CHECK(hipStreamWaitEvent(handle().compute_stream, ((EventPair *) h->requests)->halo, 0));
+      EventPair *ev = (EventPair *) h->requests;
+      if (ev->ready) { HIP_CHECK(hipEventRecord(ev->ready, handle().compute_stream)); }     // (diagnosis: the compute stream is here, the halo may not be)
+      HIP_CHECK(hipStreamWaitEvent(handle().compute_stream, ev->halo, 0));
    }
    free(h);
    return hypre_error_flag;

@@ -1403,23 +1403,26 @@ void spmv_rs_kernel(SpmvArgs p, const int *__restrict__ rs_desc, const int *__re
                                                 // REGISTER, and the constants 1 ... KP - 1 would then live in 31 VGPRs)
    const char *xb = reinterpret_cast<const char *>(xs);
    double sum = 0.0;
+   // (two at a time where the registers are tight: the sweeps' three row operands on top of 32 entries a lane would cost the
+   // fifth wave per SIMD)
+   constexpr int FG = (KP >= 32 && !F32 && OP != OP_AXPBY) ? 2 : 4;
 #pragma unroll
-   for (int g = 0; g < KP / 4; g++)
+   for (int g = 0; g < KP / FG; g++)
    {
-      if (4 * g < nch)
+      if (FG * g < nch)
       {
-         double xv[4];
+         double xv[FG];
 #pragma unroll
-         for (int j = 0; j < 4; j++)
+         for (int j = 0; j < FG; j++)
          {
-            const int c = 4 * g + j;
+            const int c = FG * g + j;
             const unsigned pos = (c & 1) ? (iw[c >> 1] >> 16) : (iw[c >> 1] & 0xffffu);
             xv[j] = *reinterpret_cast<const double *>(xb + pos);
          }
 #pragma unroll
-         for (int j = 0; j < 4; j++)
+         for (int j = 0; j < FG; j++)
          {
-            const int c = 4 * g + j;
+            const int c = FG * g + j;
             const double a = F32 ? (double) vf[c] : vv[c];
             const double t = __fma_rn(a, xv[j], sum);
             sum = (c < cnt) ? t : sum;
@@ -1502,6 +1505,11 @@ bool device_build_row_slices(SpmvPlan *p, const hypre_CSRMatrix *A, hipStream_t 
    if (n < 1 || nnz < 1 || K < 1) { return false; }
    static const int force_w = [] { const char *e = getenv("HYPRE_AMD_SPMV_RS_W"); return e ? atoi(e) : 0; }();
    const double mean = (double) nnz / (double) n;
+   // Rows of a dozen entries or fewer stay with the tiles (hypre_amd_SpmvSetRowSlices(2) takes them too): there a lane of the
+   // tiled kernel sums a row by itself as well, and its stream is on its way before the tile's scalars are back, whereas a
+   // block's slices are found through its wave headers — measured on the fine-level restriction operator of the benchmark
+   // hierarchy (11.7 entries a row): 0.147 ms from tiles, 0.18 - 0.21 ms from slices.
+   if (mean < 13.0 && force_w <= 0 && spmv_row_slices() < 2) { return false; }
    // lanes per row: a lane holds at most 32 entries; a block's entries are what the staging builder sorts (8192 at most:
    // a mean of 6144 or less); the more rows a block holds the more of the x it stages is shared between them
    int W = 1;

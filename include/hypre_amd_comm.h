@@ -82,6 +82,20 @@ HYPRE_Int hypre_amd_CommSelfTest(MPI_Comm comm, HYPRE_Int nbytes);
 
 /* neighbour exchanges and all-reduces this process has started since the last reset (benchmark reporting) */
 HYPRE_Int hypre_amd_CommCounters(HYPRE_BigInt *exchanges, HYPRE_BigInt *allreduces, HYPRE_Int reset);
+/* Diagnosis of the overlap of halo exchanges with interior work (the reference overlaps them by hand per product,
+ * parcsr_mv/par_csr_matvec_device.c:218-256).  With timing on, every device-buffer exchange and device all-reduce started
+ * from now on carries timing events of its own — send buffer packed (compute stream), transfers done (communication
+ * stream), compute stream about to wait for the transfers — tagged with hypre_amd_CommSetTag's value (the AMG cycle sets
+ * the level it is on; -1 outside a cycle).  hypre_amd_CommExposedTimes synchronises both streams, reads the exchanges since
+ * the last call out and forgets them: per tag t < max_tags (others in the last slot) the number of exchanges and of
+ * all-reduces, the EXPOSED time (compute stream waiting at the halo event: what the interior product or sweep did not
+ * hide), the whole time from "buffer packed" to "transfers done", and (host_us, may be NULL) the wall-clock time the host
+ * spent inside the transport's calls — an enqueue for RCCL, the whole transfer for a host-staged transport, during which it
+ * enqueues nothing else, so that the compute stream runs dry without ever waiting at an event —, in microseconds. */
+HYPRE_Int hypre_amd_CommSetTiming(HYPRE_Int on);
+HYPRE_Int hypre_amd_CommSetTag(HYPRE_Int tag);
+HYPRE_Int hypre_amd_CommExposedTimes(HYPRE_Int max_tags, HYPRE_Int *exchanges, HYPRE_Int *allreduces, HYPRE_Real *exposed_us,
+                                     HYPRE_Real *transfer_us, HYPRE_Real *host_us);
 /* bytes this process sent in those exchanges / contributed to device all-reduces (cleared with the counters above) */
 HYPRE_Int hypre_amd_CommBytes(HYPRE_BigInt *exchange_bytes, HYPRE_BigInt *allreduce_bytes);
 

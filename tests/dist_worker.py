@@ -218,6 +218,9 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
         # ... and the package is back in single-vector shape
         L.hypre_ParCSRMatrixMatvec(2.0, A, dxt, 0.0, dy)
         B.check()
+        # the solve with timing events on every exchange (hypre_amd_CommSetTiming): how many there were per AMG level, how long
+        # the transfers took and how much of that the compute stream spent waiting (bench.py --gpus N reports these)
+        L.hypre_amd_CommSetTiming(1)
         if opt.solver == 0:
             L.HYPRE_BoomerAMGSolve(s, A, db, dx)
             its, rel = C.c_int(), C.c_double()
@@ -242,6 +245,15 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
             L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
         B.check()
+        MT = 32
+        t_ex, t_ar = (C.c_int * MT)(), (C.c_int * MT)()
+        t_eu, t_tu = (C.c_double * MT)(), (C.c_double * MT)()
+        t_hu = (C.c_double * MT)()
+        L.hypre_amd_CommExposedTimes(MT, t_ex, t_ar, t_eu, t_tu, t_hu)
+        L.hypre_amd_CommSetTiming(0)
+        B.check()
+        mine.update(timed=dict(exchanges=sum(t_ex), allreduces=sum(t_ar), in_cycle=sum(t_ex[:MT - 1]), exposed_us=sum(t_eu), transfer_us=sum(t_tu), host_us=sum(t_hu),
+                               worst=max((t_eu[k] - t_tu[k]) for k in range(MT))))
         mine.update(replicated_level=int(L.hypre_amd_BoomerAMGGetReplicatedLevel(s)), device_levels=int(device_levels))
         mine.update(dev_its=its.value, dev_rel=rel.value, dev_x=B.parvec_to_numpy(dx), xt=xt,
                     dev_y=B.parvec_to_numpy(dy), dev_z=B.parvec_to_numpy(dz), dev_dot=dot, zt_repeat=zt_repeat,
@@ -281,6 +293,7 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             zd = np.concatenate([p["dev_z"] for p in parts])
             xd = np.concatenate([p["dev_x"] for p in parts])
             out.update(replicated_level=parts[0]["replicated_level"], device_levels=min(p["device_levels"] for p in parts))
+            out.update(timed=parts[0]["timed"])
             # multivector products, column by column, against the oracle
             Xg = np.concatenate([p["mv_x"] for p in parts]); Yg = np.concatenate([p["mv_y"] for p in parts])
             Zg = np.concatenate([p["mv_z"] for p in parts])

@@ -63,6 +63,10 @@ def test_two_or_three_ranks_on_device(name):
     assert out["dev_iterations"] == out["iterations"]
     assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
     assert out["x_err"] < 1e-9
+    # the overlap diagnosis (hypre_amd_CommExposedTimes): the solve's exchanges were timed, level by level; what the compute
+    # stream waited for an exchange cannot exceed what the exchange took
+    t = out["timed"]
+    assert t["exchanges"] > 0 and t["in_cycle"] > 0 and t["transfer_us"] > 0.0 and t["exposed_us"] >= 0.0 and t["worst"] <= 50.0 and t["host_us"] > 0.0
     if "iterations" in exp:
         assert out["dev_iterations"] == exp["iterations"]
         assert abs(out["dev_rel_resid"] - exp["rel_resid"]) <= 5e-7 * exp["rel_resid"]

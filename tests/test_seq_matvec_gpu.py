@@ -755,14 +755,14 @@ def test_a_failed_plan_allocation_falls_back_one_form(gpu_lib, oracle, site, low
     lib.hypre_CSRMatrixDestroy(dA)
 
 
-@pytest.mark.parametrize("lo,hi,n,lanes", [(4, 12, 6000, 1), (13, 48, 5000, 2), (20, 40, 9000, 2), (49, 160, 3000, 8), (60, 90, 2500, 4),
-                                           (200, 900, 1500, 32), (0, 30, 4000, 1), (1, 3, 6000, 0), (33, 64, 2000, 4), (5, 8, 300, 1)])
+@pytest.mark.parametrize("lo,hi,n,lanes", [(4, 12, 6000, 0), (13, 48, 5000, 2), (20, 40, 9000, 2), (49, 160, 3000, 8), (60, 90, 2500, 4),
+                                           (200, 900, 1500, 32), (0, 30, 4000, 1), (1, 3, 6000, 0), (33, 64, 2000, 4), (10, 20, 300, 1)])
 def test_row_slice_form(gpu_lib, oracle, lo, hi, n, lanes):
     """An uncoded matrix that cannot change behind its plan is multiplied from jagged row slices (spmv_rs_kernel: 256 / W rows a
     workgroup, W lanes a row, a lane's entries summed in stored order from registers, the W partial sums of a row added in
     lane order): every epilogue of y = alpha A x + beta b against scipy within the tolerance of this file and against the
     tiled kernel's result; every width W = 1 ... 32 and every register form (8 ... 32 entries a lane); empty rows; rows too
-    short for the form to pay keep the tiles.  The form is for matrices the library owns (coarse levels) or the caller
+    short for the form to pay (a dozen entries or fewer on average) keep the tiles.  The form is for matrices the library owns (coarse levels) or the caller
     declared immutable: here hypre_amd_CSRMatrixSetImmutable."""
     import ctypes as C
     from hypre_amd import binding as B
@@ -832,6 +832,17 @@ def test_row_slices_of_every_matrix_and_their_fallbacks(gpu_lib, oracle):
             for o in (dx, dy, dz):
                 lib.hypre_SeqVectorDestroy(o)
             lib.hypre_CSRMatrixDestroy(dA)
+        # short rows: taken under mode 2 only (8 entries a lane, a lane a row)
+        Sh = banded_csr(5000, 5000, 4, 12, 300, seed=9)
+        dSh = B.csr_from_scipy(Sh)
+        xh, yh = B.vec_from_numpy(rand_vector(5000, 3)), B.vec_from_numpy(np.zeros(5000))
+        lib.hypre_CSRMatrixMatvec(1.0, dSh, xh, 0.0, yh)
+        B.check()
+        assert lib.hypre_amd_CSRMatrixPlanForm(dSh) == 5 and lib.hypre_amd_CSRMatrixPlanRowSlices(dSh, None, None) == 1
+        assert np.all(np.abs(B.vec_to_numpy(yh) - Sh @ rand_vector(5000, 3)) <= _bound(Sh, rand_vector(5000, 3), 1.0, 0.0, rand_vector(5000, 3)))
+        for o in (xh, yh):
+            lib.hypre_SeqVectorDestroy(o)
+        lib.hypre_CSRMatrixDestroy(dSh)
         S = laplace_3d(16, 16, 16)
         dS = B.csr_from_scipy(S)
         xs_, ys_ = B.vec_from_numpy(rand_vector(4096, 3)), B.vec_from_numpy(np.zeros(4096))

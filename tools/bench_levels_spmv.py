@@ -44,4 +44,7 @@ for level in range(levels):
     lanes = L.hypre_amd_CSRMatrixPlanSliceForm(Al.contents.diag)
     if lanes:                                      # slice form: one workgroup per 256 / lanes rows
         nt.value = -(-nr // (256 // lanes))
+    rsr = C.c_int()
+    if L.hypre_amd_CSRMatrixPlanRowSlices(Al.contents.diag, C.byref(rsr), None):      # row slices: one workgroup per block of rows
+        nt.value = -(-nr // rsr.value)
     print("LEVEL %d rows %d nnz %d tiles %d bytes %d : %.4f ms  %.0f GB/s" % (level, nr, nnz, nt.value, by, ms, by / ms / 1e6), flush=True)

@@ -37,7 +37,7 @@ def level_of(grid_size, wg=256):
 kernel_rows = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"] or "spmv_sl_kernel" in r["Kernel_Name"]:
+        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"] or "spmv_sl_kernel" in r["Kernel_Name"] or "spmv_rs_kernel" in r["Kernel_Name"]:
             lv = level_of(int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]))
             if lv is not None:
                 kernel_rows[lv].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
@@ -51,7 +51,7 @@ for lv, v in kernel_rows.items():
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"] or "spmv_sl_kernel" in r["Kernel_Name"]:
+        if "spmv_tiled_kernel" in r["Kernel_Name"] or "spmv_xs_kernel" in r["Kernel_Name"] or "spmv_sl_kernel" in r["Kernel_Name"] or "spmv_rs_kernel" in r["Kernel_Name"]:
             lv = level_of(int(r["Grid_Size"]))
             if lv is not None:
                 agg[lv][r["Counter_Name"]].append(float(r["Counter_Value"]))

@@ -1,0 +1,18 @@
+# measurement pass of round 4: GPU tests, bench lines of the BASELINE configurations (default, codes off, row slices off), kernel
+# statistics of the C2 bench command, per-level tables
+set -x
+out=gpurun_out/${1:-r04_measure}
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; echo "tests exit $?"; tail -4 $out/tests.log
+timeout -k 10 300 python bench.py > $out/bench_c2.json 2> $out/bench_c2.err; echo "c2 exit $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/prof_c2 -o b --output-format csv -- python3 bench.py --no-cpu-baseline > $out/prof_c2.log 2>&1; echo "prof exit $?"
+HYPRE_AMD_SPMV_ROW_SLICES=0 timeout -k 10 300 python bench.py --no-cpu-baseline > $out/bench_c2_norowslices.json 2> $out/bench_c2_norowslices.err; echo "c2 nors exit $?"
+timeout -k 10 400 python bench.py --problem 27pt --relax 11 > $out/bench_c4.json 2> $out/bench_c4.err; echo "c4 exit $?"
+timeout -k 10 300 python bench.py --problem difconv --mixed > $out/bench_c5.json 2> $out/bench_c5.err; echo "c5 exit $?"
+timeout -k 10 300 python bench.py --relax 21 --relax-up 22 --cpu-cycles 1 > $out/bench_mc256.json 2> $out/bench_mc256.err; echo "mc256 exit $?"
+timeout -k 10 300 python tools/bench_levels.py 256 20 --variants 2 --json $out/levels_7pt.json > $out/levels_7pt.log 2>&1; echo "levels 7pt exit $?"
+timeout -k 10 300 python tools/bench_levels.py 256 20 --variants 2 --problem 27pt --relax 11 --json $out/levels_27pt.json > $out/levels_27pt.log 2>&1; echo "levels 27pt exit $?"
+HYPRE_AMD_SETUP_TIMING=1 timeout -k 10 300 python tools/setup_time.py 256 device 3 > $out/setup_device.log 2>&1; echo "setup exit $?"
+grep "V-cycle\|v2:0" $out/levels_7pt.log | head -12
+ls $out
