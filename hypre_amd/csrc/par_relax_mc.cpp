@@ -145,7 +145,9 @@ McPlan *get_mc(hypre_CSRMatrix *A)
          M->data = m->d_ca + slice0[(size_t) c];
          M->memory_location = HYPRE_MEMORY_DEVICE;
          M->owns_data = 0;
-         mark_owned(M);                    // a view into the library's own colour-sorted copy
+         // (a view into the library's own colour-sorted copy; not marked as owned: rows of one colour are not neighbours, they
+         // share no columns, and a block of them cannot stage its x — measured, also with the columns renumbered colour by
+         // colour: 7.4 ms per cycle at 256^3 against 6.9 ms — so no row slices are attempted for them)
          m->rows_of[(size_t) c] = M;
          if (M->num_rows > 0 && M->num_nonzeros > 0) { (void) get_plan(M); }    // the colour's SpMV plan: part of the setup
       }

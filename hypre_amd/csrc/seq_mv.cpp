@@ -688,6 +688,7 @@ extern "C" {
 hypre_CSRMatrix *hypre_CSRMatrixCreate(HYPRE_Int num_rows, HYPRE_Int num_cols, HYPRE_Int num_nonzeros)
 {
    hypre_CSRMatrix *m = (hypre_CSRMatrix *) calloc(1, sizeof(hypre_CSRMatrix));
+   mark_owned(m, false);              // (an address handed out again starts as nobody's)
    m->num_rows = num_rows;
    m->num_cols = num_cols;
    m->num_nonzeros = num_nonzeros;

@@ -12,6 +12,9 @@ that do not need a CPU run of the same size:
 * the hierarchy: 9 levels, grid complexity 1.354, operator complexity 2.767 (the reference's own
   run of this problem).
 
+* one V-cycle against the CPU oracle's on the same hierarchy (every level copied to the host, the oracle's row loops on the
+  host's cores): 1e-11 relative in the max norm — the full-size counterpart of the small-size cycle tests.
+
 The same hierarchies are compared entry by entry with the CPU oracle at sizes the oracle finishes in seconds
 (test_amg_gpu.py, test_bench_class_gpu.py), and bench.py compares one full-size cycle with the oracle on every run."""
 import ctypes as C
@@ -148,6 +151,23 @@ def _check_cycle_is_linear(p, f1, f2, tol, symmetric):
     assert np.linalg.norm(r) <= 0.5 * np.linalg.norm(f1)
 
 
+def _check_cycle_against_the_oracle(p, oracle, f, mixed=False):
+    """one V-cycle from a zero guess on the device against the CPU oracle's on the same hierarchy — every level copied to the
+    host, the oracle's row loops on the host's cores (the bits do not depend on the thread count): the full-size counterpart
+    of the small-size cycle tests, 1e-11 relative in the max norm"""
+    u = p.cycle(f)
+    amg = oracle.amg_from_solvers([p.s], mixed_precision=mixed)
+    import os
+    oracle.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    try:
+        ur = np.zeros(p.n)
+        amg.cycle(f, ur, u_all_zeros=True)
+    finally:
+        oracle.set_num_threads(1)
+        oracle.drop_transposes()
+    assert np.max(np.abs(u - ur)) <= 1e-11 * np.max(np.abs(ur)), np.max(np.abs(u - ur)) / np.max(np.abs(ur))
+
+
 def _levels_and_complexities(p):
     lib = p.lib
     nl = lib.hypre_amd_BoomerAMGGetNumLevels(p.s)
@@ -160,7 +180,7 @@ def _levels_and_complexities(p):
     return nl, rows / A0.num_rows, nnz / A0.num_nonzeros
 
 
-def test_c2_7pt_l1_jacobi_at_full_size(gpu_lib):
+def test_c2_7pt_l1_jacobi_at_full_size(gpu_lib, oracle):
     """Config C2: 256^3 7-point Laplacian, PMIS / ext+i(4) / l1-Jacobi V(1,1), set up on the device."""
     p = Problem(gpu_lib, relax_type=18)
     try:
@@ -169,6 +189,7 @@ def test_c2_7pt_l1_jacobi_at_full_size(gpu_lib):
         nl, gc, oc = _levels_and_complexities(p)
         assert nl == 9 and abs(gc - 1.354) < 2e-3 and abs(oc - 2.767) < 2e-3, (nl, gc, oc)
         _check_cycle_is_linear(p, x, y, 1e-12, symmetric=True)
+        _check_cycle_against_the_oracle(p, oracle, x)
         b = np.ones(p.n)
         sol, its, rel = p.pcg(b)
         assert its == 22 and rel <= 1e-8, (its, rel)
@@ -178,7 +199,7 @@ def test_c2_7pt_l1_jacobi_at_full_size(gpu_lib):
         p.close()
 
 
-def test_c4_27pt_two_stage_gs_at_full_size(gpu_lib):
+def test_c4_27pt_two_stage_gs_at_full_size(gpu_lib, oracle):
     """Config C4's per-GPU share: 256^3 27-point operator (453 M entries), two-stage Gauss-Seidel (relax 11), whose
     accumulating epilogue is the one that must see every tile exactly once."""
     p = Problem(gpu_lib, relax_type=11, problem="27pt")
@@ -186,6 +207,7 @@ def test_c4_27pt_two_stage_gs_at_full_size(gpu_lib):
         x, y = _check_operator(p, "27pt")
         p.setup()
         _check_cycle_is_linear(p, x, y, 1e-12, symmetric=False)       # forward sweeps down and up: not a symmetric cycle
+        _check_cycle_against_the_oracle(p, oracle, x)
         b = np.ones(p.n)
         sol, its, rel = p.pcg(b)
         assert its <= 20 and rel <= 1e-8, (its, rel)
@@ -195,7 +217,7 @@ def test_c4_27pt_two_stage_gs_at_full_size(gpu_lib):
         p.close()
 
 
-def test_c5_anisotropic_mixed_precision_at_full_size(gpu_lib):
+def test_c5_anisotropic_mixed_precision_at_full_size(gpu_lib, oracle):
     """Config C5's per-GPU share: 256^3 anisotropic diffusion (1, 1, 0.001), matrix values streamed as fp32 inside the
     cycle, residuals and corrections in fp64: the cycle is still linear (to fp64 accuracy: rounding the matrix once does
     not depend on the right-hand side), and PCG reaches 1e-8 on the TRUE (fp64) residual."""
@@ -206,6 +228,7 @@ def test_c5_anisotropic_mixed_precision_at_full_size(gpu_lib):
         assert abs(np.dot(x, Ay) - np.dot(y, Ax)) <= 1e-13 * np.linalg.norm(x) * np.linalg.norm(Ay)
         p.setup(mixed=True)
         _check_cycle_is_linear(p, x, y, 1e-12, symmetric=True)
+        _check_cycle_against_the_oracle(p, oracle, x, mixed=True)
         b = np.ones(p.n)
         sol, its, rel = p.pcg(b)
         assert its <= 20 and rel <= 1e-8, (its, rel)
