@@ -101,7 +101,12 @@ for l in range(min(nl, args.levels)):
             stt = L.hypre_amd_CSRMatrixPlanStaging(Pq.contents.diagT, C.byref(nt), C.byref(mp))
             line += " | P^T: tiles %d, x-staged %d (%.1f pieces)" % (nt.value, stt, mp.value)
         print(line, flush=True)
-    lev = {"level": l, "rows": nr, "nnz": nnz, "tiles": nt.value, "x_staged_tiles": st, "ops": {}}
+    rs_rows, rs_kp = C.c_int(), C.c_int()
+    rs_w = L.hypre_amd_CSRMatrixPlanRowSlices(Al.contents.diag, C.byref(rs_rows), C.byref(rs_kp))
+    form = L.hypre_amd_CSRMatrixPlanForm(Al.contents.diag)
+    print("   A: plan form %d%s" % (form, ("  (row slices: %d lanes a row, %d rows a block, %d entries a lane at most)" % (rs_w, rs_rows.value, rs_kp.value)) if rs_w else ""), flush=True)
+    lev = {"level": l, "rows": nr, "nnz": nnz, "tiles": nt.value, "x_staged_tiles": st, "plan_form": form, "row_slice_lanes": rs_w,
+           "row_slice_rows": rs_rows.value, "row_slice_entries_per_lane": rs_kp.value, "ops": {}}
     table["levels"].append(lev)
 
     def rec(name, var, wgs, ms, by):
