@@ -249,7 +249,8 @@ enum SpmvOp
    OP_JACOBI  = 1,  // y = x + w*(b - A x)./d          (b=f, d=l1 or diag vector)
    OP_JACOBI_CF = 2, // same, rows with marker!=pts copy x
    OP_TSGS    = 3,  // y = (A_fill x)./d ; aux += alpha*y   (two-stage GS inner step)
-   OP_JACOBI_MAP = 4 // OP_JACOBI on the rows rowmap[] names (marker optional): sweeps over one colour's rows
+   OP_JACOBI_MAP = 4, // OP_JACOBI on the rows rowmap[] names (marker optional): sweeps over one colour's rows
+   OP_AXPBY_DIV = 5  // OP_AXPBY and aux = (scale2 * y) ./ d: the restriction that also starts the coarse level's sweep from zero
 };
 
 struct SpmvArgs
@@ -270,6 +271,7 @@ struct SpmvArgs
    const HYPRE_Int     *marker;   // CF marker or null
    int                  marker_val;
    HYPRE_Complex        alpha, beta;
+   HYPRE_Complex        scale2;   // OP_AXPBY_DIV: aux[row] = (scale2 * y[row]) / d[row] as well
    int                  fill;     // HYPRE_SPMV_FILL_*
    int                  row_offset;
    int                  last_quad;   // (nnz - 1) & ~3: last 16-byte quad of the (col, val) arrays holding an entry
@@ -290,6 +292,9 @@ struct SpmvArgs
 void spmv_default_flags(SpmvArgs &a);   // fills gather_t / xcd_map from the tuning knobs
 
 void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStream_t s);
+// y = M x and, in the same pass, u = (w y) ./ d  (seq_mv.cpp): the restriction f_c = P^T r fused with the zero-guess Jacobi
+// sweep u_c = w f_c ./ d_c that follows it on the coarse level; false: not served (empty matrix), nothing was launched
+bool spmv_with_scaled_quotient(hypre_CSRMatrix *M, const double *x, double *y, double w, const double *d, double *u);
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);
 void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s);
 // value codes of a matrix (nullptr / 0 when it holds more than 256 distinct values): codes[nnz], the sorted table, its fp32-rounded twin

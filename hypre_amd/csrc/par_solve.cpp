@@ -452,6 +452,12 @@ int run_replicated_tail(hypre_ParAMGData *d, AmgPrivate *pv, const double *f_loc
    return err;
 }
 
+// fusions across the cycle's steps (hypre_amd_SetCycleFusion; HYPRE_AMD_CYCLE_FUSION=0): same results, fewer passes
+int &cycle_fusion()
+{
+   static int on = [] { const char *e = getenv("HYPRE_AMD_CYCLE_FUSION"); return e ? atoi(e) : 1; }();
+   return on;
+}
 // everything the launches of the sub-cycle below level gl depend on
 unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, hypre_ParVector **F, hypre_ParVector **U)
 {
@@ -480,6 +486,7 @@ unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, h
       mix((unsigned long long) (uintptr_t) (l < (int) pv->diag_buf.size() ? pv->diag_buf[(size_t) l] : nullptr));
    }
    mix(plan_generation());            // a plan dropped or rebuilt anywhere (the recorded kernels point into plans' tables)
+   mix((unsigned long long) cycle_fusion());     // (the recorded tail leaves out what a fused restriction into it did)
    SpmvArgs a{};
    spmv_default_flags(a);
    mix((unsigned long long) a.variant); mix((unsigned long long) a.gather_t); mix((unsigned long long) a.xcd_map);
@@ -490,6 +497,14 @@ bool is_jacobi_type(int t) { return t == 0 || t == 7 || t == 18; }
 bool is_ge_type(int t) { return t == 9 || t == 19 || t == 98 || t == 99 || t == 198 || t == 199; }
 
 }  // namespace
+
+// Fusions across the steps of a cycle from now on (default 1): the restriction also writes the coarse level's first sweep
+// from zero.  Same bits either way; a switch for comparisons.  on < 0: unchanged; returns the setting.
+HYPRE_Int hypre_amd_SetCycleFusion(HYPRE_Int on)
+{
+   if (on >= 0) { cycle_fusion() = on != 0; }
+   return cycle_fusion();
+}
 
 HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre_ParVector **U_array)
 {
@@ -525,6 +540,8 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       lv[(size_t) l].cur = lv[(size_t) l].home;
    }
    std::vector<int> lev_counter((size_t) L, 0), zeros((size_t) L, 0);
+   // presmoothed[l]: the restriction into level l also wrote the result of the level's first sweep from zero, u = (w f) ./ d
+   std::vector<int> presmoothed((size_t) L, 0);
    zeros[0] = U_array[0]->all_zeros;
    lev_counter[0] = 1;
    for (int k = 1; k < L; k++) { lev_counter[(size_t) k] = d->fcycle ? 1 : d->cycle_type; }
@@ -651,7 +668,8 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
             {
                if (zeros[(size_t) level] && relax_type != 0)
                {
-                  launch_scaled_div(w, fd, dg, u.cur, pts[pss] ? cf : nullptr, pts[pss], (size_t) n, s);
+                  if (presmoothed[(size_t) level]) { presmoothed[(size_t) level] = 0; }       // the restriction's epilogue did it
+                  else { launch_scaled_div(w, fd, dg, u.cur, pts[pss] ? cf : nullptr, pts[pss], (size_t) n, s); }
                }
                else
                {
@@ -763,7 +781,21 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
          if (!overwrites_all) { launch_set(uc.cur, 0.0, (size_t) nc, s); }
          zeros[(size_t) coarse] = 1;
          dev_par_matvec(-1.0, A[fine], u.cur, 1.0, fd, vtemp);
-         dev_par_matvecT(1.0, P[fine], vtemp, 0.0, F_array[coarse]->local_vector->data);
+         // One rank, the coarse level starts with a Jacobi-type sweep from zero over all its points (u_c = w f_c ./ d_c, its
+         // smoother diagonal at hand): the restriction's epilogue writes that as well — f_c is in its registers — instead of a
+         // kernel of its own reading f_c and d_c again (one launch and 8 bytes per coarse row less on every level below the
+         // finest; same bits: (w f) / d either way).  Several ranks add the neighbours' contributions to f_c afterwards: not there.
+         const int fuse_on = cycle_fusion();
+         presmoothed[(size_t) coarse] = 0;
+         bool restricted = false;
+         if (fuse_on && cycle_nprocs == 1 && overwrites_all && is_jacobi_type(ctype) && d->l1_norms[coarse] && d->l1_norms[coarse]->data &&
+             P[fine]->diagT && P[fine]->diagT->memory_location == HYPRE_MEMORY_DEVICE && P[fine]->offd->num_cols == 0)
+         {
+            restricted = spmv_with_scaled_quotient(P[fine]->diagT, vtemp, F_array[coarse]->local_vector->data, d->relax_weight[coarse],
+                                                   d->l1_norms[coarse]->data, uc.cur);
+            if (restricted) { presmoothed[(size_t) coarse] = 1; F_array[coarse]->all_zeros = 0; }
+         }
+         if (!restricted) { dev_par_matvecT(1.0, P[fine], vtemp, 0.0, F_array[coarse]->local_vector->data); }
          ++level;
          lev_counter[(size_t) level] = std::max(lev_counter[(size_t) level], (int) d->cycle_type);
          cycle_param = (level == L - 1) ? 3 : 1;

@@ -504,6 +504,17 @@ hypre_CSRMatrix *strict_lower_of(hypre_CSRMatrix *A)
    return L;
 }
 
+bool spmv_with_scaled_quotient(hypre_CSRMatrix *M, const double *x, double *y, double w, const double *d, double *u)
+{
+   if (!M || M->num_rows <= 0 || M->num_nonzeros <= 0 || !d || !u || M->memory_location != HYPRE_MEMORY_DEVICE) { return false; }
+   SpmvArgs a{};
+   a.Ai = M->i; a.Aj = M->j; a.Aa = M->data; a.Aa32 = nullptr;
+   a.x = x; a.b = nullptr; a.y = y; a.d = d; a.aux = u; a.marker = nullptr; a.marker_val = 0;
+   a.alpha = 1.0; a.beta = 0.0; a.scale2 = w; a.fill = HYPRE_SPMV_FILL_WHOLE; a.row_offset = 0;
+   spmv_default_flags(a);
+   launch_spmv(get_plan(M), a, OP_AXPBY_DIV, stream());
+   return true;
+}
 }  // namespace hamd
 
 // Band-aware tile placement policy of the plans built from now on (existing plans keep theirs): enabled 0/1,

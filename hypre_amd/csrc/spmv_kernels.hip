@@ -78,6 +78,7 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
    if (OP == OP_JACOBI_MAP) { row = p.rowmap[row]; }
    o.g = row;
    if (OP == OP_AXPBY) { if (p.beta != 0.0) { o.b = p.b[row]; } }
+   else if (OP == OP_AXPBY_DIV) { if (p.beta != 0.0) { o.b = p.b[row]; } o.d = p.d[row]; }
    else if (OP == OP_TSGS) { o.d = p.d[row]; o.x = p.aux[row]; }      // aux: read here, with the other operands, not in the epilogue
    else
    {
@@ -92,12 +93,15 @@ template <int OP>
 __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum, const RowOps &o)
 {
    const int row = o.g;
-   if (OP == OP_AXPBY)
+   if (OP == OP_AXPBY || OP == OP_AXPBY_DIV)
    {
       // y = alpha*(A x) + beta*b   (roundings spelled out: every kernel of the family gives the same bits for the same row sum)
       double r = __dmul_rn(p.alpha, sum);
       if (p.beta != 0.0) { r = __fma_rn(p.beta, o.b, r); }
       p.y[row] = r;
+      // the restriction that also starts the coarse level's sweep from zero: u = (w f) ./ d, as scaled_div_kernel rounds it
+      // (an operation of its own: its operand costs the plain product of the x-staged kernel its eighth wave per SIMD)
+      if (OP == OP_AXPBY_DIV) { p.aux[row] = __dmul_rn(p.scale2, r) / o.d; }
    }
    else if (OP == OP_TSGS)
    {
@@ -2099,6 +2103,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       switch (op)
       {
          case OP_AXPBY:      rowb = 8.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;              // y (+ b)
+         case OP_AXPBY_DIV:  rowb = 24.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;             // y, d read, u written (+ b)
          case OP_JACOBI:     rowb = 24.0; break;                                              // f, d, u'   (u is the x gather)
          case OP_JACOBI_CF:  rowb = 28.0; break;                                              // + marker
          case OP_JACOBI_MAP: rowb = 28.0 + (a.marker ? 4.0 : 0.0); break;                     // + row map
@@ -2129,6 +2134,7 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    switch (op)
    {
       case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, a, s); break;
+      case OP_AXPBY_DIV: launch_spmv_op<OP_AXPBY_DIV>(plan, a, s); break;
       case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, a, s); break;
       case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, a, s); break;
       case OP_JACOBI_MAP: launch_spmv_op<OP_JACOBI_MAP>(plan, a, s); break;

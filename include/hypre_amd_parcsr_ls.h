@@ -288,6 +288,11 @@ HYPRE_Int hypre_amd_BoomerAMGGetGraphInfo(HYPRE_Solver solver, HYPRE_Int *level,
  * fp64 residual equation from a non-zero iterate.  The reference has only the whole-library HYPRE_SINGLE
  * (utilities/HYPRE_utilities.h:78-89). */
 HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on);
+/* Fusions across the steps of a cycle (default on; environment HYPRE_AMD_CYCLE_FUSION=0): on one rank the restriction
+ * f_c = P^T r also writes the result of the coarse level's first Jacobi-type sweep from zero, u_c = (w f_c) ./ d_c, instead
+ * of a kernel of its own reading f_c and d_c again (par_cycle.c:340-420 runs the two as separate steps).  Same bits either
+ * way; the switch is for comparisons.  on < 0 leaves the setting; returns it. */
+HYPRE_Int hypre_amd_SetCycleFusion(HYPRE_Int on);
 /* grid / operator complexity of the last setup */
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
 /* Multi-rank device hierarchies: levels with at most `rows` global rows are gathered onto every rank at

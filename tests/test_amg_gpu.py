@@ -812,3 +812,44 @@ def test_a_new_setup_after_an_in_place_edit_works_on_the_new_values(gpu_lib, ora
     assert np.max(np.abs(u2 - ur2)) <= 1e-11 * np.max(np.abs(ur2))         # ... and the device cycle is the new matrix's
     lib.HYPRE_BoomerAMGDestroy(s)
     B.check()
+
+
+@pytest.mark.parametrize("kw", [dict(relax_type=18), dict(relax_type=7, relax_wt=0.8), dict(relax_type=18, cycle_type=2),
+                                dict(relax_type=18, mixed=True), dict(relax_type=18, relax_order=1), dict(relax_type=11)])
+def test_the_restriction_that_starts_the_coarse_sweep_changes_no_bit(gpu_lib, oracle, kw):
+    """On one rank the restriction f_c = P^T r also writes the coarse level's first Jacobi-type sweep from zero, u_c = (w f_c) ./ d_c
+    (hypre_amd_SetCycleFusion; an epilogue of the SpMV kernels instead of a kernel of its own).  The cycle is the same BIT FOR BIT
+    with the fusion on and off — eager, recorded as a graph and replayed, V- and W-cycles, fp32 matrix values; switching it
+    invalidates a recorded coarse tail (the recording leaves out what a fused restriction into it did); smoothers the fusion
+    does not apply to (CF-ordered sweeps, two-stage GS) are untouched — and it is the oracle's cycle."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    kw = dict(kw)
+    mixed = kw.pop("mixed", False)
+    opt, A, s = _setup(lib, n=(30, 29, 28), coarsen_type=8, **kw)
+    if mixed:
+        lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    n = 30 * 29 * 28
+    f = rand_vector(n, 5)
+    amg = oracle.amg_from_solvers([s], mixed_precision=mixed)
+    ur = np.zeros(n)
+    amg.solve(f, ur, tol=0.0, max_iter=1, u_all_zeros=True)
+    out = []
+    try:
+        for on in (1, 1, 1, 0, 0, 0, 1, 1):                # (three cycles each: eager, recorded, replayed)
+            assert lib.hypre_amd_SetCycleFusion(on) == on
+            du, df = B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(f)
+            lib.hypre_ParVectorSetZeros(du)
+            lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+            B.check()
+            out.append(B.parvec_to_numpy(du))
+            lib.hypre_ParVectorDestroy(du); lib.hypre_ParVectorDestroy(df)
+    finally:
+        lib.hypre_amd_SetCycleFusion(1)
+    for u in out:
+        assert np.array_equal(u.view(np.int64), out[0].view(np.int64))
+    assert np.max(np.abs(out[0] - ur)) <= 1e-11 * np.max(np.abs(ur))
+    lib.HYPRE_BoomerAMGDestroy(s)
+    B.check()

@@ -1,4 +1,4 @@
-"""A/B of the V(1,1) cycle with and without the row-slice form in ONE process on ONE box (the HBM-bound launches move by
+"""A/B of the V(1,1) cycle with and without the row-slice form (or the cycle's fusions: --toggle fusion) in ONE process on ONE box (the HBM-bound launches move by
 4-7 % from box to box and drift with the clocks inside a run: the two forms are measured alternately, four times each).
 
     python tools/ab_row_slices.py [n] [cycles] [--problem laplacian|27pt|difconv] [--relax 18]
@@ -20,6 +20,7 @@ ap.add_argument("cycles", type=int, nargs="?", default=30)
 ap.add_argument("--problem", default="laplacian")
 ap.add_argument("--relax", type=int, default=18)
 ap.add_argument("--codes", type=int, default=1)
+ap.add_argument("--toggle", default="rowslices", choices=["rowslices", "fusion"], help="what is switched between the two samples")
 args = ap.parse_args()
 L = B.load_library()
 n = args.n
@@ -32,7 +33,10 @@ u = B.parvec_from_numpy(np.zeros(n ** 3))
 res = {0: [], 1: []}
 for rep in range(4):
     for mode in (1, 0):
-        L.hypre_amd_SpmvSetRowSlices(mode)
+        if args.toggle == "rowslices":
+            L.hypre_amd_SpmvSetRowSlices(mode)
+        else:
+            L.hypre_amd_SetCycleFusion(mode)
         s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
         L.HYPRE_BoomerAMGSetup(s, A, None, None)
         B.check()
@@ -53,7 +57,7 @@ for rep in range(4):
         L.hypre_SetSyncCudaCompute(1)
         L.HYPRE_BoomerAMGDestroy(s)
         B.check()
-        print("rep %d row slices %d: %.4f ms per cycle" % (rep, mode, ms), flush=True)
+        print("rep %d %s %d: %.4f ms per cycle" % (rep, args.toggle, mode, ms), flush=True)
 for mode in (1, 0):
     v = sorted(res[mode])
-    print("row slices %s: median %.4f ms  (min %.4f, max %.4f)" % ("on " if mode else "off", (v[1] + v[2]) / 2, v[0], v[-1]))
+    print("%s %s: median %.4f ms  (min %.4f, max %.4f)" % (args.toggle, "on " if mode else "off", (v[1] + v[2]) / 2, v[0], v[-1]))
