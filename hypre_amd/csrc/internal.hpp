@@ -250,7 +250,9 @@ enum SpmvOp
    OP_JACOBI_CF = 2, // same, rows with marker!=pts copy x
    OP_TSGS    = 3,  // y = (A_fill x)./d ; aux += alpha*y   (two-stage GS inner step)
    OP_JACOBI_MAP = 4, // OP_JACOBI on the rows rowmap[] names (marker optional): sweeps over one colour's rows
-   OP_AXPBY_DIV = 5  // OP_AXPBY and aux = (scale2 * y) ./ d: the restriction that also starts the coarse level's sweep from zero
+   OP_AXPBY_DIV = 5, // OP_AXPBY and aux = (scale2 * y) ./ d: the restriction that also starts the coarse level's sweep from zero
+   OP_RESID_RD = 6,  // y = (alpha*(A x) + beta*b) .* (1 ./ d): the two-stage sweep's residual already scaled by the diagonal
+   OP_TSGS_FIRST = 7 // first inner step of the two-stage sweep: z' = (A_fill z) .* (1 ./ d) ; aux = (aux_or_0 + z) + alpha*z'  (beta != 0: aux is read)
 };
 
 struct SpmvArgs
@@ -327,6 +329,7 @@ void launch_elmdivpy(const double *x, const double *d, double *y, const int *mar
                      size_t n, hipStream_t s);
 void launch_scaled_div(double w, const double *f, const double *d, double *u, const int *marker,
                        int mval, size_t n, hipStream_t s);   // u = w*f./d (zero-guess Jacobi)
+void launch_scaled_recip(double w, const double *f, const double *d, double *z, size_t n, hipStream_t s);   // z = (w*f) .* (1 ./ d)
 void launch_diagscale2(const double *diag, const double *x, double beta, double *y, double *z,
                        int computeY, size_t n, hipStream_t s);
 void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipStream_t s);

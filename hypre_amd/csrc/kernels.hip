@@ -122,6 +122,16 @@ __global__ void scaled_div_kernel(double w, const double *__restrict__ f, const 
    }
 }
 
+// z = (w f) .* (1 ./ d): the start of a two-stage Gauss-Seidel sweep from a zero iterate (what scale_copy + diagscale2 give, in one pass)
+__global__ void scaled_recip_kernel(double w, const double *__restrict__ f, const double *__restrict__ d, double *__restrict__ z, size_t n)
+{
+   const size_t stride = (size_t) gridDim.x * blockDim.x;
+   for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+   {
+      z[i] = __dmul_rn(__dmul_rn(w, f[i]), 1.0 / d[i]);
+   }
+}
+
 // u_out = u_in + r./d on marked rows, u_out = u_in elsewhere (r may alias u_out)
 __global__ void jacobi_update_kernel(const double *__restrict__ u_in, const double *r, const double *__restrict__ d,
                                      const int *__restrict__ marker, int mval, double *u_out, size_t n)
@@ -446,6 +456,8 @@ void launch_elmdivpy(const double *x, const double *d, double *y, const int *mar
 { account_bytes((32.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(elmdivpy_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, d, y, marker, mval, n); }
 void launch_scaled_div(double w, const double *f, const double *d, double *u, const int *marker, int mval, size_t n, hipStream_t s)
 { account_bytes((24.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(scaled_div_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, u, marker, mval, n); }
+void launch_scaled_recip(double w, const double *f, const double *d, double *z, size_t n, hipStream_t s)
+{ account_bytes(24.0 * n); if (n) hipLaunchKernelGGL(scaled_recip_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, z, n); }
 void launch_diagscale2(const double *diag, const double *x, double beta, double *y, double *z, int computeY, size_t n, hipStream_t s)
 { account_bytes(40.0 * n); if (n) hipLaunchKernelGGL(diagscale2_kernel, dim3(lin_grid(n)), dim3(256), 0, s, diag, x, beta, y, z, computeY, n); }
 void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipStream_t s)

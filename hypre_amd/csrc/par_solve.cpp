@@ -169,6 +169,8 @@ static double *diag_scratch(size_t n)
    return buf;
 }
 
+namespace { int &cycle_fusion(); }     // (defined with the cycle below)
+
 extern "C" {
 
 // ===========================================================================
@@ -191,19 +193,65 @@ HYPRE_Int hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(hypre_ParCSRMatrix *A, h
    // u known to be zero (par_vector.h all_zeros; set by SetZeros and by the cycle on the way down):
    // A u = 0 exactly, so r = w f without touching the matrix.  The reference uses the flag this way
    // only in its Jacobi sweep (par_relax.c:1221-1228); the result here is the same bits either way.
-   if (u->all_zeros) { launch_scale_copy(relax_weight, f->local_vector->data, rd, (size_t) n, s); }
-   else { dev_par_matvec(-relax_weight, A, ud, relax_weight, f->local_vector->data, rd); }
-   launch_diagscale2(A_diag_diag, rd, 1.0, zd, ud, 1, (size_t) n, s);
+   HYPRE_Int nprocs = 1;
+   hypre_MPI_Comm_size(A->comm, &nprocs);
+   hypre_CSRMatrix *Lm = (n > 0 && diag->num_nonzeros > 0) ? strict_lower_of(diag) : nullptr;
+   // At least one inner step over a non-empty triangle (hypre_amd_SetCycleFusion): on one rank the sweep in two or three
+   // passes instead of four or five — stage 0 and the scaling of stage 1 in one kernel (z = (w f - w A u) .* (1 ./ D): an
+   // epilogue of the residual's pass; from a zero iterate one vector kernel), and the "u += z" of stage 1 folded into the
+   // first inner step's epilogue (u = (u + z) + mult z'): every rounding where it was, 24 - 32 bytes per row less.
+   // Several ranks: the residual needs the ghost block's part before it can be scaled, so it stays a pass of its own, the
+   // scaling a vector kernel (z = r .* (1 ./ D), without the "u += z"), and the first inner step — local by construction: the
+   // triangle of this rank's own diagonal block — folds the "u += z" in all the same.
+   const bool fused = cycle_fusion() && Lm && Lm->num_nonzeros > 0 && num_inner_iters >= 1;
+   const bool one_rank = nprocs == 1 && A->offd->num_nonzeros == 0;
+   const bool from_zero = u->all_zeros != 0;
+   if (fused)
+   {
+      if (from_zero) { launch_scaled_recip(relax_weight, f->local_vector->data, A_diag_diag, zd, (size_t) n, s); }
+      else if (!one_rank)
+      {
+         dev_par_matvec(-relax_weight, A, ud, relax_weight, f->local_vector->data, rd);
+         launch_scaled_recip(1.0, rd, A_diag_diag, zd, (size_t) n, s);           // (1.0 * r is r: the product with the reciprocal as before)
+      }
+      else
+      {
+         SpmvArgs a{};
+         a.Ai = diag->i; a.Aj = diag->j; a.Aa = diag->data; a.Aa32 = nullptr;
+         a.x = ud; a.b = f->local_vector->data; a.y = zd; a.aux = nullptr; a.d = A_diag_diag; a.marker = nullptr;
+         a.alpha = -relax_weight; a.beta = relax_weight; a.fill = HYPRE_SPMV_FILL_WHOLE;
+         spmv_default_flags(a);
+         launch_spmv(get_plan(diag), a, OP_RESID_RD, s);
+      }
+   }
+   else
+   {
+      if (from_zero) { launch_scale_copy(relax_weight, f->local_vector->data, rd, (size_t) n, s); }
+      else { dev_par_matvec(-relax_weight, A, ud, relax_weight, f->local_vector->data, rd); }
+      launch_diagscale2(A_diag_diag, rd, 1.0, zd, ud, 1, (size_t) n, s);
+   }
    double mult = -1.0;
    double *zin = zd, *zout = rd;
-   if (n > 0 && diag->num_nonzeros > 0)
+   if (Lm)
    {
       // the inner steps run on a cached copy of the strictly lower triangle (half the bytes of
       // masking the full matrix, which is what the reference's fill-mode SpMV does)
-      hypre_CSRMatrix *Lm = strict_lower_of(diag);
       SpmvPlan *plan = get_plan(Lm);
       for (int k = 0; k < num_inner_iters && Lm->num_nonzeros > 0; k++)
       {
+         if (fused && k == 0)
+         {
+            // z' = (L z)./D ; u = (u + z) + mult z'   (u is not read when it is known to be zero)
+            SpmvArgs a{};
+            a.Ai = Lm->i; a.Aj = Lm->j; a.Aa = Lm->data; a.Aa32 = nullptr;
+            a.x = zin; a.b = nullptr; a.y = zout; a.aux = ud; a.d = A_diag_diag; a.marker = nullptr;
+            a.alpha = mult; a.beta = from_zero ? 0.0 : 1.0; a.fill = HYPRE_SPMV_FILL_WHOLE;
+            spmv_default_flags(a);
+            launch_spmv(plan, a, OP_TSGS_FIRST, s);
+            std::swap(zin, zout);
+            mult *= -1.0;
+            continue;
+         }
          // 2+3) z_out = (L_strict z_in)./D ; u += mult * z_out   — one fused pass
          SpmvArgs a{};
          a.Ai = Lm->i; a.Aj = Lm->j; a.Aa = Lm->data; a.Aa32 = nullptr;

@@ -78,7 +78,8 @@ __device__ __forceinline__ RowOps load_row_ops(const SpmvArgs &p, int row)
    if (OP == OP_JACOBI_MAP) { row = p.rowmap[row]; }
    o.g = row;
    if (OP == OP_AXPBY) { if (p.beta != 0.0) { o.b = p.b[row]; } }
-   else if (OP == OP_AXPBY_DIV) { if (p.beta != 0.0) { o.b = p.b[row]; } o.d = p.d[row]; }
+   else if (OP == OP_AXPBY_DIV || OP == OP_RESID_RD) { if (p.beta != 0.0) { o.b = p.b[row]; } o.d = p.d[row]; }
+   else if (OP == OP_TSGS_FIRST) { o.d = p.d[row]; o.b = p.x[row]; if (p.beta != 0.0) { o.x = p.aux[row]; } }      // (x is z_in: its own row as well)
    else if (OP == OP_TSGS) { o.d = p.d[row]; o.x = p.aux[row]; }      // aux: read here, with the other operands, not in the epilogue
    else
    {
@@ -102,6 +103,22 @@ __device__ __forceinline__ void row_epilogue(const SpmvArgs &p, int, double sum,
       // the restriction that also starts the coarse level's sweep from zero: u = (w f) ./ d, as scaled_div_kernel rounds it
       // (an operation of its own: its operand costs the plain product of the x-staged kernel its eighth wave per SIMD)
       if (OP == OP_AXPBY_DIV) { p.aux[row] = __dmul_rn(p.scale2, r) / o.d; }
+   }
+   else if (OP == OP_RESID_RD)
+   {
+      // the two-stage sweep's first stage in one pass: z = (w f - w A u) .* (1 ./ D) — the residual's roundings (as OP_AXPBY
+      // forms it), then the product with the reciprocal as diagscale2_kernel forms it
+      double r = __dmul_rn(p.alpha, sum);
+      if (p.beta != 0.0) { r = __fma_rn(p.beta, o.b, r); }
+      p.y[row] = __dmul_rn(r, 1.0 / o.d);
+   }
+   else if (OP == OP_TSGS_FIRST)
+   {
+      // first inner step, with the "u += z" of the first stage folded in: z' = (L z) .* (1 ./ D) ; u = (u + z) + mult z'
+      // (u + z rounded first: what the separate pass stored; from a zero iterate o.x is 0)
+      const double z = __dmul_rn(sum, 1.0 / o.d);
+      p.y[row] = z;
+      p.aux[row] = __fma_rn(p.alpha, z, __dadd_rn(o.x, o.b));
    }
    else if (OP == OP_TSGS)
    {
@@ -2104,6 +2121,8 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       {
          case OP_AXPBY:      rowb = 8.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;              // y (+ b)
          case OP_AXPBY_DIV:  rowb = 24.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;             // y, d read, u written (+ b)
+         case OP_RESID_RD:   rowb = 16.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;             // d, z (+ f)
+         case OP_TSGS_FIRST: rowb = 32.0 + ((a.beta != 0.0) ? 8.0 : 0.0); break;             // d, z row, z' write, u write (+ u read)
          case OP_JACOBI:     rowb = 24.0; break;                                              // f, d, u'   (u is the x gather)
          case OP_JACOBI_CF:  rowb = 28.0; break;                                              // + marker
          case OP_JACOBI_MAP: rowb = 28.0 + (a.marker ? 4.0 : 0.0); break;                     // + row map
@@ -2135,6 +2154,8 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
    {
       case OP_AXPBY:     launch_spmv_op<OP_AXPBY>(plan, a, s); break;
       case OP_AXPBY_DIV: launch_spmv_op<OP_AXPBY_DIV>(plan, a, s); break;
+      case OP_RESID_RD:  launch_spmv_op<OP_RESID_RD>(plan, a, s); break;
+      case OP_TSGS_FIRST: launch_spmv_op<OP_TSGS_FIRST>(plan, a, s); break;
       case OP_JACOBI:    launch_spmv_op<OP_JACOBI>(plan, a, s); break;
       case OP_JACOBI_CF: launch_spmv_op<OP_JACOBI_CF>(plan, a, s); break;
       case OP_JACOBI_MAP: launch_spmv_op<OP_JACOBI_MAP>(plan, a, s); break;

@@ -98,6 +98,23 @@ def test_two_stage_gs_tends_to_the_gauss_seidel_sweep(gpu_lib, level):
         lib.hypre_BoomerAMGRelax(A, df, None, relax_type, 0, 1.0, 1.0, l1, db, dv, dw)
         B.check()
         assert np.array_equal(B.parvec_to_numpy(da), B.parvec_to_numpy(db))
+    # the sweep in two or three passes (hypre_amd_SetCycleFusion: residual already scaled by the diagonal, "u += z" folded into
+    # the first inner step) is the sweep in four or five, bit for bit — from a non-zero and from a zero iterate
+    try:
+        for k in (1, 2, 3):
+            for zero in (False, True):
+                res = []
+                for on in (1, 0):
+                    lib.hypre_amd_SetCycleFusion(on)
+                    da = B.parvec_from_numpy(np.zeros(n) if zero else u0)
+                    if zero:
+                        lib.hypre_ParVectorSetZeros(da)
+                    lib.hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice(A, df, 0.9, 1.0, l1, da, dr, dz, k)
+                    B.check()
+                    res.append(B.parvec_to_numpy(da))
+                assert np.array_equal(res[0].view(np.int64), res[1].view(np.int64)), (k, zero)
+    finally:
+        lib.hypre_amd_SetCycleFusion(1)
     lib.HYPRE_BoomerAMGDestroy(s)
 
 
@@ -815,13 +832,15 @@ def test_a_new_setup_after_an_in_place_edit_works_on_the_new_values(gpu_lib, ora
 
 
 @pytest.mark.parametrize("kw", [dict(relax_type=18), dict(relax_type=7, relax_wt=0.8), dict(relax_type=18, cycle_type=2),
-                                dict(relax_type=18, mixed=True), dict(relax_type=18, relax_order=1), dict(relax_type=11)])
-def test_the_restriction_that_starts_the_coarse_sweep_changes_no_bit(gpu_lib, oracle, kw):
-    """On one rank the restriction f_c = P^T r also writes the coarse level's first Jacobi-type sweep from zero, u_c = (w f_c) ./ d_c
-    (hypre_amd_SetCycleFusion; an epilogue of the SpMV kernels instead of a kernel of its own).  The cycle is the same BIT FOR BIT
-    with the fusion on and off — eager, recorded as a graph and replayed, V- and W-cycles, fp32 matrix values; switching it
-    invalidates a recorded coarse tail (the recording leaves out what a fused restriction into it did); smoothers the fusion
-    does not apply to (CF-ordered sweeps, two-stage GS) are untouched — and it is the oracle's cycle."""
+                                dict(relax_type=18, mixed=True), dict(relax_type=18, relax_order=1), dict(relax_type=11),
+                                dict(relax_type=12, problem="27pt"), dict(relax_type=11, mixed=True)])
+def test_the_fusions_across_the_steps_of_a_cycle_change_no_bit(gpu_lib, oracle, kw):
+    """hypre_amd_SetCycleFusion.  On one rank the restriction f_c = P^T r also writes the coarse level's first Jacobi-type sweep from
+    zero, u_c = (w f_c) ./ d_c (an epilogue of the SpMV kernels instead of a kernel of its own), and a two-stage Gauss-Seidel
+    sweep runs in two or three passes instead of four or five (the residual already scaled by the diagonal, "u += z" folded into
+    the first inner step).  The cycle is the same BIT FOR BIT with the fusions on and off — eager, recorded as a graph and
+    replayed, V- and W-cycles, fp32 matrix values; switching them invalidates a recorded coarse tail (the recording leaves out
+    what a fused restriction into it did); CF-ordered sweeps are untouched — and it is the oracle's cycle."""
     from hypre_amd import binding as B
     lib = gpu_lib
     kw = dict(kw)
