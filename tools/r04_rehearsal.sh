@@ -3,12 +3,20 @@ set -x
 out=gpurun_out/${1:-r04_rehearsal}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_dist_gpu.py tests/test_seq_matvec_gpu.py -m gpu -x -q > $out/tests.log 2>&1; echo "tests exit $?"; tail -4 $out/tests.log
+timeout -k 10 900 python -m pytest tests/test_dist_gpu.py -m gpu -x -q > $out/tests.log 2>&1; echo "tests exit $?"; tail -4 $out/tests.log
 export HYPRE_AMD_BENCH_TRANSPORT=gloo
-for cfg in "dev2 2" "dev4 4"; do
+for cfg in "dev2 2 --grid 128" "dev4 4 --grid 128" "c4_dev2 2 --grid 96 --problem 27pt --relax 11" "c5_dev2 2 --grid 96 --problem difconv --mixed"; do
   set -- $cfg
-  timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus $2 --grid 128 --steps 10 --warmup 3 > $out/bench_rehearsal_$1.json 2> $out/bench_rehearsal_$1.err; echo "$1 exit $?"
+  name=$1; np=$2; shift 2
+  timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $np --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus $np --steps 10 --warmup 3 "$@" > $out/bench_rehearsal_$name.json 2> $out/bench_rehearsal_$name.err; echo "$name exit $?"
 done
 unset HYPRE_AMD_BENCH_TRANSPORT
 HYPRE_AMD_BENCH_SHARE_GPU=1 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --grid 96 --steps 5 --warmup 2 > $out/bench_rehearsal_rccl_fallback.json 2> $out/bench_rehearsal_rccl_fallback.err; echo "fallback exit $?"
-tail -c 600 $out/bench_rehearsal_dev2.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/%s/bench_rehearsal_*.json" % __import__("os").environ.get("R04_OUT","r04_reh2"))):
+    try:
+        d=json.loads([l for l in open(f) if l.startswith('{"metric"')][0]); c=d['config']; o=c['overlap']
+        print(f.split('/')[-1], 'ms/step %.3f' % d['ms_per_step'], c['transport'], '| exposed %.0f transfer %.0f host %.0f us | single %.3f ms | parity %s' % (o['exposed_us_per_cycle'], o['transfer_us_per_cycle'], o['host_in_transport_us_per_cycle'], o.get('single_rank_ms_per_step_same_block',-1), (d.get('cpu_baseline') or {}).get('gpu_vs_cpu_cycle_rel_max_diff')))
+    except Exception as e: print(f, 'ERR', e)
+PY
