@@ -197,6 +197,8 @@ PROTOTYPES = {
     "hypre_amd_PlanTestFailAlloc": (Int, [Int, Int]),
     "hypre_amd_SetMixedPrecisionValues": (Int, [Int]),
     "hypre_amd_SpmvSetRowSlices": (Int, [Int]),
+    "hypre_amd_SpmvSetFusedMultivectors": (Int, [Int]),
+    "hypre_amd_SpmvFusedMultivectorLaunches": (Int, []),
     "hypre_amd_CSRMatrixPlanRowSlices": (Int, [CSRp, IntP, IntP]),
     "hypre_amd_CSRMatrixSortRows": (Int, [CSRp, Int]),
     "hypre_amd_SpmvSetBandPolicy": (Int, [Int, Int, Int]),

@@ -297,6 +297,11 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
 // y = M x and, in the same pass, u = (w y) ./ d  (seq_mv.cpp): the restriction f_c = P^T r fused with the zero-guess Jacobi
 // sweep u_c = w f_c ./ d_c that follows it on the coarse level; false: not served (empty matrix), nothing was launched
 bool spmv_with_scaled_quotient(hypre_CSRMatrix *M, const double *x, double *y, double w, const double *d, double *u);
+// y(:, v) = alpha A x(:, v) + beta b(:, v), v < nv, in one pass over the matrix (columns xstride / bstride / ystride doubles
+// apart); false: not served by this plan or these operands, nothing launched — the caller loops over the columns
+bool launch_spmv_mv(const SpmvPlan *plan, const SpmvArgs &args, int nv, long xstride, long bstride, long ystride, hipStream_t s);
+long &spmv_mv_launches();               // fused launches so far (tests)
+bool &spmv_fused_multivectors();       // default on; HYPRE_AMD_SPMV_FUSED_MV=0 / hypre_amd_SpmvSetFusedMultivectors
 void launch_spmv_rownnz(const HYPRE_Int *rownnz, int num_rownnz, const SpmvArgs &args, hipStream_t s);
 void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s);
 // value codes of a matrix (nullptr / 0 when it holds more than 256 distinct values): codes[nnz], the sorted table, its fp32-rounded twin

@@ -122,6 +122,24 @@ __global__ void scaled_div_kernel(double w, const double *__restrict__ f, const 
    }
 }
 
+// the same, two rows a lane (16-byte loads and stores: unmarked rows, aligned vectors)
+__global__ void scaled_div2_kernel(double w, const double *__restrict__ f, const double *__restrict__ d, double *__restrict__ u, size_t n)
+{
+   VEC_LOOP_BEGIN
+      const double2 fv = reinterpret_cast<const double2 *>(f)[i], dv = reinterpret_cast<const double2 *>(d)[i];
+      reinterpret_cast<double2 *>(u)[i] = make_double2((w * fv.x) / dv.x, (w * fv.y) / dv.y);
+   VEC_LOOP_END
+   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { u[n - 1] = (w * f[n - 1]) / d[n - 1]; }
+}
+__global__ void scaled_recip2_kernel(double w, const double *__restrict__ f, const double *__restrict__ d, double *__restrict__ z, size_t n)
+{
+   VEC_LOOP_BEGIN
+      const double2 fv = reinterpret_cast<const double2 *>(f)[i], dv = reinterpret_cast<const double2 *>(d)[i];
+      reinterpret_cast<double2 *>(z)[i] = make_double2(__dmul_rn(__dmul_rn(w, fv.x), 1.0 / dv.x), __dmul_rn(__dmul_rn(w, fv.y), 1.0 / dv.y));
+   VEC_LOOP_END
+   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) { z[n - 1] = __dmul_rn(__dmul_rn(w, f[n - 1]), 1.0 / d[n - 1]); }
+}
+
 // z = (w f) .* (1 ./ d): the start of a two-stage Gauss-Seidel sweep from a zero iterate (what scale_copy + diagscale2 give, in one pass)
 __global__ void scaled_recip_kernel(double w, const double *__restrict__ f, const double *__restrict__ d, double *__restrict__ z, size_t n)
 {
@@ -455,9 +473,21 @@ void launch_axpyz(double a, const double *x, double b, const double *y, double *
 void launch_elmdivpy(const double *x, const double *d, double *y, const int *marker, int mval, size_t n, hipStream_t s)
 { account_bytes((32.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(elmdivpy_kernel, dim3(lin_grid(n)), dim3(256), 0, s, x, d, y, marker, mval, n); }
 void launch_scaled_div(double w, const double *f, const double *d, double *u, const int *marker, int mval, size_t n, hipStream_t s)
-{ account_bytes((24.0 + (marker ? 4.0 : 0.0)) * n); if (n) hipLaunchKernelGGL(scaled_div_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, u, marker, mval, n); }
+{
+   account_bytes((24.0 + (marker ? 4.0 : 0.0)) * n);
+   if (!n) { return; }
+   const bool aligned = ((((uintptr_t) f) | ((uintptr_t) d) | ((uintptr_t) u)) & 15) == 0;
+   if (!marker && aligned) { hipLaunchKernelGGL(scaled_div2_kernel, dim3(vec_grid(n)), dim3(256), 0, s, w, f, d, u, n); }
+   else { hipLaunchKernelGGL(scaled_div_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, u, marker, mval, n); }
+}
 void launch_scaled_recip(double w, const double *f, const double *d, double *z, size_t n, hipStream_t s)
-{ account_bytes(24.0 * n); if (n) hipLaunchKernelGGL(scaled_recip_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, z, n); }
+{
+   account_bytes(24.0 * n);
+   if (!n) { return; }
+   const bool aligned = ((((uintptr_t) f) | ((uintptr_t) d) | ((uintptr_t) z)) & 15) == 0;
+   if (aligned) { hipLaunchKernelGGL(scaled_recip2_kernel, dim3(vec_grid(n)), dim3(256), 0, s, w, f, d, z, n); }
+   else { hipLaunchKernelGGL(scaled_recip_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, z, n); }
+}
 void launch_diagscale2(const double *diag, const double *x, double beta, double *y, double *z, int computeY, size_t n, hipStream_t s)
 { account_bytes(40.0 * n); if (n) hipLaunchKernelGGL(diagscale2_kernel, dim3(lin_grid(n)), dim3(256), 0, s, diag, x, beta, y, z, computeY, n); }
 void launch_dot(const double *x, const double *y, size_t n, double *d_out, hipStream_t s)

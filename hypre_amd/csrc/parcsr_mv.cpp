@@ -834,8 +834,8 @@ HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlaceDevice(HYPRE_Complex alpha, hypre_Pa
    HYPRE_AMD_REQUIRE_DEVICE(bl->memory_location, "hypre_ParCSRMatrixMatvec(b)");
    if (xl->num_vectors != 1 || yl->num_vectors != 1 || bl->num_vectors != 1)
    {
-      // column-major multivectors (par_csr_matvec.c:146-165 asserts idxstride == 1 as well): one product per column,
-      // each with its own halo exchange
+      // column-major multivectors (par_csr_matvec.c:146-165 asserts idxstride == 1 as well): one halo exchange for all
+      // columns, the local block's product fused over the columns, the ghost block's column by column
       const HYPRE_Int nv = xl->num_vectors;
       if (yl->num_vectors != nv || bl->num_vectors != nv || xl->idxstride != 1 || yl->idxstride != 1 || bl->idxstride != 1)
       {
@@ -860,14 +860,8 @@ HYPRE_Int hypre_ParCSRMatrixMatvecOutOfPlaceDevice(HYPRE_Complex alpha, hypre_Pa
          launch_gather(xl->data, pkg->device_send_map_elmts, pkg->buf_data, (size_t) tot_send, stream());
          ch = hypre_ParCSRCommHandleCreate_v2(1, pkg, HYPRE_MEMORY_DEVICE, pkg->buf_data, HYPRE_MEMORY_DEVICE, pkg->tmp_data);
       }
-      for (HYPRE_Int v = 0; v < nv; v++)
-      {
-         hypre_Vector xv = *xl, bv = *bl, yv = *yl;
-         xv.data += (size_t) v * xl->vecstride; xv.num_vectors = 1;
-         bv.data += (size_t) v * bl->vecstride; bv.num_vectors = 1;
-         yv.data += (size_t) v * yl->vecstride; yv.num_vectors = 1;
-         hypre_CSRMatrixMatvecDevice(0, alpha, diag, &xv, beta, b == y ? &yv : &bv, &yv, 0);
-      }
+      // the local block: all columns in one pass over the matrix where its plan allows it (seq_mv.cpp: spmv_device_columns)
+      hypre_CSRMatrixMatvecDevice(0, alpha, diag, xl, beta, b == y ? yl : bl, yl, 0);
       if (ch)
       {
          hypre_ParCSRCommHandleDestroy(ch);

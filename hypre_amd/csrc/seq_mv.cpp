@@ -445,6 +445,12 @@ bool &spmv_slice_form()
    return on;
 }
 
+bool &spmv_fused_multivectors()
+{
+   static bool on = [] { const char *e = getenv("HYPRE_AMD_SPMV_FUSED_MV"); return !(e && atoi(e) == 0); }();
+   return on;
+}
+
 bool &spmv_value_codes()
 {
    static bool on = [] { const char *e = getenv("HYPRE_AMD_SPMV_VALUE_CODES"); return !(e && atoi(e) == 0); }();
@@ -1064,6 +1070,39 @@ static void spmv_device_core(HYPRE_Complex alpha, hypre_CSRMatrix *A, const HYPR
    launch_spmv(plan, a, OP_AXPBY, s);
 }
 
+// Y = alpha A X + beta B for the nv columns of a multivector: one pass over the matrix where the plan's form allows it
+// (spmv_xs_mv_kernel; the reference sums NV products per entry too: csr_matvec.c:117-380, csr_spmv_device.c:37-134),
+// else column by column.  Same bits either way.
+static void spmv_device_columns(HYPRE_Complex alpha, hypre_CSRMatrix *A, const HYPRE_Complex *x, size_t xstride,
+                                HYPRE_Complex beta, const HYPRE_Complex *b, size_t bstride, HYPRE_Complex *y, size_t ystride,
+                                HYPRE_Int nv, HYPRE_Int fill)
+{
+   const bool plain = A->num_rows > 0 && A->num_nonzeros > 0 && alpha != 0.0 && fill == HYPRE_SPMV_FILL_WHOLE &&
+                      !(A->rownnz && (double) A->num_rownnz < 0.7 * (double) A->num_rows);
+   if (nv > 1 && plain && spmv_fused_multivectors())
+   {
+      SpmvArgs a{};
+      a.Ai = A->i; a.Aj = A->j; a.Aa = A->data; a.Aa32 = nullptr;
+      a.x = x; a.b = b; a.y = y; a.d = nullptr; a.marker = nullptr; a.marker_val = 0;
+      a.alpha = alpha; a.beta = beta; a.fill = fill; a.row_offset = 0;
+      spmv_default_flags(a);
+      if (launch_spmv_mv(get_plan(A), a, nv, (long) xstride, (long) bstride, (long) ystride, stream())) { return; }
+   }
+   for (HYPRE_Int v = 0; v < nv; v++)
+   {
+      spmv_device_core(alpha, A, x + (size_t) v * xstride, beta, b + (size_t) v * bstride, y + (size_t) v * ystride, fill);
+   }
+}
+
+// Multivector products in one pass over the matrix (default) or column by column: speed only, same bits.
+HYPRE_Int hypre_amd_SpmvSetFusedMultivectors(HYPRE_Int on)
+{
+   hamd::spmv_fused_multivectors() = on != 0;
+   return hypre_error_flag;
+}
+// launches of the fused multivector kernel since the library was loaded (tests: which path served a product)
+HYPRE_Int hypre_amd_SpmvFusedMultivectorLaunches(void) { return (HYPRE_Int) hamd::spmv_mv_launches(); }
+
 HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_CSRMatrix *A,
                                       hypre_Vector *x, HYPRE_Complex beta, hypre_Vector *b,
                                       hypre_Vector *y, HYPRE_Int offset)
@@ -1098,15 +1137,15 @@ HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypr
       x_tmp = hypre_SeqVectorCloneDeep(x);
       xd = x_tmp->data;
    }
-   for (HYPRE_Int v = 0; v < x->num_vectors; v++)
+   const bool by_columns = x->num_vectors == 1 || (x->idxstride == 1 && y->idxstride == 1 && b->idxstride == 1);
+   if (!by_columns)
    {
-      if (x->idxstride != 1 || y->idxstride != 1 || b->idxstride != 1)
-      {
-         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_CSRMatrixMatvecDevice: row-wise multivector storage is not supported");
-         break;
-      }
-      spmv_device_core(alpha, M, xd + (size_t) v * x->vecstride, beta, b->data + (size_t) v * b->vecstride,
-                       y->data + (size_t) v * y->vecstride, HYPRE_SPMV_FILL_WHOLE);
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_CSRMatrixMatvecDevice: row-wise multivector storage is not supported");
+   }
+   else
+   {
+      spmv_device_columns(alpha, M, xd, (size_t) x->vecstride, beta, b->data, (size_t) b->vecstride, y->data, (size_t) y->vecstride,
+                          x->num_vectors, HYPRE_SPMV_FILL_WHOLE);
    }
    if (handle().sync_compute && !(x->data == y->data))
    {
@@ -1122,10 +1161,10 @@ HYPRE_Int hypre_CSRMatrixMatvecDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypr
       }
       else if (plan_is_stale(M))
       {
-         for (HYPRE_Int v = 0; v < x->num_vectors; v++)
+         if (by_columns)
          {
-            spmv_device_core(alpha, M, xd + (size_t) v * x->vecstride, beta, b->data + (size_t) v * b->vecstride,
-                             y->data + (size_t) v * y->vecstride, HYPRE_SPMV_FILL_WHOLE);
+            spmv_device_columns(alpha, M, xd, (size_t) x->vecstride, beta, b->data, (size_t) b->vecstride, y->data, (size_t) y->vecstride,
+                                x->num_vectors, HYPRE_SPMV_FILL_WHOLE);
          }
       }
    }
@@ -1181,11 +1220,8 @@ HYPRE_Int hypre_CSRMatrixSpMVDevice(HYPRE_Int trans, HYPRE_Complex alpha, hypre_
       if (!plan->AT) { hypre_CSRMatrixTranspose(B, &plan->AT, 1); if (plan->owned) { mark_owned(plan->AT); } }
       M = plan->AT;
    }
-   for (HYPRE_Int v = 0; v < x->num_vectors; v++)
-   {
-      spmv_device_core(alpha, M, x->data + (size_t) v * x->vecstride, beta,
-                       y->data + (size_t) v * y->vecstride, y->data + (size_t) v * y->vecstride, fill);
-   }
+   spmv_device_columns(alpha, M, x->data, (size_t) x->vecstride, beta, y->data, (size_t) y->vecstride, y->data, (size_t) y->vecstride,
+                       x->num_vectors, fill);
    return hypre_error_flag;
 }
 

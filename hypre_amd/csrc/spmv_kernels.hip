@@ -882,6 +882,299 @@ void spmv_xs_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__r
 #endif
 }
 
+// ---------------------------------------------------------------------------
+// Several right-hand sides in ONE pass over the matrix: Y(:, v) = alpha A X(:, v) + beta B(:, v), v < NV, multivectors stored
+// column by column (seq_mv/vector.h:22-40).  The reference sums NV products per entry in registers (host:
+// seq_mv/csr_matvec.c:117-380, NV = 2, 3, 4; device: csr_spmv_device.c:37-134); the column loop of seq_mv.cpp streams the
+// matrix NV times.  Here a tile of the x-staged form fetches its window of values and local indices ONCE and the x pieces of
+// all NV columns in the same trip (NV staged copies side by side in LDS), parks values and indices in LDS — not products: a
+// parked product serves one column, a parked value all of them — and a lane per row (W lanes per row where the rows are
+// long) sums its entries for the NV columns out of LDS: 1.25 + NV reads per entry instead of NV x (read x, write the
+// product, read it again), one barrier instead of two per column.
+// Same bits as NV single-vector products: every product rounded, then the additions of tile_reduce in its order (stored
+// order on one lane; W interleaved partial sums and the xor tree on W lanes, W chosen as tile_reduce chooses it).
+// Serves fp64 and coded matrices (VF_F64 / VF_CODE) multiplied as a whole; everything else keeps the column loop.
+// ---------------------------------------------------------------------------
+template <int NV, bool CODED, int W>
+__device__ __forceinline__ void mv_row_sums(const SpmvArgs &p, int r0, int nrows, int ka, int rp_cap, bool staged, int stage_elems,
+                                            const double *xsv, const double *valS, const unsigned char *cdS, const double *dictl,
+                                            const unsigned short *liS, const int *rp, long xstride, long bstride, long ystride,
+                                            const double *bv)
+{
+   constexpr int MB = 4;                     // entries a lane has in flight (values, indices, then NV x each): the additions keep their order
+   const int G = (int) blockDim.x / W;       // rows a pass takes (the workgroup may have more lanes than the 256 that stream the tile)
+   const int tid = threadIdx.x, sub = tid & (W - 1);
+   for (int base = 0; base < nrows; base += G)
+   {
+      const int rr = base + tid / W;
+      const bool live = rr < nrows;
+      const int row = r0 + min(rr, nrows - 1);
+      int s = 0, e = 0;
+      if (live)
+      {
+         s = (rr     <= rp_cap) ? rp[rr]     : p.Ai[row];
+         e = (rr + 1 <= rp_cap) ? rp[rr + 1] : p.Ai[row + 1];
+      }
+      double sum[NV];
+#pragma unroll
+      for (int v = 0; v < NV; v++) { sum[v] = 0.0; }
+      for (int k = s + sub; k < e; k += MB * W)
+      {
+         double a[MB], xv[MB][NV];
+         if (staged)
+         {
+            unsigned li[MB];
+#pragma unroll
+            for (int i = 0; i < MB; i++)
+            {
+               const int q = min(k + i * W, e - 1) - ka;
+               a[i] = CODED ? dictl[cdS[q]] : valS[q];
+               li[i] = liS[q];
+            }
+#pragma unroll
+            for (int i = 0; i < MB; i++)
+            {
+#pragma unroll
+               for (int v = 0; v < NV; v++) { xv[i][v] = xsv[v * stage_elems + li[i]]; }
+            }
+         }
+         else
+         {
+            // a tile whose columns do not fit the staging area: x through the cache
+            int c[MB];
+#pragma unroll
+            for (int i = 0; i < MB; i++)
+            {
+               const int q = min(k + i * W, e - 1);
+               a[i] = CODED ? dictl[cdS[q - ka]] : valS[q - ka];
+               c[i] = p.Aj[q];
+            }
+#pragma unroll
+            for (int i = 0; i < MB; i++)
+            {
+#pragma unroll
+               for (int v = 0; v < NV; v++) { xv[i][v] = p.x[(size_t) v * xstride + c[i]]; }
+            }
+         }
+#pragma unroll
+         for (int i = 0; i < MB; i++)
+         {
+            if (k + i * W < e)
+            {
+#pragma unroll
+               for (int v = 0; v < NV; v++)
+               {
+#pragma clang fp contract(off)
+                  const double pr = a[i] * xv[i][v];
+                  sum[v] = sum[v] + pr;
+               }
+            }
+         }
+      }
+      if (W > 1)
+      {
+#pragma unroll
+         for (int v = 0; v < NV; v++) { sum[v] = subwave_sum<W>(sum[v]); }
+      }
+      if (live && sub == 0)
+      {
+#pragma unroll
+         for (int v = 0; v < NV; v++)
+         {
+            // the epilogue of OP_AXPBY (row_epilogue)
+            double r = __dmul_rn(p.alpha, sum[v]);
+            if (p.beta != 0.0) { r = __fma_rn(p.beta, (W == 1 && rr == tid) ? bv[v] : p.b[(size_t) v * bstride + row], r); }
+            p.y[(size_t) v * ystride + row] = r;
+         }
+      }
+   }
+}
+
+constexpr int MV_THREADS_MAX = 384;       // tiles of short rows hold more rows than 256: a fifth and sixth wave take them in the same pass
+template <int NV, bool CODED>
+__global__ __launch_bounds__(MV_THREADS_MAX)
+void spmv_xs_mv_kernel(SpmvArgs p, const int *__restrict__ tile_row, const int *__restrict__ tile_k,
+                       const int *__restrict__ xs_cnt, const int *__restrict__ xs_desc, const unsigned short *__restrict__ lidx,
+                       int num_tiles, int stage_elems, int win_elems, int rp_cap, int xs_units, long xstride, long bstride, long ystride)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *xsv  = reinterpret_cast<double *>(smem_raw);                               // NV staged copies of x, stage_elems each
+   double *valS = xsv + (size_t) NV * stage_elems;                                    // the window's values (CODED: its codes, one byte each)
+   unsigned char *cdS = reinterpret_cast<unsigned char *>(valS);
+   unsigned short *liS = reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(valS) + (CODED ? (size_t) win_elems : sizeof(double) * (size_t) win_elems));
+   int *rp = reinterpret_cast<int *>(liS + win_elems);
+   const double *dictl = reinterpret_cast<const double *>(rp + ((rp_cap + 4) & ~3));  // CODED only
+
+   int tile = (int) blockIdx.x;
+   if (p.tile_perm)
+   {
+      if (tile >= num_tiles) { return; }
+      tile = p.tile_perm[tile];
+   }
+   else if (p.xcd_map > 0)
+   {
+      const int g = blockIdx.x >> 3, c = blockIdx.x & 7, C = p.xcd_map;
+      tile = (g / C) * (8 * C) + c * C + (g % C);
+   }
+   if ((unsigned) tile >= (unsigned) num_tiles) { return; }
+
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   const bool streamer = wave < 4;            // waves 4 and 5 (tiles of more than 256 rows) only sum rows
+   const int ka = tile * SPMV_TILE;
+   // one batch of requests, as spmv_xs_kernel: the window's values (or codes) and local indices, the tile's bounds and
+   // this wave's piece descriptors
+   const int kA = ka + 4 * tid, kB = kA + 4 * SPMV_THREADS;
+   const int qA = min(kA, p.last_quad), qB = min(kB, p.last_quad);
+   unsigned cdA = 0, cdB = 0;
+   v2d vA01 = {0.0, 0.0}, vA23 = {0.0, 0.0}, vB01 = {0.0, 0.0}, vB23 = {0.0, 0.0};
+   v2i lA = {0, 0}, lB = {0, 0};
+   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
+   int fp_plan = 0, fc0 = 0, fc1 = 0;
+   double   ckv = 0.0;
+   unsigned ckc = 0;
+   if (streamer)
+   {
+      if (CODED)
+      {
+         cdA = stream_load<unsigned>(p.Ac8 + qA);
+         cdB = stream_load<unsigned>(p.Ac8 + qB);
+      }
+      else
+      {
+         vA01 = stream_load<v2d>(p.Aa + qA); vA23 = stream_load<v2d>(p.Aa + qA + 2);
+         vB01 = stream_load<v2d>(p.Aa + qB); vB23 = stream_load<v2d>(p.Aa + qB + 2);
+      }
+      lA = stream_load<v2i>(lidx + qA); lB = stream_load<v2i>(lidx + qB);
+      const int *dsc = xs_desc + (size_t) tile * XS_DESC + XS_WSEG * wave;
+#pragma unroll
+      for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
+      const int qs0 = min(ka + 5, p.last_quad), qs1 = min(ka + 1029, p.last_quad);
+      fp_plan = p.tile_fp[tile];
+      fc0 = p.Aj[qs0]; fc1 = p.Aj[qs1];
+      // the rotating value check of a coded matrix (see spmv_xs_kernel)
+      if (CODED)
+      {
+         const int ck = min(ka + 8 * (int) ((4u * p.rot + (unsigned) wave) & 255u) + (lane & 7), p.nnz - 1);
+         ckv = p.Aa[ck];
+         ckc = p.Ac8[ck];
+      }
+   }
+   const int r0 = tile_row[tile], r1 = tile_row[tile + 1];
+   const int k0 = tile_k[tile], k1 = tile_k[tile + 1];
+   const int xc = xs_cnt[tile];
+   asm volatile("" :: "s"(tile_row), "s"(tile_k), "s"(xs_cnt), "s"(xs_desc), "s"(lidx), "s"(p.Aa), "s"(p.Aj), "s"(p.tile_fp), "s"(p.Ac8) : "memory");
+   if (r1 <= r0) { return; }
+   const int nrows = r1 - r0;
+   const int nseg = (xc >> 8) <= xs_units ? (xc & 0xff) : 0;
+   const bool staged = nseg != 0;
+   if (streamer)
+   {
+      {
+         const bool off = fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1);
+         if (off && tid == 0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+      }
+      if (CODED)
+      {
+         const int dl = (p.ndict + 1) >> 1;
+         if (lane < dl - 64 * wave)
+         {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.dict + 128 * wave + 2 * lane),
+                                             (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(const_cast<double *>(dictl)) + 1024 * wave), 16, 0, 0);
+         }
+      }
+      if (staged)
+      {
+         // the x pieces of every column: NV copies of the tile's staging area, one after the other
+#pragma unroll
+         for (int v = 0; v < NV; v++)
+         {
+#pragma unroll
+            for (int j = 0; j < XS_WSEG; j++)
+            {
+               const unsigned offb = (unsigned) seg_ol[j] >> 16, lanes = (unsigned) seg_ol[j] & 0xffffu;
+               if ((unsigned) lane < lanes)
+               {
+                  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + (size_t) v * xstride + (size_t) (unsigned) seg_start[j] + 2 * lane),
+                                                   (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(xsv + (size_t) v * stage_elems) + offb), 16, 0, 0);
+               }
+            }
+         }
+      }
+   }
+   // the first row's operands of every lane: same trip
+   double bv[NV];
+#pragma unroll
+   for (int v = 0; v < NV; v++) { bv[v] = 0.0; }
+   if (p.beta != 0.0)
+   {
+      const int rb = max(r0 + min(tid, nrows - 1), 0);
+#pragma unroll
+      for (int v = 0; v < NV; v++) { bv[v] = p.b[(size_t) v * bstride + rb]; }
+   }
+   if (streamer)
+   {
+      // the spill of the tile's last row past the window (rows of at most SPMV_THREADS entries: the launcher's condition) and
+      // the row pointers
+      const int kC = ka + 8 * SPMV_THREADS + tid;
+      const int qC = kC < k1 ? kC : min(ka + 8 * SPMV_THREADS, p.last_quad);
+      const unsigned lC = lidx[qC];
+      unsigned cdC = 0;
+      double vC = 0.0;
+      if (CODED) { cdC = p.Ac8[qC]; } else { vC = p.Aa[qC]; }
+      constexpr int RPJ = (RP_CAP + SPMV_THREADS) / SPMV_THREADS;
+      const int lim = min(nrows, rp_cap);
+      int rpv[RPJ];
+#pragma unroll
+      for (int j = 0; j < RPJ; j++) { rpv[j] = p.Ai[r0 + min(tid + j * SPMV_THREADS, lim)]; }
+#pragma unroll
+      for (int j = 0; j < RPJ; j++) { rp[min(tid + j * SPMV_THREADS, lim)] = rpv[j]; }
+      if (tid == 0 && rpv[0] != k0) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+      // park the window
+      if (CODED)
+      {
+         *reinterpret_cast<unsigned *>(cdS + (kA - ka)) = cdA;
+         *reinterpret_cast<unsigned *>(cdS + (kB - ka)) = cdB;
+         if (kC < k1) { cdS[kC - ka] = (unsigned char) cdC; }
+      }
+      else
+      {
+         *reinterpret_cast<v2d *>(valS + (kA - ka))     = vA01;
+         *reinterpret_cast<v2d *>(valS + (kA - ka) + 2) = vA23;
+         *reinterpret_cast<v2d *>(valS + (kB - ka))     = vB01;
+         *reinterpret_cast<v2d *>(valS + (kB - ka) + 2) = vB23;
+         if (kC < k1) { valS[kC - ka] = vC; }
+      }
+      *reinterpret_cast<v2i *>(liS + (kA - ka)) = lA;
+      *reinterpret_cast<v2i *>(liS + (kB - ka)) = lB;
+      if (kC < k1) { liS[kC - ka] = (unsigned short) lC; }
+   }
+   __syncthreads();
+   if (CODED && streamer)
+   {
+      if (__double_as_longlong(dictl[ckc]) != __double_as_longlong(ckv)) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+   }
+
+   const int avg = (k1 - k0) / nrows;
+   int Wd = 1;
+   if (avg > 12)
+   {
+      Wd = p.reduce_w;
+      if (Wd <= 0) { Wd = 32; while (Wd > 1 && nrows * Wd > SPMV_THREADS) { Wd >>= 1; } }
+   }
+#define MV_SUMS(WW) mv_row_sums<NV, CODED, WW>(p, r0, nrows, ka, rp_cap, staged, stage_elems, xsv, valS, cdS, dictl, liS, rp, xstride, bstride, ystride, bv)
+   switch (Wd)
+   {
+      case 1:  MV_SUMS(1); break;
+      case 2:  MV_SUMS(2); break;
+      case 4:  MV_SUMS(4); break;
+      case 8:  MV_SUMS(8); break;
+      case 16: MV_SUMS(16); break;
+      default: MV_SUMS(32); break;
+   }
+#undef MV_SUMS
+}
+
 // ---- plan construction: per tile, the segments of x its entries touch and per entry the index of its column in
 // their concatenation.  One workgroup per tile.  Columns are handled in units of two (16 bytes of x): sort the units
 // (bitonic, LDS), keep the distinct ones, cut where the gap to the next unit exceeds a threshold T — the smallest power
@@ -1194,6 +1487,125 @@ void spmv_sl_kernel(SpmvArgs p, const int *__restrict__ sl_cnt, const int *__res
       if (off) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
    }
    if (r < num_rows && sub == 0) { row_epilogue<OP>(p, r, sum, ops); }
+}
+
+// The slice form with a multivector: a lane's codes and local indices are in registers, so the columns cost their x pieces
+// (NV staged copies), NV reads per entry and NV sums — the matrix words are read once.  Same bits as spmv_sl_kernel column
+// by column (and so as every other form).  y = alpha A x + beta b only.
+template <int NV, int W, int KP>
+__global__ __launch_bounds__(SPMV_THREADS)
+void spmv_sl_mv_kernel(SpmvArgs p, const int *__restrict__ sl_desc, const int *__restrict__ sl_k0,
+                       const int *__restrict__ sl_fp, const int *__restrict__ sl_perm, const unsigned *__restrict__ sl_data,
+                       int blocks, int num_rows, int nnz, int stage_elems, long xstride, long bstride, long ystride)
+{
+   constexpr int wc = KP / 4, wl = KP / 2;
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   double *xs = reinterpret_cast<double *>(smem_raw);
+   const double *dictl = xs + (size_t) NV * stage_elems;
+
+   int block = (int) blockIdx.x;
+   if (sl_perm)
+   {
+      if (block >= blocks) { return; }
+      block = sl_perm[block];
+   }
+   else { const int g = block >> 3, c = block & 7; block = (g >> 3) * 64 + c * 8 + (g & 7); }
+   if ((unsigned) block >= (unsigned) blocks) { return; }
+
+   const int tid = threadIdx.x, lane = tid & 63;
+   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+   constexpr int R = SPMV_THREADS / W;
+   const unsigned *sd = sl_data + ((size_t) (block * 4 + wave) * (size_t) (wc + wl)) * 64 + lane;
+   unsigned cw[wc], lw[wl];
+#pragma unroll
+   for (int w = 0; w < wc; w++) { cw[w] = sd[w * 64]; }
+#pragma unroll
+   for (int w = 0; w < wl; w++) { lw[w] = sd[(wc + w) * 64]; }
+   const int r = block * R + tid / W, sub = tid % W;
+   const int rs = p.Ai[min(r, num_rows)], re = p.Ai[min(r + 1, num_rows)];
+   const int rc = max(min(r, num_rows - 1), 0);
+   double bv[NV];
+#pragma unroll
+   for (int v = 0; v < NV; v++) { bv[v] = 0.0; }
+   if (p.beta != 0.0)
+   {
+#pragma unroll
+      for (int v = 0; v < NV; v++) { bv[v] = p.b[(size_t) v * bstride + rc]; }
+   }
+   const int *dsc = sl_desc + (size_t) block * XS_DESC + XS_WSEG * wave;
+   int seg_start[XS_WSEG], seg_ol[XS_WSEG];
+#pragma unroll
+   for (int j = 0; j < XS_WSEG; j++) { seg_start[j] = dsc[j]; seg_ol[j] = dsc[XS_SEGS + j]; }
+   const int k0 = sl_k0[block], k1b = sl_k0[block + 1], fp_plan = sl_fp[block];
+   asm volatile("" :: "s"(sl_desc), "s"(sl_k0), "s"(sl_fp), "s"(sl_data), "s"(p.Ai) : "memory");
+#pragma unroll
+   for (int v = 0; v < NV; v++)
+   {
+#pragma unroll
+      for (int j = 0; j < XS_WSEG; j++)
+      {
+         const unsigned offb = (unsigned) seg_ol[j] >> 16, lanes = (unsigned) seg_ol[j] & 0xffffu;
+         if ((unsigned) lane < lanes)
+         {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.x + (size_t) v * xstride + (size_t) (unsigned) seg_start[j] + 2 * lane),
+                                             (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(xs + (size_t) v * stage_elems) + offb), 16, 0, 0);
+         }
+      }
+   }
+   {
+      const int dl = (p.ndict + 1) >> 1;
+      if (lane < dl - 64 * wave)
+      {
+         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (p.dict + 128 * wave + 2 * lane),
+                                          (__attribute__((address_space(3))) void *) (reinterpret_cast<char *>(const_cast<double *>(dictl)) + 1024 * wave), 16, 0, 0);
+      }
+   }
+   // the watch's samples and the rotating value check, as spmv_sl_kernel
+   const int q0 = min(max(k0, 0), nnz - 1), q1 = min(max(k0, 0) + 1, nnz - 1);
+   const int fc0 = p.Aj[q0], fc1 = p.Aj[q1];
+   const int ck = min(max(min(k0 + 8 * (int) ((4u * p.rot + (unsigned) wave) & 511u) + (lane & 7), k1b - 1), 0), nnz - 1);
+   const double ckv = p.Aa[ck];
+   const unsigned ckc = p.Ac8[ck];
+   __syncthreads();
+
+   const int mylen = (re - rs - sub + W - 1) / W;
+   double sum[NV];
+#pragma unroll
+   for (int v = 0; v < NV; v++) { sum[v] = 0.0; }
+#pragma unroll
+   for (int j = 0; j < KP; j++)
+   {
+      const unsigned code = (cw[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      const unsigned li = (lw[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+      const double a = dictl[code];
+#pragma unroll
+      for (int v = 0; v < NV; v++)
+      {
+#pragma clang fp contract(off)
+         const double pr = a * xs[v * stage_elems + li];
+         if (j < mylen) { sum[v] = sum[v] + pr; }
+      }
+   }
+   if (W == 2)
+   {
+#pragma unroll
+      for (int v = 0; v < NV; v++) { sum[v] += __shfl_xor(sum[v], 1, 64); }
+   }
+   {
+      bool off = __double_as_longlong(dictl[ckc]) != __double_as_longlong(ckv);
+      if (tid == 0) { off = off || fp_plan != (int) ((unsigned) fc0 * 2654435761u + (unsigned) fc1) || rs != k0; }
+      if (off) { __hip_atomic_fetch_or(p.stale, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+   }
+   if (r < num_rows && sub == 0)
+   {
+#pragma unroll
+      for (int v = 0; v < NV; v++)
+      {
+         double t = __dmul_rn(p.alpha, sum[v]);
+         if (p.beta != 0.0) { t = __fma_rn(p.beta, bv[v], t); }
+         p.y[(size_t) v * ystride + r] = t;
+      }
+   }
 }
 
 // ---- slice form construction
@@ -2161,6 +2573,144 @@ void launch_spmv(const SpmvPlan *plan, const SpmvArgs &args, SpmvOp op, hipStrea
       case OP_JACOBI_MAP: launch_spmv_op<OP_JACOBI_MAP>(plan, a, s); break;
       case OP_TSGS:      launch_spmv_op<OP_TSGS>(plan, a, s); break;
    }
+}
+
+// Fused product with a multivector (spmv_xs_mv_kernel): columns v < nv of x, b, y lie xstride / bstride / ystride doubles
+// apart.  false: this plan or these operands are not served (the caller multiplies column by column); nothing was launched.
+template <int NV, bool CODED>
+static void launch_xs_mv(const SpmvPlan *plan, const SpmvArgs &a, int stage_elems, int win_elems, int rp_cap, size_t lds,
+                         long xstride, long bstride, long ystride, hipStream_t s)
+{
+   static bool raised = false;
+   if (!raised)
+   {
+      (void) hipFuncSetAttribute((const void *) (spmv_xs_mv_kernel<NV, CODED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipGetLastError();
+      raised = true;
+   }
+   const int unit = a.tile_perm ? 1 : (a.xcd_map > 0 ? 8 * a.xcd_map : 8);
+   const int grid = ((plan->num_tiles + unit - 1) / unit) * unit;
+   // a lane per row where the rows are short: a fifth and a sixth wave take rows 256 .. 383 of a tile in the same pass
+   const int threads = (plan->max_tile_rows > SPMV_THREADS && plan->max_tile_rows <= 320) ? 320 :
+                       (plan->max_tile_rows > 320 ? MV_THREADS_MAX : SPMV_THREADS);
+   hipLaunchKernelGGL((spmv_xs_mv_kernel<NV, CODED>), dim3(grid), dim3(threads), lds, s, a,
+                      plan->d_tile_row, plan->d_tile_k, plan->d_xs_cnt, plan->d_xs_desc, plan->d_lidx,
+                      plan->num_tiles, stage_elems, win_elems, rp_cap, plan->xs_launch_units, xstride, bstride, ystride);
+}
+
+long &spmv_mv_launches() { static long n = 0; return n; }
+template <int NV, int W, int KP>
+static void launch_sl_mv(const SpmvPlan *plan, const SpmvArgs &a, int stage_elems, size_t lds, long xstride, long bstride, long ystride, hipStream_t s)
+{
+   static bool raised = false;
+   if (!raised)
+   {
+      (void) hipFuncSetAttribute((const void *) (spmv_sl_mv_kernel<NV, W, KP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipGetLastError();
+      raised = true;
+   }
+   const int grid = plan->d_sl_perm ? plan->sl_blocks : ((plan->sl_blocks + 63) / 64) * 64;
+   hipLaunchKernelGGL((spmv_sl_mv_kernel<NV, W, KP>), dim3(grid), dim3(SPMV_THREADS), lds, s, a, plan->d_sl_desc, plan->d_sl_k0,
+                      plan->d_sl_fp, plan->d_sl_perm, plan->d_sl_data, plan->sl_blocks, plan->num_rows, plan->nnz, stage_elems, xstride, bstride, ystride);
+}
+template <int NV>
+static void launch_sl_mv_nv(const SpmvPlan *plan, const SpmvArgs &a, int stage_elems, size_t lds, long xstride, long bstride, long ystride, hipStream_t s)
+{
+   if (plan->sl_w == 1) { launch_sl_mv<NV, 1, 8>(plan, a, stage_elems, lds, xstride, bstride, ystride, s); }
+   else if (plan->sl_k == 8) { launch_sl_mv<NV, 2, 8>(plan, a, stage_elems, lds, xstride, bstride, ystride, s); }
+   else { launch_sl_mv<NV, 2, 16>(plan, a, stage_elems, lds, xstride, bstride, ystride, s); }
+}
+static inline size_t sl_mv_lds_bytes(const SpmvPlan *plan, int nv, int ndict, int &stage_elems)
+{
+   stage_elems = 2 * plan->sl_launch_units + 8;
+   return sizeof(double) * ((size_t) nv * stage_elems + (size_t) ((ndict + 1) & ~1));
+}
+
+constexpr int MV_WIN = 2320;        // SPMV_TILE + SPMV_THREADS entries of a window and its spill, a multiple of 16
+static inline size_t mv_lds_bytes(const SpmvPlan *plan, int nv, bool coded, int ndict, int &stage_elems, int &rp_cap)
+{
+   int rowsum_elems;
+   (void) tiled_lds_bytes(plan, rowsum_elems, rp_cap);
+   stage_elems = 2 * plan->xs_launch_units + 8;
+   return sizeof(double) * (size_t) nv * stage_elems + (coded ? (size_t) MV_WIN : sizeof(double) * (size_t) MV_WIN) + sizeof(unsigned short) * (size_t) MV_WIN +
+          sizeof(int) * (size_t) ((rp_cap + 4) & ~3) + (coded ? sizeof(double) * (size_t) ((ndict + 1) & ~1) : 0);
+}
+
+bool spmv_mv_serves(const SpmvPlan *plan, const SpmvArgs &args, long xstride)
+{
+   SpmvArgs a = args;
+   if (!plan->tiled || !takes_xs(plan, a) || a.fill != HYPRE_SPMV_FILL_WHOLE || a.Aa32 || handle().fp32_values) { return false; }
+   if (plan->max_row_nnz > SPMV_THREADS || (xstride & 1) != 0 || !plan->d_tile_fp || !plan->d_stale) { return false; }
+   // nearly all tiles staged: the others gather NV columns through the cache, entry by entry
+   if ((long long) plan->xs_tiles * 10 < (long long) plan->num_tiles * 9) { return false; }
+   int stage_elems, rp_cap;
+   return mv_lds_bytes(plan, 2, plan->d_codes != nullptr, plan->ndict, stage_elems, rp_cap) <= (size_t) 160 * 1024;
+}
+
+bool launch_spmv_mv(const SpmvPlan *plan, const SpmvArgs &args, int nv, long xstride, long bstride, long ystride, hipStream_t s)
+{
+   if (plan->num_rows <= 0 || nv < 2 || !spmv_mv_serves(plan, args, xstride)) { return false; }
+   SpmvArgs a = args;
+   a.last_quad = (plan->nnz > 0 ? (int) (plan->nnz - 1) : 0) & ~3;
+   a.x_last = plan->num_cols > 0 ? plan->num_cols - 1 : 0;
+   a.tile_perm = plan->d_tile_perm;
+   a.tile_fp = plan->d_tile_fp;
+   a.stale = plan->d_stale;
+   a.nnz = plan->nnz;
+   a.Ac8 = nullptr; a.dict = nullptr; a.ndict = 0; a.dict_rounded = 0; a.use_rs = 0;
+   const bool coded = plan->d_codes != nullptr;
+   if (coded) { a.Ac8 = plan->d_codes; a.ndict = plan->ndict; a.dict = plan->d_dict; }
+   const double nz = (double) plan->nnz, nr = (double) plan->num_rows;
+   const double vecs = (8.0 + ((a.beta != 0.0) ? 8.0 : 0.0)) * nr + 8.0 * std::min((double) plan->num_cols, nz);     // per column: y (+ b), x
+   for (int v0 = 0; v0 < nv; )
+   {
+      const bool slice = coded && plan->d_sl_data != nullptr;      // a lane per row (or half row), the matrix words in registers
+      // columns per pass: four over the tiles (the matrix stream is what the pass saves); the slice form's matrix words are
+      // few, its passes are bound by the x pieces, and a fourth staged copy costs a resident workgroup per CU: threes and twos
+      // (measured per column on the 256^3 7-point operator: 0.108 / 0.104 / 0.118 ms at 2 / 3 / 4 columns, 0.150 alone)
+      const int left = nv - v0;
+      int g = slice ? (left == 4 ? 2 : std::min(3, left)) : std::min(4, left), stage_elems = 0, rp_cap = 0;
+      size_t lds = 0;
+      if (slice) { while (g > 1 && (lds = sl_mv_lds_bytes(plan, g, a.ndict, stage_elems)) > (size_t) 160 * 1024) { g--; } }
+      else { while (g > 1 && (lds = mv_lds_bytes(plan, g, coded, a.ndict, stage_elems, rp_cap)) > (size_t) 160 * 1024) { g--; } }
+      SpmvArgs c = a;
+      c.x = a.x + (size_t) v0 * xstride;
+      c.y = a.y + (size_t) v0 * ystride;
+      c.b = a.b ? a.b + (size_t) v0 * bstride : nullptr;
+      if (g == 1) { launch_spmv(plan, c, OP_AXPBY, s); v0 += 1; continue; }
+      c.rot = const_cast<SpmvPlan *>(plan)->launches++;
+      spmv_mv_launches()++;
+      // bytes: the matrix once (CSR count: 12 bytes per entry and the row pointers; streamed: what the x-staged form holds
+      // per entry and per tile), the vectors of every column
+      if (slice)
+      {
+         account_bytes(nz * 12.0 + 4.0 * (nr + 1.0) + g * vecs,
+                       (double) plan->sl_blocks * ((double) SPMV_THREADS * plan->sl_k * 3.0 + 4.0 * (XS_DESC + 4) + 8.0 * a.ndict + 4.0 * 72.0) +
+                       4.0 * (nr + 1.0) + g * vecs);
+         switch (g)
+         {
+            case 2:  launch_sl_mv_nv<2>(plan, c, stage_elems, lds, xstride, bstride, ystride, s); break;
+            case 3:  launch_sl_mv_nv<3>(plan, c, stage_elems, lds, xstride, bstride, ystride, s); break;
+            default: launch_sl_mv_nv<4>(plan, c, stage_elems, lds, xstride, bstride, ystride, s); break;
+         }
+         v0 += g;
+         continue;
+      }
+      account_bytes(nz * 12.0 + 4.0 * (nr + 1.0) + g * vecs,
+                    nz * ((coded ? 1.0 : 8.0) + 2.0) + 4.0 * (nr + 1.0) + g * vecs +
+                    (double) plan->num_tiles * (4.0 * (XS_DESC + 6) + (coded ? 8.0 * a.ndict + 4.0 * 72.0 : 0.0)));
+      switch (g)
+      {
+         case 2: if (coded) launch_xs_mv<2, true>(plan, c, stage_elems, MV_WIN, rp_cap, lds, xstride, bstride, ystride, s);
+                 else       launch_xs_mv<2, false>(plan, c, stage_elems, MV_WIN, rp_cap, lds, xstride, bstride, ystride, s); break;
+         case 3: if (coded) launch_xs_mv<3, true>(plan, c, stage_elems, MV_WIN, rp_cap, lds, xstride, bstride, ystride, s);
+                 else       launch_xs_mv<3, false>(plan, c, stage_elems, MV_WIN, rp_cap, lds, xstride, bstride, ystride, s); break;
+         default: if (coded) launch_xs_mv<4, true>(plan, c, stage_elems, MV_WIN, rp_cap, lds, xstride, bstride, ystride, s);
+                  else       launch_xs_mv<4, false>(plan, c, stage_elems, MV_WIN, rp_cap, lds, xstride, bstride, ystride, s); break;
+      }
+      v0 += g;
+   }
+   return true;
 }
 
 void launch_spmv_allrows_update(int num_rows, const SpmvArgs &args, hipStream_t s)

@@ -204,6 +204,13 @@ HYPRE_Int hypre_amd_SpmvSetSliceForm(HYPRE_Int on);
  * order.  mode 0 off, 1 owned / immutable matrices (default; environment HYPRE_AMD_SPMV_ROW_SLICES), 2 every matrix (the
  * caller then owes hypre_amd_CSRMatrixInvalidatePlan after any change of the arrays); < 0 unchanged.  Plans built afterwards. */
 HYPRE_Int hypre_amd_SpmvSetRowSlices(HYPRE_Int mode);
+/* Products with a multivector (num_vectors > 1, stored column by column): one pass over the matrix for up to four
+ * columns at a time where the matrix's plan has the x-staged form (default), or one pass per column (on = 0).  Speed
+ * only: the same bits.  Replaces the NV = 2, 3, 4 paths of seq_mv/csr_matvec.c:117-380 and the NV sums per row of
+ * seq_mv/csr_spmv_device.c:37-134. */
+HYPRE_Int hypre_amd_SpmvSetFusedMultivectors(HYPRE_Int on);
+/* Launches of the fused multivector kernel since the library was loaded (tests: which path served a product). */
+HYPRE_Int hypre_amd_SpmvFusedMultivectorLaunches(void);
 /* Lanes per row of the row-slice form in the plan of the device matrix A (0: none); fills the rows of a block and the most
  * entries a lane holds. */
 HYPRE_Int hypre_amd_CSRMatrixPlanRowSlices(hypre_CSRMatrix *A, HYPRE_Int *rows_per_block, HYPRE_Int *entries_per_lane);

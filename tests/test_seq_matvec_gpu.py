@@ -216,6 +216,81 @@ def test_multivectors_column_by_column(gpu_lib, oracle, par):
         assert np.all(np.abs(Z[:, k] - zr) <= _bound(A.T.tocsr(), X[:, k], -0.4, 0.5, Bm[:, k]))
 
 
+def _mv_matrix(what):
+    if what == "7pt":                       # coded (two values), rows of 4-7 entries: a lane per row
+        return laplace_3d(24, 22, 20), True
+    if what == "27pt":                      # coded, up to 27 entries per row: several lanes per row
+        return laplace_3d(16, 15, 14, stencil=27), True
+    if what == "coded_unequal":             # five values, rows of 3-40 entries: coded tiles (no slice form)
+        A = banded_csr(20000, 20000, 3, 40, 600, seed=8)
+        A.data[:] = np.array([6.0, -1.0, 0.25, -0.0, 3e-300])[np.random.default_rng(9).integers(0, 5, A.nnz)]
+        return A, True
+    if what == "banded_short":              # all values distinct, 3-11 entries per row
+        return banded_csr(30000, 30000, 3, 11, 700, seed=3, empty_frac=0.02), True
+    if what == "banded_long":               # 20-60 per row: 2 to 8 lanes per row, tile by tile
+        return banded_csr(9000, 9000, 20, 60, 500, seed=4), True
+    if what == "banded_rect":               # rectangular, rows up to the 256 the fused kernel takes, spills past the window
+        return banded_csr(3000, 5000, 100, 256, 900, seed=5), True
+    if what == "rows_too_long":             # rows of up to 400 entries: column by column
+        return banded_csr(3000, 5000, 100, 400, 900, seed=6), False
+    if what == "scattered":                 # columns all over a wide x: most tiles cannot be staged, column by column
+        return random_csr(4000, 400000, 10, 40, seed=7), False
+    if what == "odd_rows":                  # an odd number of rows: the second column of y and b is not 16-byte aligned (fine),
+        return laplace_3d(9, 7, 5), True    # of x as well (315 columns): column by column
+    raise ValueError(what)
+
+
+@pytest.mark.parametrize("what", ["7pt", "27pt", "coded_unequal", "banded_short", "banded_long", "banded_rect", "rows_too_long", "scattered", "odd_rows"])
+@pytest.mark.parametrize("nv,alpha,beta", [(2, 1.0, 0.0), (3, 0.7, -1.3), (4, -1.0, 1.0), (7, 2.5, 0.5)])
+def test_fused_multivector_products_have_the_bits_of_the_column_loop(gpu_lib, oracle, what, nv, alpha, beta):
+    """One pass over the matrix for up to four columns at a time (spmv_xs_mv_kernel; reference: csr_matvec.c:117-380,
+    csr_spmv_device.c:37-134) against one pass per column: the same bits in every column, for coded and fp64 matrices, a
+    lane or several lanes per row, spilling rows, 2 / 3 / 4 columns and 7 = 4 + 3; operands the fused kernel does not take
+    (rows over 256 entries, unstaged tiles, columns of x that are not 16-byte aligned) fall back to the loop; and every
+    column is the oracle's single-vector product."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    A, fused_expected = _mv_matrix(what)
+    if what == "odd_rows":
+        fused_expected = False
+    n, m = A.shape
+    X = np.stack([rand_vector(m, 10 + k) for k in range(nv)], axis=1)
+    Bm = np.stack([rand_vector(n, 20 + k) for k in range(nv)], axis=1)
+    dA = B.csr_from_scipy(A)
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.hypre_amd_SpmvSetFusedMultivectors(on)
+            _, vx = _multivector(B, X)
+            _, vb = _multivector(B, Bm)
+            _, vy = _multivector(B, np.full((n, nv), 7.0))
+            before = lib.hypre_amd_SpmvFusedMultivectorLaunches()
+            lib.hypre_CSRMatrixMatvecOutOfPlace(alpha, dA, vx, beta, vb, vy, 0)
+            B.check()
+            launches = lib.hypre_amd_SpmvFusedMultivectorLaunches() - before
+            # passes: four columns at a time over the tiles; threes and twos over the slice form (plan form 4)
+            passes = {2: 1, 3: 1, 4: 2, 7: 3}[nv] if lib.hypre_amd_CSRMatrixPlanForm(dA) == 4 else (nv + 3) // 4
+            assert launches == (passes if (on and fused_expected) else 0), (what, on, launches)
+            out[on] = _columns(B, vy)
+            # in place: Y = alpha A X + beta Y
+            lib.hypre_CSRMatrixMatvec(alpha, dA, vx, beta, vb)
+            B.check()
+            out[on, "inplace"] = _columns(B, vb)
+            for o in (vx, vb, vy):
+                lib.hypre_SeqVectorDestroy(o)
+    finally:
+        lib.hypre_amd_SpmvSetFusedMultivectors(1)
+    lib.hypre_CSRMatrixDestroy(dA)
+    assert np.array_equal(out[1].view(np.int64), out[0].view(np.int64))
+    assert np.array_equal(out[1, "inplace"].view(np.int64), out[0, "inplace"].view(np.int64))
+    assert np.array_equal(out[1].view(np.int64), out[1, "inplace"].view(np.int64))
+    oA = oracle.Csr.from_scipy(A)
+    for k in range(nv):
+        yr = np.zeros(n)
+        oracle.csr_matvec(alpha, oA, X[:, k].copy(), beta, Bm[:, k].copy(), yr)
+        assert np.all(np.abs(out[1][:, k] - yr) <= _bound(A, X[:, k], alpha, beta, Bm[:, k]))
+
+
 @pytest.mark.parametrize("total", [2049, 2050, 2051, 2052, 2053, 4099, 2048 + 255, 2048 + 256, 2048 + 257, 2048 + 600])
 def test_last_row_spills_past_the_streamed_window(gpu_lib, oracle, total):
     """The tiled kernel streams 2048 entries per tile and fetches what the tile's last row has beyond that window
