@@ -999,12 +999,9 @@ HYPRE_Int hypre_ParCSRMatrixMatvecTDevice(HYPRE_Complex alpha, hypre_ParCSRMatri
          }
          ch = hypre_ParCSRCommHandleCreate_v2(2, pkg, HYPRE_MEMORY_DEVICE, pkg->tmp_data, HYPRE_MEMORY_DEVICE, pkg->buf_data);
       }
-      for (HYPRE_Int v = 0; v < nv; v++)
-      {
-         hypre_Vector xv = column(xl, v), yv = column(yl, v);
-         if (A->diagT) { hypre_CSRMatrixMatvecDevice(0, alpha, A->diagT, &xv, beta, &yv, &yv, 0); }
-         else          { hypre_CSRMatrixMatvecDevice(1, alpha, diag, &xv, beta, &yv, &yv, 0); }
-      }
+      // the local block: all columns in one pass over the (stored or cached) transpose where its plan allows it
+      if (A->diagT) { hypre_CSRMatrixMatvecDevice(0, alpha, A->diagT, xl, beta, yl, yl, 0); }
+      else          { hypre_CSRMatrixMatvecDevice(1, alpha, diag, xl, beta, yl, yl, 0); }
       if (ch)
       {
          hypre_ParCSRCommHandleDestroy(ch);

@@ -84,6 +84,29 @@ class Problem:
         self.lib.hypre_ParVectorDestroy(dx); self.lib.hypre_ParVectorDestroy(dy)
         return y
 
+    def matvec_columns(self, X):
+        """Y = A X for the columns of X handed over as one multivector (stored column by column)."""
+        B, lib = self.B, self.lib
+        n, nv = X.shape
+
+        def mv(M):
+            pv = B.parvec_from_numpy(np.ascontiguousarray(M.T).ravel(), global_size=n)
+            pv.contents.partitioning[1] = n
+            pv.contents.last_index = n - 1
+            pv.contents.actual_local_size = n
+            v = pv.contents.local_vector.contents
+            v.size, v.num_vectors, v.vecstride, v.idxstride = n, nv, n, 1
+            return pv
+        dx, dy = mv(X), mv(np.zeros((n, nv)))
+        before = lib.hypre_amd_SpmvFusedMultivectorLaunches()
+        lib.hypre_ParCSRMatrixMatvec(1.0, self.A, dx, 0.0, dy)
+        B.check()
+        assert lib.hypre_amd_SpmvFusedMultivectorLaunches() > before          # the fused kernel served it
+        v = dy.contents.local_vector.contents
+        Y = B.fetch(v.data, n * nv, np.float64, v.memory_location).reshape(nv, n).T
+        lib.hypre_ParVectorDestroy(dx); lib.hypre_ParVectorDestroy(dy)
+        return Y
+
     def cycle(self, f):
         """u = B f: one V-cycle from a zero guess, as a preconditioner call."""
         df, du = self.vec(f), self.vec(np.zeros(self.n))
@@ -135,6 +158,11 @@ def _check_operator(p, kind):
     scale = np.linalg.norm(x) * np.linalg.norm(Ay)
     assert abs(np.dot(x, Ay) - np.dot(y, Ax)) <= 1e-13 * scale
     assert np.max(np.abs(p.matvec(x, transpose=True) - Ax)) <= 1e-13 * np.max(np.abs(Ax))
+    # the four vectors as ONE multivector (one pass over the matrix for its columns): the closed forms again, and the bits
+    # of the single-vector products
+    Y = p.matvec_columns(np.stack([np.ones(p.n), lin, x, y], axis=1))
+    assert np.array_equal(Y[:, 0], ones) and np.array_equal(Y[:, 1], y_lin)
+    assert np.array_equal(Y[:, 2].view(np.int64), Ax.view(np.int64)) and np.array_equal(Y[:, 3].view(np.int64), Ay.view(np.int64))
     return x, y
 
 
