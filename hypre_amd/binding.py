@@ -236,6 +236,8 @@ PROTOTYPES = {
     "hypre_ParCSRMatrixSetDNumNonzeros": (Int, [ParCSRp]),
     "hypre_amd_ParCSRMatrixKeepTranspose": (Int, [ParCSRp]),
     "hypre_ParVectorCreate": (ParVecp, [Int, BigInt, BigIntP]),
+    "hypre_ParMultiVectorCreate": (ParVecp, [Int, BigInt, BigIntP, Int]),
+    "hypre_ParCSRDiagScaleVector": (Int, [ParCSRp, ParVecp, ParVecp]),
     "hypre_ParVectorInitialize_v2": (Int, [ParVecp, Int]),
     "hypre_ParVectorInitialize": (Int, [ParVecp]),
     "hypre_ParVectorDestroy": (Int, [ParVecp]),
@@ -419,6 +421,28 @@ def parvec_from_numpy(x, comm=0, global_size=None, first=0, location=HYPRE_MEMOR
     v = lib.hypre_amd_ParVectorFromArray(comm, gs, _bp(part), _rp(x), location)
     check()
     return v
+
+
+def parmultivec_from_numpy(M, comm=0, global_size=None, first=0, location=HYPRE_MEMORY_DEVICE):
+    """ParVector of M.shape[1] columns (stored one after the other: parcsr_mv/par_vector.c:77-87) holding the local rows
+    M[:, v] of every column; global_size and first are the global length and this rank's first row of ONE column."""
+    M = np.asarray(M, dtype=np.float64)
+    n, nv = M.shape
+    part = np.array([first, first + n], dtype=np.int64)
+    gs = int(global_size if global_size is not None else n)
+    v = lib.hypre_ParMultiVectorCreate(comm, gs, _bp(part), nv)
+    lib.hypre_ParVectorInitialize_v2(v, location)
+    flat = np.ascontiguousarray(M.T).ravel()
+    if flat.size:
+        lib.hypre_Memcpy(C.cast(v.contents.local_vector.contents.data, C.c_void_p), flat.ctypes.data_as(C.c_void_p), flat.nbytes,
+                         location, HYPRE_MEMORY_HOST)
+    check()
+    return v
+
+
+def parmultivec_to_numpy(v):
+    l = v.contents.local_vector.contents
+    return fetch(l.data, l.size * l.num_vectors, np.float64, l.memory_location).reshape(l.num_vectors, l.size).T.copy()
 
 
 def parvec_to_numpy(v):

@@ -334,6 +334,7 @@ void launch_elmdivpy(const double *x, const double *d, double *y, const int *mar
                      size_t n, hipStream_t s);
 void launch_scaled_div(double w, const double *f, const double *d, double *u, const int *marker,
                        int mval, size_t n, hipStream_t s);   // u = w*f./d (zero-guess Jacobi)
+void launch_diag_first_scale(const int *Ai, const double *Aa, const double *y, double *x, size_t n, int nv, size_t ys, size_t xs, hipStream_t s);
 void launch_scaled_recip(double w, const double *f, const double *d, double *z, size_t n, hipStream_t s);   // z = (w*f) .* (1 ./ d)
 void launch_diagscale2(const double *diag, const double *x, double beta, double *y, double *z,
                        int computeY, size_t n, hipStream_t s);

@@ -480,6 +480,22 @@ void launch_scaled_div(double w, const double *f, const double *d, double *u, co
    if (!marker && aligned) { hipLaunchKernelGGL(scaled_div2_kernel, dim3(vec_grid(n)), dim3(256), 0, s, w, f, d, u, n); }
    else { hipLaunchKernelGGL(scaled_div_kernel, dim3(lin_grid(n)), dim3(256), 0, s, w, f, d, u, marker, mval, n); }
 }
+// x(:, v) = y(:, v) ./ (first entry of every row of A): hypre_ParCSRDiagScaleVector (par_csr_matop.c:6479-6575), the
+// preconditioner of the reference driver's DS-PCG / DS-GMRES; nv columns ys / xs doubles apart
+__global__ void diag_first_scale_kernel(const int *__restrict__ Ai, const double *__restrict__ Aa, const double *__restrict__ y,
+                                        double *__restrict__ x, size_t n, int nv, size_t ys, size_t xs)
+{
+   for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+   {
+      const double d = Aa[Ai[i]];
+      for (int v = 0; v < nv; v++) { x[(size_t) v * xs + i] = y[(size_t) v * ys + i] / d; }
+   }
+}
+void launch_diag_first_scale(const int *Ai, const double *Aa, const double *y, double *x, size_t n, int nv, size_t ys, size_t xs, hipStream_t s)
+{
+   account_bytes((12.0 + 16.0 * nv) * n);
+   if (n && nv > 0) { hipLaunchKernelGGL(diag_first_scale_kernel, dim3(lin_grid(n)), dim3(256), 0, s, Ai, Aa, y, x, n, nv, ys, xs); }
+}
 void launch_scaled_recip(double w, const double *f, const double *d, double *z, size_t n, hipStream_t s)
 {
    account_bytes(24.0 * n);

@@ -1122,7 +1122,9 @@ HYPRE_Int HYPRE_ParCSRPCGSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
    hypre_amd_PCGData *d = (hypre_amd_PCGData *) solver;
    hypre_ParVectorDestroy(d->p); hypre_ParVectorDestroy(d->s); hypre_ParVectorDestroy(d->r); hypre_ParVectorDestroy(d->r_old);
    const HYPRE_MemoryLocation loc = x->local_vector->memory_location;
-   auto mk = [&]() { hypre_ParVector *v = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts); hypre_ParVectorInitialize_v2(v, loc); return v; };
+   // work vectors shaped like x (krylov/pcg.c:226-260 CreateVector(x)): as many columns as a multivector x has (`ij -nc N`)
+   const HYPRE_Int nv = x->local_vector->num_vectors;
+   auto mk = [&]() { hypre_ParVector *v = hypre_ParMultiVectorCreate(A->comm, A->global_num_rows, A->row_starts, nv); hypre_ParVectorInitialize_v2(v, loc); return v; };
    d->p = mk(); d->s = mk(); d->r = mk();
    d->r_old = d->flex ? mk() : nullptr;
    if (!d->d_rr && loc == HYPRE_MEMORY_DEVICE) { d->d_rr = hypre_TAlloc(double, 2, HYPRE_MEMORY_DEVICE); }
@@ -1143,6 +1145,21 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       hypre_error_w_msg(HYPRE_ERROR_GENERIC, "HYPRE_ParCSRPCGSolve: call HYPRE_ParCSRPCGSetup after HYPRE_PCGSetFlex");
       return hypre_error_flag;
    }
+   // multivectors (`ij -nc N`, test/TEST_ij/vector.jobs): the reference's PCG works on whatever its vector functions take,
+   // and hypre_ParVector's take every column — one Krylov iteration over the columns together.  The fused updates below
+   // run over the columns' common storage, which has to be one piece.
+   const HYPRE_Int nvec = x->local_vector->num_vectors;
+   for (hypre_ParVector *v : {b, x, p, s, r})
+   {
+      const hypre_Vector *l = v->local_vector;
+      if (l->num_vectors != nvec || (nvec > 1 && (l->idxstride != 1 || l->vecstride != l->size)))
+      {
+         hypre_error_w_msg(HYPRE_ERROR_GENERIC, "HYPRE_ParCSRPCGSolve: b, x and the work vectors of HYPRE_ParCSRPCGSetup must have the same number of "
+                                                "columns, stored one after the other");
+         return hypre_error_flag;
+      }
+   }
+   const size_t vec_len = (size_t) r->local_vector->size * (size_t) nvec;
    const int saved_sync = handle().sync_compute;
    handle().sync_compute = 0;
    verify_par_plans(A);                    // a solve never starts from a plan its matrix has moved away from
@@ -1187,12 +1204,12 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       if (d->flex) { hypre_ParVectorCopy(r, d->r_old); }          // pcg.c:636-639
       double *d_rr = d->d_rr;
       launch_pcg_update(alpha, -alpha, p->local_vector->data, s->local_vector->data, x->local_vector->data,
-                        r->local_vector->data, (size_t) r->local_vector->size, d_rr, stream());
+                        r->local_vector->data, vec_len, d_rr, stream());
       x->all_zeros = 0; r->all_zeros = 0;
       precond(r, s);
       // gamma = <r, s> and, for the two-norm test, <r, r> (left on the device by the fused update): ONE all-reduce of
       // two values and one read-back per iteration (pcg.c:716-760 reduces them separately)
-      launch_dot(r->local_vector->data, s->local_vector->data, (size_t) r->local_vector->size, d_rr + 1, stream());
+      launch_dot(r->local_vector->data, s->local_vector->data, vec_len, d_rr + 1, stream());
       {
          double sums[2];
          dev_global_sums(r->comm, d_rr, 2, sums);
@@ -1204,7 +1221,7 @@ HYPRE_Int HYPRE_ParCSRPCGSolve(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_
       if (gamma <= 0.0) { hypre_error_w_msg(HYPRE_ERROR_CONV, "Negative or zero gamma value in PCG"); break; }
       beta = (d->flex ? delta : gamma) / gamma_old;                 // pcg.c:957-965
       // p = beta p + s in one pass (Scale then Axpy in the reference)
-      launch_pcg_direction(beta, s->local_vector->data, p->local_vector->data, (size_t) p->local_vector->size, stream());
+      launch_pcg_direction(beta, s->local_vector->data, p->local_vector->data, vec_len, stream());
    }
    if (i >= d->max_iter && (i_prod / bi_prod) >= eps && eps > 0)
    {

@@ -359,6 +359,14 @@ hypre_ParVector *hypre_ParVectorCreate(MPI_Comm comm, HYPRE_BigInt global_size, 
    return v;
 }
 
+// par_vector.c:77-87: global_size is the global length of ONE column
+hypre_ParVector *hypre_ParMultiVectorCreate(MPI_Comm comm, HYPRE_BigInt global_size, HYPRE_BigInt *partitioning_in, HYPRE_Int num_vectors)
+{
+   hypre_ParVector *v = hypre_ParVectorCreate(comm, global_size, partitioning_in);
+   v->local_vector->num_vectors = num_vectors;
+   return v;
+}
+
 HYPRE_Int hypre_ParVectorInitialize_v2(hypre_ParVector *v, HYPRE_MemoryLocation loc)
 {
    hypre_SeqVectorInitialize_v2(v->local_vector, loc);
@@ -444,6 +452,43 @@ HYPRE_Real hypre_ParVectorInnerProd(hypre_ParVector *x, hypre_ParVector *y)
    dev_global_sums(x->comm, d_out, 1, &r);
    return r;
 }
+// x = y ./ diag(A), column by column of a multivector (par_csr_matop.c:6479-6658: the first entry of every row of the local
+// block is its diagonal)
+HYPRE_Int hypre_ParCSRDiagScaleVector(hypre_ParCSRMatrix *A, hypre_ParVector *par_y, hypre_ParVector *par_x)
+{
+   hypre_CSRMatrix *diag = A->diag;
+   hypre_Vector *x = par_x->local_vector, *y = par_y->local_vector;
+   if (x->num_vectors != y->num_vectors) { hypre_error_w_msg(HYPRE_ERROR_GENERIC, "Error! incompatible number of vectors!\n"); return hypre_error_flag; }
+   if (diag->num_rows != x->size) { hypre_error_w_msg(HYPRE_ERROR_GENERIC, "Error! incompatible x size!\n"); return hypre_error_flag; }
+   if (x->size > 0 && x->vecstride <= 0) { hypre_error_w_msg(HYPRE_ERROR_GENERIC, "Error! non-positive x vector stride!\n"); return hypre_error_flag; }
+   if (y->size > 0 && y->vecstride <= 0) { hypre_error_w_msg(HYPRE_ERROR_GENERIC, "Error! non-positive y vector stride!\n"); return hypre_error_flag; }
+   if (diag->num_rows != y->size) { hypre_error_w_msg(HYPRE_ERROR_GENERIC, "Error! incompatible y size!\n"); return hypre_error_flag; }
+   HYPRE_AMD_REQUIRE_DEVICE(diag->memory_location, "hypre_ParCSRDiagScaleVector(A)");
+   HYPRE_AMD_REQUIRE_DEVICE(x->memory_location, "hypre_ParCSRDiagScaleVector(x)");
+   HYPRE_AMD_REQUIRE_DEVICE(y->memory_location, "hypre_ParCSRDiagScaleVector(y)");
+   if (x->num_vectors > 1 && (x->idxstride != 1 || y->idxstride != 1))
+   {
+      hypre_error_w_msg(HYPRE_ERROR_GENERIC, "hypre_ParCSRDiagScaleVector: row-wise multivector storage is not supported");
+      return hypre_error_flag;
+   }
+   launch_diag_first_scale(diag->i, diag->data, y->data, x->data, (size_t) diag->num_rows, x->num_vectors,
+                           (size_t) y->vecstride, (size_t) x->vecstride, stream());
+   par_x->all_zeros = 0;
+   maybe_sync();
+   return hypre_error_flag;
+}
+// parcsr_ls/HYPRE_parcsr_pcg.c: the diagonal-scaling preconditioner of the Krylov drivers (`ij -solver 2`)
+HYPRE_Int HYPRE_ParCSRDiagScaleSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPRE_ParVector y, HYPRE_ParVector x)
+{
+   (void) solver; (void) A; (void) y; (void) x;
+   return hypre_error_flag;
+}
+HYPRE_Int HYPRE_ParCSRDiagScale(HYPRE_Solver solver, HYPRE_ParCSRMatrix HA, HYPRE_ParVector Hy, HYPRE_ParVector Hx)
+{
+   (void) solver;
+   return hypre_ParCSRDiagScaleVector(HA, Hy, Hx);
+}
+
 HYPRE_Int hypre_ParVectorElmdivpy(hypre_ParVector *x, hypre_ParVector *b, hypre_ParVector *y)
 {
    return hypre_SeqVectorElmdivpy(x->local_vector, b->local_vector, y->local_vector);

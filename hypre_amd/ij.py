@@ -25,7 +25,8 @@ class IJOptions:
         self.sys_num_fun = 1          # -sysL <num functions>: systems version of the 7-point operator
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
-        self.solver = 0               # 0 AMG, 1 AMG-PCG, 3 AMG-GMRES
+        self.solver = 0               # 0 AMG, 1 AMG-PCG, 2 DS-PCG (diagonal scaling), 3 AMG-GMRES
+        self.num_components = 1       # -nc: columns of b and x (multivectors; test/ij.c:874-878, 3400-3404)
         self.k_dim = 5                # -k (GMRES restart length, test/ij.c:1731)
         self.flex = 0                 # -flex (flexible PCG: Polak-Ribiere beta)
         self.rhs = "one"              # one (-rhsisone default) | rand (-rhsrand) | xisone
@@ -294,7 +295,7 @@ _VALUE_FLAGS = {
     "-tr": ("trunc_factor", float, 1), "-Pmx": ("P_max_elmts", int, 1), "-interptype": ("interp_type", int, 1),
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
-    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nf": ("num_functions", int, 1), "-flex": ("flex", int, 1),
+    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nc": ("num_components", int, 1), "-nf": ("num_functions", int, 1), "-flex": ("flex", int, 1),
     "-alpha": ("alpha", float, 1), "-eps": ("eps", float, 1), "-sysL": ("sys_num_fun", int, 1), "-ff": ("filter_functions", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),
@@ -346,8 +347,12 @@ def parse_cli(argv):
             i += 3
         else:
             raise SystemExit("ij: option %s is outside the scope of this driver" % flag)
-    if opt.solver not in (0, 1, 3):
-        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 3 AMG-GMRES)" % opt.solver)
+    if opt.solver not in (0, 1, 2, 3):
+        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 2 DS-PCG, 3 AMG-GMRES)" % opt.solver)
+    if opt.num_components < 1 or (opt.num_components > 1 and (opt.solver != 2 or opt.rhs != "one" or opt.rhsfromfile)):
+        # test/ij.c:3400-3404 takes several components with the constant right-hand sides only; of the solvers that accept
+        # multivectors (test/TEST_ij/vector.jobs) this driver has the diagonally scaled PCG
+        raise SystemExit("ij: -nc %d needs -solver 2 and -rhsisone in this driver" % opt.num_components)
     if opt.interp_type not in (6, 3):
         raise SystemExit("ij: -interptype %d is outside the scope of this driver (6 ext+i, 3 direct)" % opt.interp_type)
     smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 88, 89)
@@ -368,6 +373,8 @@ def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
     out = out or sys.stdout
     L = B.load_library()
     A = build_matrix(opt, comm=comm, rank=rank, nprocs=nprocs)
+    if opt.solver == 2:
+        return run_ds_pcg(opt, A, comm=comm, rank=rank, allreduce=allreduce, out=out)
     s = create_amg(opt, memory_location=DEVICE)
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
     B.check()
@@ -432,6 +439,57 @@ def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
         out.write("\n".join(lines) + "\n")
         out.flush()
     return its.value, rel.value
+
+
+def solve_ds_pcg(opt, A, db, dx, comm=0):
+    """test/ij.c:5007-5027, 5179-5191: PCG with the diagonal scaling preconditioner (solver 2); db and dx may be
+    multivectors (-nc N)."""
+    L = B.load_library()
+    pcg = C.c_void_p()
+    L.HYPRE_ParCSRPCGCreate(comm, C.byref(pcg))
+    L.HYPRE_PCGSetTol(pcg, opt.tol)
+    L.HYPRE_PCGSetMaxIter(pcg, opt.max_iter)
+    L.HYPRE_PCGSetTwoNorm(pcg, opt.two_norm)
+    L.HYPRE_PCGSetFlex(pcg, opt.flex)
+    L.HYPRE_PCGSetPrecond(pcg, C.cast(L.HYPRE_ParCSRDiagScale, C.c_void_p), C.cast(L.HYPRE_ParCSRDiagScaleSetup, C.c_void_p), None)
+    L.HYPRE_ParCSRPCGSetup(pcg, A, db, dx)
+    L.HYPRE_ParCSRPCGSolve(pcg, A, db, dx)
+    its, rel = C.c_int(), C.c_double()
+    L.HYPRE_PCGGetNumIterations(pcg, C.byref(its))
+    L.HYPRE_PCGGetFinalRelativeResidualNorm(pcg, C.byref(rel))
+    L.HYPRE_ParCSRPCGDestroy(pcg)
+    return its.value, rel.value
+
+
+def run_ds_pcg(opt, A, comm=0, rank=0, allreduce=None, out=None):
+    """`ij -solver 2 [-nc N]` on the device: no hierarchy; the N columns of b (test/ij.c:3483-3512: the same values in
+    every component) and of the zero initial guess as multivectors."""
+    L = B.load_library()
+    L.hypre_ParCSRMatrixMigrate(A, DEVICE)
+    Am = A.contents
+    first, nglob = int(Am.row_starts[0]), int(Am.global_num_rows)
+    b, x0 = build_rhs_host(opt, A, rank=rank, allreduce=allreduce)
+    nv = opt.num_components
+    if b is None:
+        ones = B.parvec_from_numpy(np.ones(len(x0)), comm=comm, global_size=nglob, first=first)
+        db1 = B.parvec_from_numpy(np.zeros(len(x0)), comm=comm, global_size=nglob, first=first)
+        L.hypre_ParCSRMatrixMatvec(1.0, A, ones, 0.0, db1)
+        b = B.parvec_to_numpy(db1)
+        L.hypre_ParVectorDestroy(ones); L.hypre_ParVectorDestroy(db1)
+    if nv > 1:
+        db = B.parmultivec_from_numpy(np.repeat(b[:, None], nv, axis=1), comm=comm, global_size=nglob, first=first)
+        dx = B.parmultivec_from_numpy(np.repeat(x0[:, None], nv, axis=1), comm=comm, global_size=nglob, first=first)
+    else:
+        db = B.parvec_from_numpy(b, comm=comm, global_size=nglob, first=first)
+        dx = B.parvec_from_numpy(x0, comm=comm, global_size=nglob, first=first)
+    its, rel = solve_ds_pcg(opt, A, db, dx, comm=comm)
+    L.HYPRE_ClearError(256)
+    B.check()
+    L.hypre_ParVectorDestroy(db); L.hypre_ParVectorDestroy(dx)
+    if rank == 0:
+        out.write("\n".join(["", "Iterations = %d" % its, "Final Relative Residual Norm = %e" % rel, ""]) + "\n")
+        out.flush()
+    return its, rel
 
 
 def solve_gmres(opt, amg, A, b, x, comm=0):

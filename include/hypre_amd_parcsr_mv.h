@@ -182,7 +182,12 @@ HYPRE_Int hypre_ParCSRMatrixSetDNumNonzeros(hypre_ParCSRMatrix *matrix);
 HYPRE_Int hypre_amd_ParCSRMatrixKeepTranspose(hypre_ParCSRMatrix *A);
 
 hypre_ParVector *hypre_ParVectorCreate(MPI_Comm comm, HYPRE_BigInt global_size, HYPRE_BigInt *partitioning_in);
+/* parcsr_mv/par_vector.c:77-87 (global_size: the global length of one column; columns stored one after the other) */
+hypre_ParVector *hypre_ParMultiVectorCreate(MPI_Comm comm, HYPRE_BigInt global_size, HYPRE_BigInt *partitioning_in,
+                                            HYPRE_Int num_vectors);
 HYPRE_Int hypre_ParVectorInitialize_v2(hypre_ParVector *vector, HYPRE_MemoryLocation memory_location);
+/* x = y ./ diag(A), every column of a multivector (parcsr_mv/par_csr_matop.c:6479-6658) */
+HYPRE_Int hypre_ParCSRDiagScaleVector(hypre_ParCSRMatrix *par_A, hypre_ParVector *par_y, hypre_ParVector *par_x);
 HYPRE_Int hypre_ParVectorInitialize(hypre_ParVector *vector);
 HYPRE_Int hypre_ParVectorDestroy(hypre_ParVector *vector);
 HYPRE_Int hypre_ParVectorSetLocalSize(hypre_ParVector *vector, HYPRE_Int local_size);

@@ -1145,6 +1145,89 @@ int oracle_pcg_amg_flex(const oamg *amg, const double *b, double *x, double r_to
 }
 
 /* ------------------------------------------------------------------------- */
+/* PCG on a multivector with the diagonal scaling preconditioner: the          */
+/* reference driver's DS-PCG (`ij -solver 2 -nc N`, test/ij.c:5007-5191) —     */
+/* hypre_PCGSolve (krylov/pcg.c:318-1000) over vectors of nv columns, whose    */
+/* functions (parcsr_ls/par_krylov_func.c) take every column at once: the      */
+/* products column by column (seq_mv/csr_matvec.c:117-380 forms each column's  */
+/* sums as the single-vector loop does), ONE inner product over all columns   */
+/* (par_vector.c:513-533 over size * num_vectors), x = y ./ diag(A) per column */
+/* (hypre_ParCSRDiagScaleVector, par_csr_matop.c:6479-6575: the first entry of */
+/* a row of the local block).  b, x: nv columns of n global rows, one after    */
+/* the other.  Pinned by test/TEST_ij/vector.saved (B0, B6 - B10, B100 - B110). */
+/* ------------------------------------------------------------------------- */
+static void ds_columns(const opar *A, const double *y, double *x, long long n, int nv)
+{
+   for (int rk = 0; rk < A->nranks; rk++)
+   {
+      const ocsr *D = &A->diag[rk];
+      const long long r0 = A->row_starts[rk];
+      for (int i = 0; i < D->nrows; i++)
+      {
+         const double d = D->a[D->i[i]];
+         for (int v = 0; v < nv; v++) { x[(long long) v * n + r0 + i] = y[(long long) v * n + r0 + i] / d; }
+      }
+   }
+}
+int oracle_pcg_ds_multi(const opar *A, const double *b, double *x, int nv, double r_tol, double a_tol, int max_iter,
+                        int two_norm, double *rel_resid_out, int *converged_out)
+{
+   const long long n = A->row_starts[A->nranks], N = n * nv;
+   double *p = (double *) calloc((size_t) N, sizeof(double));
+   double *s = (double *) calloc((size_t) N, sizeof(double));
+   double *r = (double *) calloc((size_t) N, sizeof(double));
+   double bi_prod, eps, gamma, gamma_old, alpha, beta, sdotp, i_prod = 0.0, i_prod_0 = 0.0;
+   int i = 0, converged = 0;
+#define MATVEC_COLS(al, xx, be, yy) do { for (int v_ = 0; v_ < nv; v_++) { oracle_par_matvec((al), A, (xx) + v_ * n, (be), (yy) + v_ * n, (yy) + v_ * n); } } while (0)
+   if (two_norm) { bi_prod = oracle_inner_prod(b, b, N); }
+   else { ds_columns(A, b, p, n, nv); bi_prod = oracle_inner_prod(p, b, N); }
+   eps = r_tol * r_tol;
+   if (bi_prod > 0.0)
+   {
+      const double e2 = a_tol * a_tol / bi_prod;
+      eps = (r_tol * r_tol > e2) ? r_tol * r_tol : e2;
+   }
+   else
+   {
+      memcpy(x, b, sizeof(double) * (size_t) N);
+      if (rel_resid_out) { *rel_resid_out = 0.0; }
+      if (converged_out) { *converged_out = 0; }
+      free(p); free(s); free(r);
+      return 0;
+   }
+   memcpy(r, b, sizeof(double) * (size_t) N);
+   MATVEC_COLS(-1.0, x, 1.0, r);
+   ds_columns(A, r, p, n, nv);
+   gamma = oracle_inner_prod(r, p, N);
+   i_prod_0 = two_norm ? oracle_inner_prod(r, r, N) : gamma;
+   while ((i + 1) <= max_iter)
+   {
+      i++;
+      MATVEC_COLS(1.0, p, 0.0, s);
+      sdotp = oracle_inner_prod(s, p, N);
+      if (sdotp == 0.0) { if (i == 1) { i_prod = i_prod_0; } break; }
+      alpha = gamma / sdotp;
+      if (alpha <= 0.0) { if (i == 1) { i_prod = i_prod_0; } break; }
+      gamma_old = gamma;
+      oracle_axpy(alpha, p, x, N);
+      oracle_axpy(-alpha, s, r, N);
+      ds_columns(A, r, s, n, nv);
+      gamma = oracle_inner_prod(r, s, N);
+      i_prod = two_norm ? oracle_inner_prod(r, r, N) : gamma;
+      if (i_prod / bi_prod < eps) { converged = 1; break; }
+      if (gamma <= 0.0) { break; }
+      beta = gamma / gamma_old;
+      oracle_scale(beta, p, N);
+      oracle_axpy(1.0, s, p, N);
+   }
+#undef MATVEC_COLS
+   if (rel_resid_out) { *rel_resid_out = sqrt(i_prod / bi_prod); }
+   if (converged_out) { *converged_out = converged; }
+   free(p); free(s); free(r);
+   return i;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Right-preconditioned restarted GMRES with the AMG cycle as preconditioner  */
 /* (krylov/gmres.c:274-1000 with the defaults rel_change = 0, cf_tol = 0,     */
 /* skip_real_r_check = 0, min_iter = 0, hybrid = 0; modified Gram-Schmidt,    */

@@ -97,6 +97,8 @@ def load():
     L.oracle_gmres_amg.restype = C.c_int
     L.oracle_gmres_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                    RealP, IntP]
+    L.oracle_pcg_ds_multi.restype = C.c_int
+    L.oracle_pcg_ds_multi.argtypes = [P(OPAR), RealP, RealP, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, RealP, IntP]
     _lib = L
     return L
 
@@ -276,6 +278,19 @@ def csr_matvecT(alpha, A, x, beta, y):
 
 def par_matvec(alpha, A, x, beta, b, y):
     return load().oracle_par_matvec(alpha, C.byref(A.c), _rp(x), beta, _rp(b), _rp(y))
+
+
+def pcg_ds_multi(A, B_cols, X_cols, tol=1e-8, atol=0.0, max_iter=1000, two_norm=1):
+    """DS-PCG on the multivector whose columns are the columns of B_cols (n x nv), started from X_cols (n x nv, overwritten
+    with the solution): `ij -solver 2 -nc nv`.  Returns (iterations, final relative residual, converged)."""
+    n, nv = B_cols.shape
+    b = np.ascontiguousarray(B_cols.T, dtype=np.float64).ravel()
+    x = np.ascontiguousarray(X_cols.T, dtype=np.float64).ravel()
+    rel = C.c_double(0.0)
+    conv = C.c_int(0)
+    its = load().oracle_pcg_ds_multi(C.byref(A.c), _rp(b), _rp(x), nv, tol, atol, max_iter, two_norm, C.byref(rel), C.byref(conv))
+    X_cols[:, :] = x.reshape(nv, n).T
+    return its, rel.value, conv.value
 
 
 def par_matvecT(alpha, A, x, beta, y):

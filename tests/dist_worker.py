@@ -127,6 +127,46 @@ def compare_setup(case, L, B, ij, O, dist, comm, rank, world):
         print("RESULT " + json.dumps(out), flush=True)
 
 
+def run_ds_pcg_case(case, opt, A, device, L, B, ij, O, dist, comm, rank, world):
+    """`ij -solver 2 -nc N` (test/TEST_ij/vector.jobs): PCG with diagonal scaling on a multivector of N columns — no
+    hierarchy.  The CPU oracle solves the gathered problem; with "device" the library solves it too, distributed, on the
+    GPU (multivector products with one halo exchange for all columns, fused over the columns on the local block)."""
+    nv = opt.num_components
+    b, x = ij.build_rhs_host(opt, A, rank=rank)
+    mine = dict(h=O.export_par(A), b=b, x=x)
+    if device:
+        Am = A.contents
+        first, nglob = int(Am.row_starts[0]), int(Am.global_num_rows)
+        L.hypre_ParCSRMatrixMigrate(A, B.HYPRE_MEMORY_DEVICE)
+        db = B.parmultivec_from_numpy(np.repeat(b[:, None], nv, axis=1), comm=comm, global_size=nglob, first=first)
+        dx = B.parmultivec_from_numpy(np.repeat(x[:, None], nv, axis=1), comm=comm, global_size=nglob, first=first)
+        fused_before = L.hypre_amd_SpmvFusedMultivectorLaunches()
+        its, rel = ij.solve_ds_pcg(opt, A, db, dx, comm=comm)
+        L.HYPRE_ClearError(256)
+        B.check()
+        mine.update(dev_its=its, dev_rel=rel, dev_x=B.parmultivec_to_numpy(dx),
+                    fused=int(L.hypre_amd_SpmvFusedMultivectorLaunches() - fused_before))
+        L.hypre_ParVectorDestroy(db); L.hypre_ParVectorDestroy(dx)
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0)
+    if rank == 0:
+        Ao = O.par_from_exports([p["h"] for p in parts])
+        bg = np.concatenate([p["b"] for p in parts]); xg = np.concatenate([p["x"] for p in parts])
+        X = np.repeat(xg[:, None], nv, axis=1)
+        its, rel, conv = O.pcg_ds_multi(Ao, np.repeat(bg[:, None], nv, axis=1), X, tol=opt.tol, max_iter=opt.max_iter,
+                                        two_norm=opt.two_norm)
+        out = {"iterations": its, "rel_resid": rel}
+        if device:
+            Xd = np.concatenate([p["dev_x"] for p in parts])
+            out.update(dev_iterations=parts[0]["dev_its"], dev_rel_resid=parts[0]["dev_rel"],
+                       x_err=float(np.max(np.abs(Xd - X)) / np.max(np.abs(X))), fused=[p["fused"] for p in parts])
+        if "name" in case:
+            out["name"] = case["name"]
+        print("RESULT " + json.dumps(out), flush=True)
+    L.hypre_ParCSRMatrixDestroy(A)
+    B.check()
+
+
 def run_case(case, L, B, ij, O, dist, comm, rank, world):
     if case.get("compare_setup"):
         return compare_setup(case, L, B, ij, O, dist, comm, rank, world)
@@ -136,6 +176,8 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             setattr(opt, name, os.path.join(ROOT, "tests", "golden", "ij_files", getattr(opt, name)))
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
     device = bool(case.get("device", 0))
+    if opt.solver == 2:
+        return run_ds_pcg_case(case, opt, A, device, L, B, ij, O, dist, comm, rank, world)
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE if device else B.HYPRE_MEMORY_HOST)
     if "replicate" in case:
         L.hypre_amd_BoomerAMGSetReplicateThreshold(s, int(case["replicate"]))

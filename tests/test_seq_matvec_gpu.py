@@ -276,6 +276,11 @@ def test_fused_multivector_products_have_the_bits_of_the_column_loop(gpu_lib, or
             lib.hypre_CSRMatrixMatvec(alpha, dA, vx, beta, vb)
             B.check()
             out[on, "inplace"] = _columns(B, vb)
+            if n == m:
+                # x is y (the host routine clones x: csr_matvec.c:109-113): X <- alpha A X + beta X
+                lib.hypre_CSRMatrixMatvec(alpha, dA, vx, beta, vx)
+                B.check()
+                out[on, "aliased"] = _columns(B, vx)
             for o in (vx, vb, vy):
                 lib.hypre_SeqVectorDestroy(o)
     finally:
@@ -284,6 +289,10 @@ def test_fused_multivector_products_have_the_bits_of_the_column_loop(gpu_lib, or
     assert np.array_equal(out[1].view(np.int64), out[0].view(np.int64))
     assert np.array_equal(out[1, "inplace"].view(np.int64), out[0, "inplace"].view(np.int64))
     assert np.array_equal(out[1].view(np.int64), out[1, "inplace"].view(np.int64))
+    if n == m:
+        assert np.array_equal(out[1, "aliased"].view(np.int64), out[0, "aliased"].view(np.int64))
+        ref = alpha * (A @ X) + beta * X
+        assert np.all(np.abs(out[1, "aliased"] - ref) <= np.stack([_bound(A, X[:, k], alpha, beta, X[:, k]) for k in range(nv)], axis=1))
     oA = oracle.Csr.from_scipy(A)
     for k in range(nv):
         yr = np.zeros(n)
