@@ -95,7 +95,9 @@ HYPRE_Int HYPRE_ParCSRGMRESSetup(HYPRE_Solver solver, HYPRE_ParCSRMatrix A, HYPR
    hypre_amd_GMRESData *d = (hypre_amd_GMRESData *) solver;
    free_vectors(d);
    const HYPRE_MemoryLocation loc = x->local_vector->memory_location;
-   auto mk = [&]() { hypre_ParVector *v = hypre_ParVectorCreate(A->comm, A->global_num_rows, A->row_starts); hypre_ParVectorInitialize_v2(v, loc); return v; };
+   // work vectors shaped like x (gmres.c:204-215 CreateVector / CreateVectorArray): the columns of a multivector x
+   const HYPRE_Int nv = x->local_vector->num_vectors;
+   auto mk = [&]() { hypre_ParVector *v = hypre_ParMultiVectorCreate(A->comm, A->global_num_rows, A->row_starts, nv); hypre_ParVectorInitialize_v2(v, loc); return v; };
    d->r = mk(); d->w = mk();
    for (HYPRE_Int i = 0; i <= d->k_dim; i++) { d->p.push_back(mk()); }
    if (d->precond_setup) { d->precond_setup(d->precond_data, A, b, x); }

@@ -25,7 +25,7 @@ class IJOptions:
         self.sys_num_fun = 1          # -sysL <num functions>: systems version of the 7-point operator
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
-        self.solver = 0               # 0 AMG, 1 AMG-PCG, 2 DS-PCG (diagonal scaling), 3 AMG-GMRES
+        self.solver = 0               # 0 AMG, 1 AMG-PCG, 2 DS-PCG (diagonal scaling), 3 AMG-GMRES, 4 DS-GMRES
         self.num_components = 1       # -nc: columns of b and x (multivectors; test/ij.c:874-878, 3400-3404)
         self.k_dim = 5                # -k (GMRES restart length, test/ij.c:1731)
         self.flex = 0                 # -flex (flexible PCG: Polak-Ribiere beta)
@@ -347,12 +347,12 @@ def parse_cli(argv):
             i += 3
         else:
             raise SystemExit("ij: option %s is outside the scope of this driver" % flag)
-    if opt.solver not in (0, 1, 2, 3):
-        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 2 DS-PCG, 3 AMG-GMRES)" % opt.solver)
-    if opt.num_components < 1 or (opt.num_components > 1 and (opt.solver != 2 or opt.rhs != "one" or opt.rhsfromfile)):
+    if opt.solver not in (0, 1, 2, 3, 4):
+        raise SystemExit("ij: -solver %d is outside the scope of this driver (0 AMG, 1 AMG-PCG, 2 DS-PCG, 3 AMG-GMRES, 4 DS-GMRES)" % opt.solver)
+    if opt.num_components < 1 or (opt.num_components > 1 and (opt.solver not in (2, 4) or opt.rhs != "one" or opt.rhsfromfile)):
         # test/ij.c:3400-3404 takes several components with the constant right-hand sides only; of the solvers that accept
         # multivectors (test/TEST_ij/vector.jobs) this driver has the diagonally scaled PCG
-        raise SystemExit("ij: -nc %d needs -solver 2 and -rhsisone in this driver" % opt.num_components)
+        raise SystemExit("ij: -nc %d needs -solver 2 or 4 and -rhsisone in this driver" % opt.num_components)
     if opt.interp_type not in (6, 3):
         raise SystemExit("ij: -interptype %d is outside the scope of this driver (6 ext+i, 3 direct)" % opt.interp_type)
     smoothers = (-1, 0, 3, 4, 6, 7, 8, 11, 12, 13, 14, 15, 16, 17, 18, 88, 89)
@@ -373,7 +373,7 @@ def run(opt, comm=0, rank=0, nprocs=1, allreduce=None, out=None):
     out = out or sys.stdout
     L = B.load_library()
     A = build_matrix(opt, comm=comm, rank=rank, nprocs=nprocs)
-    if opt.solver == 2:
+    if opt.solver in (2, 4):
         return run_ds_pcg(opt, A, comm=comm, rank=rank, allreduce=allreduce, out=out)
     s = create_amg(opt, memory_location=DEVICE)
     L.HYPRE_BoomerAMGSetup(s, A, None, None)
@@ -461,8 +461,27 @@ def solve_ds_pcg(opt, A, db, dx, comm=0):
     return its.value, rel.value
 
 
+def solve_ds_gmres(opt, A, db, dx, comm=0):
+    """test/ij.c:6710-6727, 6932-6942: GMRES(k) with the diagonal scaling preconditioner (solver 4); multivectors as above."""
+    L = B.load_library()
+    g = C.c_void_p()
+    L.HYPRE_ParCSRGMRESCreate(comm, C.byref(g))
+    L.HYPRE_GMRESSetKDim(g, opt.k_dim)
+    L.HYPRE_GMRESSetMaxIter(g, opt.max_iter)
+    L.HYPRE_GMRESSetTol(g, opt.tol)
+    L.HYPRE_GMRESSetAbsoluteTol(g, 0.0)
+    L.HYPRE_GMRESSetPrecond(g, C.cast(L.HYPRE_ParCSRDiagScale, C.c_void_p), C.cast(L.HYPRE_ParCSRDiagScaleSetup, C.c_void_p), None)
+    L.HYPRE_ParCSRGMRESSetup(g, A, db, dx)
+    L.HYPRE_ParCSRGMRESSolve(g, A, db, dx)
+    its, rel = C.c_int(), C.c_double()
+    L.HYPRE_GMRESGetNumIterations(g, C.byref(its))
+    L.HYPRE_GMRESGetFinalRelativeResidualNorm(g, C.byref(rel))
+    L.HYPRE_ParCSRGMRESDestroy(g)
+    return its.value, rel.value
+
+
 def run_ds_pcg(opt, A, comm=0, rank=0, allreduce=None, out=None):
-    """`ij -solver 2 [-nc N]` on the device: no hierarchy; the N columns of b (test/ij.c:3483-3512: the same values in
+    """`ij -solver 2 | 4 [-nc N]` on the device: no hierarchy; the N columns of b (test/ij.c:3483-3512: the same values in
     every component) and of the zero initial guess as multivectors."""
     L = B.load_library()
     L.hypre_ParCSRMatrixMigrate(A, DEVICE)
@@ -482,12 +501,13 @@ def run_ds_pcg(opt, A, comm=0, rank=0, allreduce=None, out=None):
     else:
         db = B.parvec_from_numpy(b, comm=comm, global_size=nglob, first=first)
         dx = B.parvec_from_numpy(x0, comm=comm, global_size=nglob, first=first)
-    its, rel = solve_ds_pcg(opt, A, db, dx, comm=comm)
+    its, rel = (solve_ds_gmres if opt.solver == 4 else solve_ds_pcg)(opt, A, db, dx, comm=comm)
     L.HYPRE_ClearError(256)
     B.check()
     L.hypre_ParVectorDestroy(db); L.hypre_ParVectorDestroy(dx)
     if rank == 0:
-        out.write("\n".join(["", "Iterations = %d" % its, "Final Relative Residual Norm = %e" % rel, ""]) + "\n")
+        tag = "GMRES " if opt.solver == 4 else ""
+        out.write("\n".join(["", "%sIterations = %d" % (tag, its), "Final %sRelative Residual Norm = %e" % (tag, rel), ""]) + "\n")
         out.flush()
     return its, rel
 

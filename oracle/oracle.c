@@ -1235,11 +1235,13 @@ int oracle_pcg_ds_multi(const opar *A, const double *b, double *x, int nv, doubl
 /* Returns the iteration count; *rel_resid_out = |r| / |b| as the driver      */
 /* prints it ("Final GMRES Relative Residual Norm").                          */
 /* ------------------------------------------------------------------------- */
-int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
-                     int k_dim, int precond_cycles, double *rel_resid_out, int *converged_out)
+/* the loop, over vectors of nv columns of nrow rows each; amg != NULL: the AMG cycle as preconditioner (nv = 1), else the
+ * diagonal scaling of every column (`ij -solver 4 -nc N`: DS-GMRES on multivectors, test/TEST_ij/vector.jobs) */
+static int gmres_core(const oamg *amg, const opar *A, int nv, const double *b, double *x, double r_tol, double a_tol, int max_iter,
+                      int k_dim, int precond_cycles, double *rel_resid_out, int *converged_out)
 {
-   const opar *A = amg->A_outer ? amg->A_outer : &amg->A[0];
-   const long long n = A->row_starts[A->nranks];
+   const long long nrow = A->row_starts[A->nranks];
+   const long long n = nrow * nv;
    const double epsmac = 1.e-16;
    double **p = (double **) calloc((size_t) k_dim + 1, sizeof(double *));
    double **hh = (double **) calloc((size_t) k_dim + 1, sizeof(double *));
@@ -1259,11 +1261,13 @@ int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, 
 #define PRECOND(rhs, sol)                                                                  \
    do {                                                                                    \
       for (long long q_ = 0; q_ < n; q_++) { (sol)[q_] = 0.0; }                            \
-      oracle_amg_solve(amg, (rhs), (sol), 0.0, 0, precond_cycles, 0, 1, NULL, NULL, NULL); \
+      if (amg) { oracle_amg_solve(amg, (rhs), (sol), 0.0, 0, precond_cycles, 0, 1, NULL, NULL, NULL); } \
+      else { ds_columns(A, (rhs), (sol), nrow, nv); }                                      \
    } while (0)
+#define GM_MATVEC(al, xx, be, yy) do { for (int v_ = 0; v_ < nv; v_++) { oracle_par_matvec((al), A, (xx) + v_ * nrow, (be), (yy) + v_ * nrow, (yy) + v_ * nrow); } } while (0)
 
    memcpy(p[0], b, sizeof(double) * (size_t) n);
-   oracle_par_matvec(-1.0, A, x, 1.0, p[0], p[0]);
+   GM_MATVEC(-1.0, x, 1.0, p[0]);
    b_norm = sqrt(oracle_inner_prod(b, b, n));
    real_r_norm_old = b_norm;
    r_norm = sqrt(oracle_inner_prod(p[0], p[0], n));
@@ -1278,7 +1282,7 @@ int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, 
       if (r_norm <= epsilon)
       {
          memcpy(r, b, sizeof(double) * (size_t) n);
-         oracle_par_matvec(-1.0, A, x, 1.0, r, r);
+         GM_MATVEC(-1.0, x, 1.0, r);
          r_norm = sqrt(oracle_inner_prod(r, r, n));
          if (r_norm <= epsilon) { break; }
       }
@@ -1290,7 +1294,7 @@ int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, 
          i++;
          iter++;
          PRECOND(p[i - 1], r);
-         oracle_par_matvec(1.0, A, r, 0.0, p[i], p[i]);
+         GM_MATVEC(1.0, r, 0.0, p[i]);
          for (j = 0; j < i; j++)
          {
             hh[j][i - 1] = oracle_inner_prod(p[j], p[i], n);
@@ -1335,7 +1339,7 @@ int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, 
       if (r_norm <= epsilon)
       {
          memcpy(r, b, sizeof(double) * (size_t) n);
-         oracle_par_matvec(-1.0, A, x, 1.0, r, r);
+         GM_MATVEC(-1.0, x, 1.0, r);
          real_r_norm_new = r_norm = sqrt(oracle_inner_prod(r, r, n));
          if (r_norm <= epsilon) { converged = 1; break; }
          if (real_r_norm_new >= real_r_norm_old) { converged = 1; break; }
@@ -1358,9 +1362,24 @@ int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, 
       }
    }
 #undef PRECOND
+#undef GM_MATVEC
    if (rel_resid_out) { *rel_resid_out = (b_norm > 0.0) ? r_norm / b_norm : r_norm; }
    if (converged_out) { *converged_out = converged; }
    for (i = 0; i <= k_dim; i++) { free(p[i]); free(hh[i]); }
    free(p); free(hh); free(rs); free(c); free(sn); free(r); free(w);
    return iter;
+}
+
+int oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,
+                     int k_dim, int precond_cycles, double *rel_resid_out, int *converged_out)
+{
+   const opar *A = amg->A_outer ? amg->A_outer : &amg->A[0];
+   return gmres_core(amg, A, 1, b, x, r_tol, a_tol, max_iter, k_dim, precond_cycles, rel_resid_out, converged_out);
+}
+
+/* DS-GMRES on a multivector of nv columns (`ij -solver 4 -nc N`; pinned by test/TEST_ij/vector.saved B1, B101) */
+int oracle_gmres_ds_multi(const opar *A, const double *b, double *x, int nv, double r_tol, double a_tol, int max_iter,
+                          int k_dim, double *rel_resid_out, int *converged_out)
+{
+   return gmres_core(NULL, A, nv, b, x, r_tol, a_tol, max_iter, k_dim, 1, rel_resid_out, converged_out);
 }

@@ -94,6 +94,8 @@ int    oracle_pcg_amg_flex(const oamg *amg, const double *b, double *x, double r
 /* DS-PCG on a multivector of nv columns (`ij -solver 2 -nc N`; pinned by test/TEST_ij/vector.saved) */
 int    oracle_pcg_ds_multi(const opar *A, const double *b, double *x, int nv, double r_tol, double a_tol, int max_iter,
                            int two_norm, double *rel_resid_out, int *converged_out);
+int    oracle_gmres_ds_multi(const opar *A, const double *b, double *x, int nv, double r_tol, double a_tol, int max_iter,
+                             int k_dim, double *rel_resid_out, int *converged_out);
 /* relax 15: num_its iterations of unpreconditioned CG from the current x (par_relax_more.c:464-493) */
 void   oracle_cg_relax(const opar *A, const double *b, double *x, int num_its);
 int    oracle_gmres_amg(const oamg *amg, const double *b, double *x, double r_tol, double a_tol, int max_iter,

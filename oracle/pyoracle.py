@@ -97,6 +97,8 @@ def load():
     L.oracle_gmres_amg.restype = C.c_int
     L.oracle_gmres_amg.argtypes = [P(OAMG), RealP, RealP, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
                                    RealP, IntP]
+    L.oracle_gmres_ds_multi.restype = C.c_int
+    L.oracle_gmres_ds_multi.argtypes = [P(OPAR), RealP, RealP, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, RealP, IntP]
     L.oracle_pcg_ds_multi.restype = C.c_int
     L.oracle_pcg_ds_multi.argtypes = [P(OPAR), RealP, RealP, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, RealP, IntP]
     _lib = L
@@ -289,6 +291,18 @@ def pcg_ds_multi(A, B_cols, X_cols, tol=1e-8, atol=0.0, max_iter=1000, two_norm=
     rel = C.c_double(0.0)
     conv = C.c_int(0)
     its = load().oracle_pcg_ds_multi(C.byref(A.c), _rp(b), _rp(x), nv, tol, atol, max_iter, two_norm, C.byref(rel), C.byref(conv))
+    X_cols[:, :] = x.reshape(nv, n).T
+    return its, rel.value, conv.value
+
+
+def gmres_ds_multi(A, B_cols, X_cols, tol=1e-8, atol=0.0, max_iter=1000, k_dim=5):
+    """DS-GMRES(k_dim) on a multivector (`ij -solver 4 -nc nv`); arguments as pcg_ds_multi."""
+    n, nv = B_cols.shape
+    b = np.ascontiguousarray(B_cols.T, dtype=np.float64).ravel()
+    x = np.ascontiguousarray(X_cols.T, dtype=np.float64).ravel()
+    rel = C.c_double(0.0)
+    conv = C.c_int(0)
+    its = load().oracle_gmres_ds_multi(C.byref(A.c), _rp(b), _rp(x), nv, tol, atol, max_iter, k_dim, C.byref(rel), C.byref(conv))
     X_cols[:, :] = x.reshape(nv, n).T
     return its, rel.value, conv.value
 

@@ -141,7 +141,7 @@ def run_ds_pcg_case(case, opt, A, device, L, B, ij, O, dist, comm, rank, world):
         db = B.parmultivec_from_numpy(np.repeat(b[:, None], nv, axis=1), comm=comm, global_size=nglob, first=first)
         dx = B.parmultivec_from_numpy(np.repeat(x[:, None], nv, axis=1), comm=comm, global_size=nglob, first=first)
         fused_before = L.hypre_amd_SpmvFusedMultivectorLaunches()
-        its, rel = ij.solve_ds_pcg(opt, A, db, dx, comm=comm)
+        its, rel = (ij.solve_ds_gmres if opt.solver == 4 else ij.solve_ds_pcg)(opt, A, db, dx, comm=comm)
         L.HYPRE_ClearError(256)
         B.check()
         mine.update(dev_its=its, dev_rel=rel, dev_x=B.parmultivec_to_numpy(dx),
@@ -153,8 +153,12 @@ def run_ds_pcg_case(case, opt, A, device, L, B, ij, O, dist, comm, rank, world):
         Ao = O.par_from_exports([p["h"] for p in parts])
         bg = np.concatenate([p["b"] for p in parts]); xg = np.concatenate([p["x"] for p in parts])
         X = np.repeat(xg[:, None], nv, axis=1)
-        its, rel, conv = O.pcg_ds_multi(Ao, np.repeat(bg[:, None], nv, axis=1), X, tol=opt.tol, max_iter=opt.max_iter,
-                                        two_norm=opt.two_norm)
+        if opt.solver == 2:
+            its, rel, conv = O.pcg_ds_multi(Ao, np.repeat(bg[:, None], nv, axis=1), X, tol=opt.tol, max_iter=opt.max_iter,
+                                            two_norm=opt.two_norm)
+        else:
+            its, rel, conv = O.gmres_ds_multi(Ao, np.repeat(bg[:, None], nv, axis=1), X, tol=opt.tol, max_iter=opt.max_iter,
+                                              k_dim=opt.k_dim)
         out = {"iterations": its, "rel_resid": rel}
         if device:
             Xd = np.concatenate([p["dev_x"] for p in parts])
@@ -176,7 +180,7 @@ def run_case(case, L, B, ij, O, dist, comm, rank, world):
             setattr(opt, name, os.path.join(ROOT, "tests", "golden", "ij_files", getattr(opt, name)))
     A = ij.build_matrix(opt, comm=comm, rank=rank, nprocs=world)
     device = bool(case.get("device", 0))
-    if opt.solver == 2:
+    if opt.solver in (2, 4):
         return run_ds_pcg_case(case, opt, A, device, L, B, ij, O, dist, comm, rank, world)
     s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE if device else B.HYPRE_MEMORY_HOST)
     if "replicate" in case:

@@ -29,7 +29,7 @@ def test_reference_job_line_parses_to_the_golden_options(name):
 
 def test_out_of_scope_flags_are_refused():
     from hypre_amd import ij
-    for bad in (["-agg_nl", "1"], ["-solver", "4"], ["-nc", "3"], ["-solver", "2", "-nc", "3", "-rhsrand"], ["-cljp"], ["-smtype", "6"], ["-interptype", "7"], ["-rlx", "5"], ["-rap", "1"],
+    for bad in (["-agg_nl", "1"], ["-solver", "5"], ["-nc", "3"], ["-solver", "2", "-nc", "3", "-rhsrand"], ["-cljp"], ["-smtype", "6"], ["-interptype", "7"], ["-rlx", "5"], ["-rap", "1"],
                 ["-w", "-10"], ["-owl", "-10", "0"], ["-rlx_coarse", "29"]):
         with pytest.raises(SystemExit):
             ij.parse_cli(bad)
@@ -56,13 +56,13 @@ def _replay(case, timeout=600):
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
                                   "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24",
                                   "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405", "solvers.out.24", "solvers.out.28",
-                                  "vector.out.B0", "vector.out.B7", "vector.out.B10", "vector.out.B100"])
+                                  "vector.out.B0", "vector.out.B7", "vector.out.B10", "vector.out.B100", "vector.out.B1", "vector.out.B101"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
     exp = case["expect"]
     if "iterations" in exp:
-        label = {1: "Iterations", 2: "Iterations", 3: "GMRES Iterations"}.get(case["options"].get("solver", 0), "BoomerAMG Iterations")
+        label = {1: "Iterations", 2: "Iterations", 3: "GMRES Iterations", 4: "GMRES Iterations"}.get(case["options"].get("solver", 0), "BoomerAMG Iterations")
         assert re.search(r"^%s = %d$" % (label, exp["iterations"]), out, re.M), out
         m = re.search(r"^Final %sRelative Residual Norm = (\S+)$" % ("GMRES " if label.startswith("GMRES") else ""), out, re.M)
         assert m and abs(float(m.group(1)) - exp["rel_resid"]) <= 1.5e-6 * exp["rel_resid"], out
