@@ -132,7 +132,14 @@ def run_ds_pcg_case(case, opt, A, device, L, B, ij, O, dist, comm, rank, world):
     hierarchy.  The CPU oracle solves the gathered problem; with "device" the library solves it too, distributed, on the
     GPU (multivector products with one halo exchange for all columns, fused over the columns on the local block)."""
     nv = opt.num_components
-    b, x = ij.build_rhs_host(opt, A, rank=rank)
+
+    def allsum(v):
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    b, x = ij.build_rhs_host(opt, A, rank=rank, allreduce=allsum)
     mine = dict(h=O.export_par(A), b=b, x=x)
     if device:
         Am = A.contents

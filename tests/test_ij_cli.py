@@ -56,7 +56,7 @@ def _replay(case, timeout=600):
 @pytest.mark.parametrize("name", ["default.out.0", "fsai.out.103", "smoother.out.0", "smoother.out.3", "smoother.out.9",
                                   "smoother.out.11.1", "solvers.out.19", "solvers.out.23", "survey.C1", "smoother.out.13", "smoother.out.24",
                                   "coarsening.out.4", "interp.out.0", "matrix.out.0", "matrix.out.11", "solvers.out.405", "solvers.out.24", "solvers.out.28",
-                                  "vector.out.B0", "vector.out.B7", "vector.out.B10", "vector.out.B100", "vector.out.B1", "vector.out.B101"])
+                                  "vector.out.B0", "vector.out.B7", "vector.out.B10", "vector.out.B100", "vector.out.B1", "vector.out.B101", "fsai.out.3", "solvers.out.3"])
 def test_replay_reference_job_on_the_device(name):
     case = GOLD[name]
     out = _replay(case)
