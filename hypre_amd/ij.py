@@ -26,6 +26,7 @@ class IJOptions:
         self.c = (1.0, 1.0, 1.0)      # -c cx cy cz
         self.a = (1.0, 1.0, 1.0)      # -a ax ay az (difconv)
         self.solver = 0               # 0 AMG, 1 AMG-PCG, 2 DS-PCG (diagonal scaling), 3 AMG-GMRES, 4 DS-GMRES
+        self.neg_a = 0                # -negA 1: solve with -A (test/ij.c:4014-4017)
         self.num_components = 1       # -nc: columns of b and x (multivectors; test/ij.c:874-878, 3400-3404)
         self.k_dim = 5                # -k (GMRES restart length, test/ij.c:1731)
         self.flex = 0                 # -flex (flexible PCG: Polak-Ribiere beta)
@@ -119,7 +120,17 @@ def stencil_values(opt):
 
 
 def build_matrix(opt, comm=0, rank=0, nprocs=1):
-    """Rank (p,q,r) = (id % P, (id / P) % Q, id / (P*Q))   (test/ij.c:9693-9695)."""
+    """Rank (p,q,r) = (id % P, (id / P) % Q, id / (P*Q))   (test/ij.c:9693-9695); -negA 1: the operator times -1
+    (test/ij.c:4014-4017 hypre_ParCSRMatrixScale(A, -1): test/TEST_ij/posneg.jobs)."""
+    A = _build_matrix(opt, comm=comm, rank=rank, nprocs=nprocs)
+    if opt.neg_a:
+        for blk in (A.contents.diag.contents, A.contents.offd.contents):
+            if blk.num_nonzeros > 0:
+                np.ctypeslib.as_array(blk.data, shape=(blk.num_nonzeros,))[:] *= -1.0
+    return A
+
+
+def _build_matrix(opt, comm=0, rank=0, nprocs=1):
     if opt.fromfile:
         return read_matrix(opt.fromfile, comm=comm)
     P, Q, R = opt.P if opt.P else (1, nprocs, 1)     # test/ij.c BuildParLaplacian: P = 1, Q = num_procs, R = 1
@@ -295,7 +306,7 @@ _VALUE_FLAGS = {
     "-tr": ("trunc_factor", float, 1), "-Pmx": ("P_max_elmts", int, 1), "-interptype": ("interp_type", int, 1),
     "-tol": ("tol", float, 1), "-max_iter": ("max_iter", int, 1), "-mg_max_iter": ("mg_max_iter", int, 1),
     "-mxl": ("max_levels", int, 1), "-coarse_th": ("coarse_threshold", int, 1), "-keepT": ("keep_transpose", int, 1),
-    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nc": ("num_components", int, 1), "-nf": ("num_functions", int, 1), "-flex": ("flex", int, 1),
+    "-precon_cycles": ("precon_cycles", int, 1), "-k": ("k_dim", int, 1), "-nc": ("num_components", int, 1), "-negA": ("neg_a", int, 1), "-nf": ("num_functions", int, 1), "-flex": ("flex", int, 1),
     "-alpha": ("alpha", float, 1), "-eps": ("eps", float, 1), "-sysL": ("sys_num_fun", int, 1), "-ff": ("filter_functions", int, 1),
     "-cheby_order": ("cheby_order", int, 1), "-cheby_eig_est": ("cheby_eig_est", int, 1),
     "-cheby_variant": ("cheby_variant", int, 1), "-cheby_scale": ("cheby_scale", int, 1),

@@ -100,3 +100,31 @@ def test_distributed_direct_interpolation_is_rank_invariant():
     assert abs(one["grid"] - four["grid"]) < 1e-12 and abs(one["operator"] - four["operator"]) < 1e-12
     assert one["iterations"] == four["iterations"]
     assert abs(one["rel_resid"] - four["rel_resid"]) <= 1e-6 * one["rel_resid"]
+
+
+POSNEG = {"posneg.out.400": (2, "-solver 0 -rhsrand"), "posneg.out.401": (3, "-solver 3 -rhsrand"),
+          "posneg.out.402": (4, "-cheby_eig_est 10 -cheby_order 4 -cheby_variant 0 -cheby_scale 1 -rlx 16"),
+          "posneg.out.403": (4, "-solver 3 -cheby_eig_est 0 -cheby_order 3 -cheby_variant 1 -cheby_scale 1 -rlx 16")}
+
+
+def posneg_pair(name, extra=None):
+    """test/TEST_ij/posneg.jobs + posneg.sh: a job line with `-negA 0` and with `-negA 1` (the operator times -1, same
+    right-hand side) must print the same closing lines — the setup's sign tests on the diagonal (strength of connection,
+    interpolation weights, smoother diagonals) and the Chebyshev spectrum estimate."""
+    from hypre_amd import ij
+    nranks, cmd = POSNEG[name]
+    outs = []
+    for neg in (0, 1):
+        opt = ij.parse_cli((cmd + " -negA %d" % neg).split())
+        options = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(opt).items()
+                   if v != getattr(ij.IJOptions(), k)}
+        outs.append(run_ranks(nranks, {"options": options}, timeout=600, extra=extra))
+    return outs
+
+
+@pytest.mark.parametrize("name", sorted(POSNEG))
+def test_negated_operator_solves_alike(name):
+    pos, neg = posneg_pair(name)
+    assert pos["iterations"] == neg["iterations"] and pos["levels"] == neg["levels"] and pos["sizes"] == neg["sizes"]
+    assert abs(pos["rel_resid"] - neg["rel_resid"]) <= 5e-7 * pos["rel_resid"]          # the 7 digits posneg.sh compares
+    assert abs(pos["grid"] - neg["grid"]) < 1e-12 and abs(pos["operator"] - neg["operator"]) < 1e-12

@@ -306,6 +306,19 @@ def test_ds_pcg_on_multivectors_four_ranks_on_device(name):
         assert all(f > 0 for f in out["fused"])          # the fused kernel served the local blocks' products
 
 
+@pytest.mark.parametrize("name", ["posneg.out.400", "posneg.out.402", "posneg.out.403"])
+def test_negated_operator_solves_alike_on_device(name):
+    """test/TEST_ij/posneg.jobs on the device path: with -A the distributed device solve (AMG, Chebyshev smoothing,
+    GMRES) takes the iterations and reaches the residual it does with A, and both are the oracle's."""
+    from test_dist_golden import posneg_pair
+    pos, neg = posneg_pair(name, extra={"device": 1, "transport": "staged"})
+    for out in (pos, neg):
+        assert out["dev_iterations"] == out["iterations"]
+        assert abs(out["dev_rel_resid"] - out["rel_resid"]) <= 1e-6 * out["rel_resid"]
+    assert pos["dev_iterations"] == neg["dev_iterations"]
+    assert abs(pos["dev_rel_resid"] - neg["dev_rel_resid"]) <= 5e-7 * pos["dev_rel_resid"]
+
+
 def test_pcg_three_ranks_on_device():
     case = dict(GOLD["solvers.out.19"])
     out = run_ranks(3, {"options": case["options"]}, timeout=600, extra={"device": 1, "transport": "staged"})
