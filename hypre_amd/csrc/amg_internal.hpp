@@ -7,6 +7,42 @@
 
 namespace hamd {
 
+// The smallest levels of a V(1,1) Jacobi cycle in one kernel of one workgroup (tail_kernels.hip)
+constexpr int SMALL_TAIL_MAX_LEVELS = 10;
+constexpr int SMALL_TAIL_MAX_COARSE = 32;      // unknowns of the coarsest level's dense solve
+struct SmallTailLevel
+{
+   // byte offsets into the kernel's LDS (the image's arrays first, the work vectors behind them)
+   int    Ai, Aj, Aa;                          // the level's operator
+   int    Pi, Pj, Pa;                          // interpolation to this level from the next
+   int    Ri, Rj, Ra;                          // restriction from this level to the next: the stored transpose of P
+   int    d;                                   // smoother diagonal
+   int    f, u, alt;                           // right-hand side, iterate, second buffer of the out-of-place sweep
+   int    n;                                   // rows
+   int    wA, wP, wR;                          // lanes per row of the passes over A, P, R (powers of two <= 64)
+   double w;                                   // relaxation weight
+   const int    *gAj;                          // the operator's columns and values where they are, when the image leaves them
+   const double *gAa;                          // out (the first level of a tail that would not fit LDS otherwise); else null
+};
+struct SmallTailArgs
+{
+   SmallTailLevel lv[SMALL_TAIL_MAX_LEVELS];
+   int            nl;                          // levels (the last one is solved directly)
+   const void    *image;                       // the levels' arrays as the kernel lays them out in LDS (AmgPrivate::tail_image)
+   int            image_bytes;                 // a multiple of 16
+   int            lds_bytes;                   // image + work vectors
+   int            lu_off, ncoarse;             // factors of the coarsest operator
+   int            vt_off;                      // residual scratch, as long as the first level
+   const double  *f_in;                        // right-hand side of the first level
+   double        *u_io;                        // its iterate: read when the restriction into it wrote the sweep from zero; the result
+   int            first_presmoothed;
+   int            round32;                     // mixed precision: matrix values rounded through fp32
+   int            reg_first;                   // the first level's operator is held in registers (lv[0].gAj / gAa, gAi: where it lies)
+   const int     *gAi;
+   int            nnz0;
+};
+void launch_small_tail(const SmallTailArgs &t, hipStream_t s);
+
 // Device-side state that rides along with a hypre_ParAMGData (amd_private).
 struct AmgPrivate
 {
@@ -50,6 +86,16 @@ struct AmgPrivate
    double         graph_bytes_csr = 0.0, graph_bytes_stream = 0.0;   // ... and to the byte counters (Handle::bytes_*)
    int            graph_launches = 0;         // kernel nodes of the graph (reported by the benchmark)
    void drop_graph();
+
+   // one-workgroup tail (tail_kernels.hip): first level of it, or -1 (decided at the first cycle; levels whose operator
+   // holds at most small_tail_nnz entries; 0: off)
+   int            small_tail_nnz   = [] { const char *e = getenv("HYPRE_AMD_SMALL_TAIL_NNZ"); return e ? atoi(e) : 20000; }();
+   int            small_tail_level = -2;      // -2: not decided yet
+   int            small_tail_used  = -2;      // level the last cycle entered the tail at (-1: it did not; tests)
+   void          *tail_image       = nullptr; // device: the tail levels' arrays in the kernel's LDS layout
+   unsigned long long tail_image_sig = 0;     // what the image was built from
+   int            tail_outside     = -1;      // form of the image (0 all in LDS, 1 first operator in registers, 2 streamed); -1: not known
+   SmallTailArgs  tail_args{};                // offsets of the image's arrays (vectors and flags are filled per cycle)
 
    // relax 15: one unpreconditioned-CG solver per level, created at the first cycle that needs it
    std::vector<HYPRE_Solver> cg_smoothers;

@@ -330,6 +330,11 @@ hypre_Vector *hypre_amd_BoomerAMGGetChebyDS(HYPRE_Solver s, HYPRE_Int l)
 // rank (0 disables; see par_amg_replicate.cpp)
 HYPRE_Int hypre_amd_BoomerAMGSetReplicateThreshold(HYPRE_Solver s, HYPRE_Int rows)
 { AMG_DATA(s, d); ((AmgPrivate *) d->amd_private)->replicate_rows = rows < 0 ? 0 : rows; return hypre_error_flag; }
+HYPRE_Int hypre_amd_BoomerAMGGetSmallTailLevel(HYPRE_Solver s)
+{
+   hypre_ParAMGData *d = (hypre_ParAMGData *) s;
+   return d && d->amd_private ? ((AmgPrivate *) d->amd_private)->small_tail_used : -2;
+}
 HYPRE_Int hypre_amd_BoomerAMGGetReplicatedLevel(HYPRE_Solver s)
 { hypre_ParAMGData *d = (hypre_ParAMGData *) s; return (d && ((AmgPrivate *) d->amd_private)->tail) ? ((AmgPrivate *) d->amd_private)->tail_level : -1; }
 

@@ -46,6 +46,8 @@ void AmgPrivate::release_device()
    if (d_coarse_lu) { hypre_Free(d_coarse_lu, HYPRE_MEMORY_DEVICE); d_coarse_lu = nullptr; }
    if (d_coarse_rhs) { hypre_Free(d_coarse_rhs, HYPRE_MEMORY_DEVICE); d_coarse_rhs = nullptr; }
    coarse_n = 0;
+   if (tail_image) { (void) hipFree(tail_image); tail_image = nullptr; }
+   tail_image_sig = 0; small_tail_level = -2; small_tail_used = -2; tail_outside = -1;
    if (mp_r) { hypre_ParVectorDestroy(mp_r); mp_r = nullptr; }
    if (mp_e) { hypre_ParVectorDestroy(mp_e); mp_e = nullptr; }
 }
@@ -169,7 +171,7 @@ static double *diag_scratch(size_t n)
    return buf;
 }
 
-namespace { int &cycle_fusion(); }     // (defined with the cycle below)
+namespace { int &cycle_fusion(); int &small_tail_on(); int &small_tail_forced_form(); }     // (defined with the cycle below)
 
 extern "C" {
 
@@ -506,6 +508,118 @@ int &cycle_fusion()
    static int on = [] { const char *e = getenv("HYPRE_AMD_CYCLE_FUSION"); return e ? atoi(e) : 1; }();
    return on;
 }
+// the smallest levels of a Jacobi V(1,1) cycle in one kernel of one workgroup (tail_kernels.hip; hypre_amd_SetSmallTail)
+int &small_tail_on()
+{
+   static int on = [] { const char *e = getenv("HYPRE_AMD_SMALL_TAIL"); return e ? atoi(e) : 1; }();
+   return on;
+}
+// The image of levels st .. L-1 the one-workgroup tail copies into LDS (tail_kernels.hip): every array the walk reads, at the
+// offset the kernel addresses it, and behind it the room of the work vectors.  Built when the hierarchy (its arrays'
+// addresses) is new; false: the levels do not fit the LDS of one workgroup.
+// form: 0 every array in LDS; 1 the first level's operator in the lanes' registers (its rows times their lanes fill the
+// workgroup once, a lane's share is at most 16 entries); 2 the first level's operator streamed from where it lies
+bool build_small_tail_image(hypre_ParAMGData *d, AmgPrivate *pv, int st, hipStream_t s, int form = 0)
+{
+   const bool first_operator_outside = form != 0;
+   const int L = d->num_levels;
+   hypre_ParCSRMatrix **A = d->A_array, **P = d->P_array;
+   unsigned long long h = 1469598103934665603ull;
+   auto mix = [&](unsigned long long v) { h ^= v; h *= 1099511628211ull; };
+   mix((unsigned long long) st); mix((unsigned long long) L); mix((unsigned long long) (uintptr_t) pv->d_coarse_lu); mix((unsigned long long) pv->coarse_n);
+   mix((unsigned long long) form);
+   for (int l = st; l < L; l++)
+   {
+      mix((unsigned long long) (uintptr_t) A[l]->diag->i); mix((unsigned long long) (uintptr_t) A[l]->diag->data); mix((unsigned long long) A[l]->diag->num_nonzeros);
+      if (l < L - 1)
+      {
+         mix((unsigned long long) (uintptr_t) P[l]->diag->data); mix((unsigned long long) (uintptr_t) P[l]->diagT->data);
+         mix((unsigned long long) (uintptr_t) d->l1_norms[l]->data);
+      }
+   }
+   if (pv->tail_image && pv->tail_image_sig == h) { return true; }
+   if (pv->tail_image) { (void) hipFree(pv->tail_image); pv->tail_image = nullptr; pv->tail_image_sig = 0; }
+   int reg_lanes = 0;
+   if (form == 1)
+   {
+      // lanes per row of the register form: enough that a lane holds at most 16 entries of the longest row, few enough that
+      // all rows fit the workgroup at once
+      hypre_CSRMatrix *Ad = A[st]->diag;
+      std::vector<HYPRE_Int> ri((size_t) Ad->num_rows + 1);
+      HIP_CHECK(hipStreamSynchronize(s));
+      hypre_TMemcpy(ri.data(), Ad->i, HYPRE_Int, Ad->num_rows + 1, HYPRE_MEMORY_HOST, HYPRE_MEMORY_DEVICE);
+      int longest = 0;
+      for (HYPRE_Int r = 0; r < Ad->num_rows; r++) { longest = std::max(longest, (int) (ri[(size_t) r + 1] - ri[(size_t) r])); }
+      // (the lanes per row the other forms take, where a lane's share then fits its registers: the same order of the sums)
+      int wmax = 1, wlen = 1;
+      while (2 * wmax <= 64 && 2LL * wmax * std::max((int) Ad->num_rows, 1) <= 1024) { wmax *= 2; }
+      const int avg = Ad->num_rows > 0 ? (int) ((Ad->num_nonzeros + Ad->num_rows - 1) / Ad->num_rows) : 1;
+      while (wlen < avg && wlen < 64) { wlen *= 2; }
+      int W = std::min(wmax, wlen);
+      while (16 * W < longest && W < 64) { W *= 2; }
+      if (16 * W < longest || (long long) W * Ad->num_rows > 1024 || Ad->num_nonzeros < 1) { return false; }
+      reg_lanes = W;
+   }
+   SmallTailArgs &ta = pv->tail_args;
+   ta = SmallTailArgs{};
+   int off = 0;
+   auto take = [&](size_t bytes) { const int o = off; off += (int) ((bytes + 15) & ~(size_t) 15); return o; };
+   auto lanes = [](int rows, int entries)
+   {
+      int wmax = 1, wlen = 1;
+      while (2 * wmax <= 64 && 2 * wmax * std::max(rows, 1) <= 1024) { wmax *= 2; }
+      const int avg = rows > 0 ? (entries + rows - 1) / rows : 1;
+      while (wlen < avg && wlen < 64) { wlen *= 2; }
+      return std::min(wmax, wlen);
+   };
+   struct Piece { const void *src; int off; size_t bytes; };
+   std::vector<Piece> pieces;
+   auto put = [&](const void *src, size_t bytes) { const int o = take(bytes); pieces.push_back({src, o, bytes}); return o; };
+   ta.nl = L - st;
+   for (int l = st; l < L - 1; l++)
+   {
+      SmallTailLevel &q = ta.lv[l - st];
+      hypre_CSRMatrix *Ad = A[l]->diag, *Pd = P[l]->diag, *Rd = P[l]->diagT;
+      q.n = Ad->num_rows;
+      q.Ai = put(Ad->i, sizeof(int) * ((size_t) Ad->num_rows + 1));
+      if (l == st && first_operator_outside) { q.gAj = Ad->j; q.gAa = Ad->data; ta.gAi = Ad->i; ta.nnz0 = Ad->num_nonzeros; }
+      else
+      {
+         q.Aj = put(Ad->j, sizeof(int) * (size_t) Ad->num_nonzeros);
+         q.Aa = put(Ad->data, sizeof(double) * (size_t) Ad->num_nonzeros);
+      }
+      q.Pi = put(Pd->i, sizeof(int) * ((size_t) Pd->num_rows + 1)); q.Pj = put(Pd->j, sizeof(int) * (size_t) Pd->num_nonzeros);
+      q.Pa = put(Pd->data, sizeof(double) * (size_t) Pd->num_nonzeros);
+      q.Ri = put(Rd->i, sizeof(int) * ((size_t) Rd->num_rows + 1)); q.Rj = put(Rd->j, sizeof(int) * (size_t) Rd->num_nonzeros);
+      q.Ra = put(Rd->data, sizeof(double) * (size_t) Rd->num_nonzeros);
+      q.d = put(d->l1_norms[l]->data, sizeof(double) * (size_t) Ad->num_rows);
+      q.wA = lanes(Ad->num_rows, Ad->num_nonzeros); q.wP = lanes(Pd->num_rows, Pd->num_nonzeros); q.wR = lanes(Rd->num_rows, Rd->num_nonzeros);
+      if (l == st && form == 1) { q.wA = reg_lanes; ta.reg_first = 1; }
+   }
+   ta.lv[L - 1 - st].n = A[L - 1]->diag->num_rows;
+   ta.ncoarse = pv->coarse_n;
+   ta.lu_off = put(pv->d_coarse_lu, sizeof(double) * (size_t) pv->coarse_n * (size_t) pv->coarse_n);
+   ta.image_bytes = off;
+   for (int l = st; l < L; l++)
+   {
+      SmallTailLevel &q = ta.lv[l - st];
+      q.f = take(sizeof(double) * (size_t) q.n); q.u = take(sizeof(double) * (size_t) q.n); q.alt = take(sizeof(double) * (size_t) q.n);
+   }
+   ta.vt_off = take(sizeof(double) * (size_t) ta.lv[0].n);
+   ta.lds_bytes = off;
+   if (off > 158 * 1024) { ta = SmallTailArgs{}; return false; }
+   if (hipMalloc(&pv->tail_image, (size_t) std::max(ta.image_bytes, 16)) != hipSuccess) { (void) hipGetLastError(); pv->tail_image = nullptr; return false; }
+   for (const Piece &pc : pieces)
+   {
+      if (pc.bytes) { HIP_CHECK(hipMemcpyAsync((char *) pv->tail_image + pc.off, pc.src, pc.bytes, hipMemcpyDeviceToDevice, s)); }
+   }
+   ta.image = pv->tail_image;
+   pv->tail_image_sig = h;
+   return true;
+}
+
+// tests: the form of the tail's image (-1: the first that fits)
+int &small_tail_forced_form() { static int f = -1; return f; }
 // everything the launches of the sub-cycle below level gl depend on
 unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, hypre_ParVector **F, hypre_ParVector **U)
 {
@@ -535,6 +649,7 @@ unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, h
    }
    mix(plan_generation());            // a plan dropped or rebuilt anywhere (the recorded kernels point into plans' tables)
    mix((unsigned long long) cycle_fusion());     // (the recorded tail leaves out what a fused restriction into it did)
+   mix((unsigned long long) (small_tail_on() ? pv->small_tail_nnz : 0)); mix((unsigned long long) (small_tail_forced_form() + 1));     // (one kernel instead of a dozen launches in the recorded tail)
    SpmvArgs a{};
    spmv_default_flags(a);
    mix((unsigned long long) a.variant); mix((unsigned long long) a.gather_t); mix((unsigned long long) a.xcd_map);
@@ -552,6 +667,23 @@ HYPRE_Int hypre_amd_SetCycleFusion(HYPRE_Int on)
 {
    if (on >= 0) { cycle_fusion() = on != 0; }
    return cycle_fusion();
+}
+
+// The smallest levels of a V(1,1) cycle with Jacobi-type smoothing in one kernel of one workgroup from now on (default 1):
+// the levels whose operators hold at most `max_entries` entries each (default 20 000; < 0: unchanged).  The order of a
+// row's sum differs from the per-level kernels' (rounding only).  on < 0: unchanged; returns the setting.
+HYPRE_Int hypre_amd_SetSmallTail(HYPRE_Int on)
+{
+   if (on >= 0) { small_tail_on() = on != 0; }
+   return small_tail_on();
+}
+// Test hook: the form the tail's image takes from now on — 0 every array in LDS, 1 the first level's operator in the lanes'
+// registers, 2 streamed from where it lies; -1 the first of these that fits (default).  A form that does not fit a
+// hierarchy moves the tail a level down.
+HYPRE_Int hypre_amd_SetSmallTailForm(HYPRE_Int form)
+{
+   small_tail_forced_form() = (form >= 0 && form <= 2) ? form : -1;
+   return hypre_error_flag;
 }
 
 HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre_ParVector **U_array)
@@ -600,10 +732,63 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
    const bool old_version = d->grid_relax_points != nullptr;
    double cycle_op_count = d->cycle_op_count;
 
-   // ---- coarse tail as a HIP graph (single rank, plain V-cycle, smoothers whose launches do not depend on host state
-   // that changes from cycle to cycle) ----
    HYPRE_Int cycle_nprocs = 1;
    hypre_MPI_Comm_size(A[0]->comm, &cycle_nprocs);
+   // ---- the smallest levels in one kernel of one workgroup (tail_kernels.hip): one rank, a plain V(1,1) cycle, Jacobi or
+   // l1-Jacobi over all points with the smoother diagonals at hand, a direct solve on the coarsest level ----
+   int st = -1;
+   {
+      const int t1 = d->grid_relax_type[1], t2 = d->grid_relax_type[2], t3 = d->grid_relax_type[3];
+      const bool ok = small_tail_on() && pv->small_tail_nnz > 0 && cycle_nprocs == 1 && d->cycle_type == 1 && !d->fcycle && !old_version &&
+                      L >= 3 && (t1 == 7 || t1 == 18) && (t2 == 7 || t2 == 18) && is_ge_type(t3) && d->relax_order == 0 &&
+                      d->num_grid_sweeps[1] == 1 && d->num_grid_sweeps[2] == 1 && d->num_grid_sweeps[3] == 1 && !pv->tail;
+      if (ok)
+      {
+         if (pv->small_tail_level == -2)
+         {
+            int first = L - 1;
+            while (first - 1 >= 1 && A[first - 1]->diag->num_nonzeros <= pv->small_tail_nnz && L - (first - 1) <= SMALL_TAIL_MAX_LEVELS) { first--; }
+            pv->small_tail_level = (first <= L - 2) ? first : -1;
+         }
+         st = pv->small_tail_level;
+         for (int l = st; st >= 0 && l < L; l++)
+         {
+            const bool last = l == L - 1;
+            const bool here = A[l]->diag->memory_location == HYPRE_MEMORY_DEVICE && A[l]->offd->num_nonzeros == 0 &&
+                              (last || (d->l1_norms[l] && d->l1_norms[l]->data && P[l] && P[l]->diagT &&
+                                        P[l]->diagT->memory_location == HYPRE_MEMORY_DEVICE && P[l]->offd->num_nonzeros == 0));
+            if (!here) { st = -1; }
+         }
+         if (st >= 0)
+         {
+            if (!d->gs_setup) { hypre_GaussElimSetup(d, L - 1, t3); }
+            ensure_coarse_factors(d);
+            if (pv->coarse_n != A[L - 1]->diag->num_rows || pv->coarse_n > SMALL_TAIL_MAX_COARSE || pv->coarse_n < 1) { st = -1; }
+         }
+         // the levels' arrays as the kernel holds them in LDS; a tail that does not fit starts a level further down
+         auto image_of = [&](int lvl)
+         {
+            // (the form that worked last time first: with an unchanged hierarchy that is a comparison of two numbers)
+            const int forced = small_tail_forced_form();
+            if (forced >= 0) { pv->tail_outside = forced; return build_small_tail_image(d, pv, lvl, s, forced); }
+            if (pv->tail_outside >= 0 && build_small_tail_image(d, pv, lvl, s, pv->tail_outside)) { return true; }
+            for (int form = 0; form < 3; form++)
+            {
+               if (build_small_tail_image(d, pv, lvl, s, form)) { pv->tail_outside = form; return true; }
+            }
+            pv->tail_outside = -1;
+            return false;
+         };
+         while (st >= 0 && !image_of(st))
+         {
+            st = (st + 1 <= L - 2) ? st + 1 : -1;
+            pv->small_tail_level = st;
+         }
+      }
+   }
+   pv->small_tail_used = st;
+   // ---- coarse tail as a HIP graph (single rank, plain V-cycle, smoothers whose launches do not depend on host state
+   // that changes from cycle to cycle) ----
    int gl = -1;
    {
       auto graphable = [&](int t) { return is_jacobi_type(t) || is_ge_type(t) || t == 11 || t == 12 || t == 16 || t == 21 || t == 22; };
@@ -651,6 +836,32 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) { capturing = true; op_count_at_capture = cycle_op_count; csr_at_capture = handle().bytes_csr; stream_at_capture = handle().bytes_stream; }
             else { (void) hipGetLastError(); pv->graph_state = 0; gl = -1; }
          }
+      }
+      if (st >= 0 && level == st && arrived_down && !replayed)
+      {
+         // everything from here down and back up to this level's post-smoothing sweep: one launch
+         SmallTailArgs ta = pv->tail_args;
+         double csr_bytes = 0.0;
+         for (int l = st; l < L; l++)
+         {
+            ta.lv[l - st].w = d->relax_weight[l];
+            if (l < L - 1)
+            {
+               cycle_op_count += 2.0 * A[l]->d_num_nonzeros;
+               csr_bytes += 2.0 * (12.0 * A[l]->diag->num_nonzeros + 36.0 * A[l]->diag->num_rows) +
+                            2.0 * (12.0 * P[l]->diag->num_nonzeros + 20.0 * P[l]->diag->num_rows);
+            }
+            else { cycle_op_count += A[l]->d_num_nonzeros; }
+         }
+         ta.f_in = F_array[st]->local_vector->data;
+         ta.u_io = lv[(size_t) st].home;
+         ta.first_presmoothed = presmoothed[(size_t) st];
+         presmoothed[(size_t) st] = 0;
+         ta.round32 = handle().fp32_values ? 1 : 0;
+         account_bytes(csr_bytes);
+         launch_small_tail(ta, s);
+         for (int l = st; l < L; l++) { lv[(size_t) l].cur = lv[(size_t) l].home; zeros[(size_t) l] = 0; lev_counter[(size_t) l] = -1; }
+         replayed = true;
       }
       arrived_down = false;
       int num_sweep, relax_type;

@@ -293,6 +293,19 @@ HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on
  * of a kernel of its own reading f_c and d_c again (par_cycle.c:340-420 runs the two as separate steps).  Same bits either
  * way; the switch is for comparisons.  on < 0 leaves the setting; returns it. */
 HYPRE_Int hypre_amd_SetCycleFusion(HYPRE_Int on);
+/* The smallest levels of a V(1,1) cycle with Jacobi / l1-Jacobi smoothing (relax 7 / 18, no C/F ordering) and a direct
+ * coarse solve in ONE kernel of one workgroup (default on; environment HYPRE_AMD_SMALL_TAIL=0): from the first level whose
+ * operator — and every coarser one — holds at most 20 000 entries (HYPRE_AMD_SMALL_TAIL_NNZ) down and back up, every step
+ * of par_cycle.c:23-803 is a launch of ~5 us for a fraction of a microsecond of work; one workgroup walks them with a
+ * barrier in between.  One rank only.  Same arithmetic, the products of a row added in a fixed order of its own (rounding
+ * differences against the per-level kernels).  on < 0 leaves the setting; returns it. */
+HYPRE_Int hypre_amd_SetSmallTail(HYPRE_Int on);
+/* Test hook: how the tail's kernel holds the first level's operator — 0 with everything else in LDS, 1 in the lanes'
+ * registers (its rows times their lanes fill the workgroup once), 2 streamed from global memory; -1 (default) the first of
+ * these that fits. */
+HYPRE_Int hypre_amd_SetSmallTailForm(HYPRE_Int form);
+/* first level of the one-workgroup tail in the last cycle of this solver (-1: none, -2: no cycle has run) */
+HYPRE_Int hypre_amd_BoomerAMGGetSmallTailLevel(HYPRE_Solver solver);
 /* grid / operator complexity of the last setup */
 HYPRE_Int hypre_amd_BoomerAMGGetComplexities(HYPRE_Solver solver, HYPRE_Real *grid, HYPRE_Real *op);
 /* Multi-rank device hierarchies: levels with at most `rows` global rows are gathered onto every rank at

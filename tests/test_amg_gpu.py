@@ -872,3 +872,67 @@ def test_the_fusions_across_the_steps_of_a_cycle_change_no_bit(gpu_lib, oracle, 
     assert np.max(np.abs(out[0] - ur)) <= 1e-11 * np.max(np.abs(ur))
     lib.HYPRE_BoomerAMGDestroy(s)
     B.check()
+
+
+@pytest.mark.parametrize("kw", [dict(relax_type=18), dict(relax_type=7, relax_wt=0.8), dict(relax_type=18, mixed=True),
+                                dict(relax_type=18, problem="27pt"), dict(relax_type=18, n=(40, 12, 9)),
+                                dict(relax_type=18, cycle_type=2), dict(relax_type=18, relax_order=1), dict(relax_type=11)])
+def test_the_smallest_levels_in_one_kernel(gpu_lib, oracle, kw):
+    """hypre_amd_SetSmallTail.  From the first level whose operators hold at most 20 000 entries down to the direct solve and
+    back up, a V(1,1) cycle with Jacobi / l1-Jacobi smoothing runs as ONE kernel of one workgroup instead of a dozen launches
+    (tail_kernels.hip).  The cycle with it is the cycle without it up to the order of a row's sum (1e-13), the same bits
+    eager, recorded in the coarse-tail graph and replayed, it is the oracle's cycle, and configurations it does not serve
+    (W-cycles, C/F-ordered sweeps, other smoothers) leave it out."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    kw = dict(kw)
+    mixed = kw.pop("mixed", False)
+    dims = kw.pop("n", (30, 29, 28))
+    served = kw.get("cycle_type", 1) == 1 and kw.get("relax_order", 0) == 0 and kw["relax_type"] in (7, 18)
+    opt, A, s = _setup(lib, n=dims, coarsen_type=8, **kw)
+    if mixed:
+        lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
+    lib.HYPRE_BoomerAMGSetTol(s, 0.0)
+    lib.HYPRE_BoomerAMGSetMaxIter(s, 1)
+    n = dims[0] * dims[1] * dims[2]
+    f = rand_vector(n, 6)
+    amg = oracle.amg_from_solvers([s], mixed_precision=mixed)
+    ur = np.zeros(n)
+    amg.solve(f, ur, tol=0.0, max_iter=1, u_all_zeros=True)
+    nl = lib.hypre_amd_BoomerAMGGetNumLevels(s)
+    out, used, by_form = {1: [], 0: []}, {}, {}
+    try:
+        # (three cycles each: eager, recorded, replayed; then the two other forms of the kernel's image: the first level's
+        # operator in the lanes' registers, and streamed from global memory)
+        for on, form in ((1, -1), (1, -1), (1, -1), (0, -1), (0, -1), (0, -1), (1, 1), (1, 1), (1, 2), (1, 2), (1, 0)):
+            lib.hypre_amd_SetSmallTailForm(form)
+            assert lib.hypre_amd_SetSmallTail(on) == on
+            du, df = B.parvec_from_numpy(np.zeros(n)), B.parvec_from_numpy(f)
+            lib.hypre_ParVectorSetZeros(du)
+            lib.HYPRE_BoomerAMGSolve(s, A, df, du)
+            B.check()
+            if form < 0:
+                out[on].append(B.parvec_to_numpy(du))
+                used[on] = lib.hypre_amd_BoomerAMGGetSmallTailLevel(s)
+            else:
+                by_form.setdefault(form, []).append(B.parvec_to_numpy(du))
+            lib.hypre_ParVectorDestroy(du); lib.hypre_ParVectorDestroy(df)
+    finally:
+        lib.hypre_amd_SetSmallTail(1)
+        lib.hypre_amd_SetSmallTailForm(-1)
+    assert used[0] == -1
+    assert (1 <= used[1] <= nl - 2) if served else used[1] == -1, (used, nl)
+    for on in (0, 1):
+        for u in out[on]:
+            assert np.array_equal(u.view(np.int64), out[on][0].view(np.int64))
+    scale = np.max(np.abs(ur))
+    assert np.max(np.abs(out[1][0] - out[0][0])) <= 1e-13 * scale
+    for form, us in by_form.items():
+        for u in us:
+            assert np.array_equal(u.view(np.int64), us[0].view(np.int64))
+            assert np.max(np.abs(u - out[0][0])) <= 1e-13 * scale, form
+    assert np.max(np.abs(out[1][0] - ur)) <= 1e-11 * scale
+    if not served:
+        assert np.array_equal(out[1][0].view(np.int64), out[0][0].view(np.int64))
+    lib.HYPRE_BoomerAMGDestroy(s)
+    B.check()

@@ -1,4 +1,4 @@
-"""A/B of the V(1,1) cycle with and without the row-slice form (or the cycle's fusions: --toggle fusion) in ONE process on ONE box (the HBM-bound launches move by
+"""A/B of the V(1,1) cycle with and without the row-slice form (or the cycle's fusions: --toggle fusion; or the one-workgroup tail: --toggle smalltail) in ONE process on ONE box (the HBM-bound launches move by
 4-7 % from box to box and drift with the clocks inside a run: the two forms are measured alternately, four times each).
 
     python tools/ab_row_slices.py [n] [cycles] [--problem laplacian|27pt|difconv] [--relax 18]
@@ -20,7 +20,7 @@ ap.add_argument("cycles", type=int, nargs="?", default=30)
 ap.add_argument("--problem", default="laplacian")
 ap.add_argument("--relax", type=int, default=18)
 ap.add_argument("--codes", type=int, default=1)
-ap.add_argument("--toggle", default="rowslices", choices=["rowslices", "fusion"], help="what is switched between the two samples")
+ap.add_argument("--toggle", default="rowslices", choices=["rowslices", "fusion", "smalltail"], help="what is switched between the two samples")
 args = ap.parse_args()
 L = B.load_library()
 n = args.n
@@ -35,6 +35,8 @@ for rep in range(4):
     for mode in (1, 0):
         if args.toggle == "rowslices":
             L.hypre_amd_SpmvSetRowSlices(mode)
+        elif args.toggle == "smalltail":
+            L.hypre_amd_SetSmallTail(mode)
         else:
             L.hypre_amd_SetCycleFusion(mode)
         s = ij.create_amg(opt, memory_location=B.HYPRE_MEMORY_DEVICE)
