@@ -37,6 +37,8 @@ struct SmallTailArgs
    double        *u_io;                        // its iterate: read when the restriction into it wrote the sweep from zero; the result
    int            first_presmoothed;
    int            round32;                     // mixed precision: matrix values rounded through fp32
+   int            kind_down, kind_up;          // smoother on the way down / up: 0 Jacobi (relax 7 / 18), 1 two-stage Gauss-Seidel (11 / 12)
+   int            inner_down, inner_up;        // its inner steps (relax 11: 1, relax 12: 2)
    int            reg_first;                   // the first level's operator is held in registers (lv[0].gAj / gAa, gAi: where it lies)
    const int     *gAi;
    int            nnz0;

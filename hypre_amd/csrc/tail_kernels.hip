@@ -41,9 +41,53 @@ __device__ __forceinline__ double tail_value(const double *a, int k, int r32)
 
 // sum of row [s, e) of (j, a) times x with W lanes (this lane: sub), NB entries in flight: 4 out of LDS, more when the
 // operator streams from global memory: 24 (a lane's share of a row is then one trip, or two)
-template <int NB>
+enum { T_RESID = 0, T_RESTRICT = 1, T_RESTRICT_DIV = 2, T_INTERP_ADD = 3, T_JACOBI = 4, T_RESID_RD = 5, T_L_FIRST = 6, T_L_NEXT = 7 };
+// the passes over the strictly lower triangle (the inner steps of the two-stage Gauss-Seidel sweep): entries left of the diagonal only
+template <int OPK> struct tail_lower { static constexpr bool value = OPK == T_L_FIRST || OPK == T_L_NEXT; };
+
+// what a row's sum becomes: the row epilogues of spmv_kernels.hip (and scaled_div / scaled_recip), rounding for rounding
+template <int OPK>
+__device__ __forceinline__ void tail_epilogue(int row, double sum, const double *x, const double *f, const double *d, double w,
+                                              double *y, double *u, int flag)
+{
+   if (OPK == T_RESID) { y[row] = __fma_rn(1.0, f[row], __dmul_rn(-1.0, sum)); }                  // OP_AXPBY, alpha -1, beta 1
+   else if (OPK == T_RESTRICT) { y[row] = __dmul_rn(1.0, sum); }                                     // OP_AXPBY, alpha 1, beta 0
+   else if (OPK == T_RESTRICT_DIV) { const double r = __dmul_rn(1.0, sum); y[row] = r; u[row] = __dmul_rn(w, r) / d[row]; }
+   else if (OPK == T_INTERP_ADD) { y[row] = __fma_rn(1.0, y[row], __dmul_rn(1.0, sum)); }            // OP_AXPBY in place, beta 1
+   else if (OPK == T_JACOBI)
+   {
+      // OP_JACOBI: y = x + (w f - w (A x)) / d, out of place
+      const double t = __fma_rn(w, f[row], -__dmul_rn(w, sum));
+      y[row] = __dadd_rn(x[row], t / d[row]);
+   }
+   else if (OPK == T_RESID_RD)
+   {
+      // OP_RESID_RD, alpha -w, beta w: z = (w f - w A u) .* (1 ./ D)
+      double r = __dmul_rn(-w, sum);
+      r = __fma_rn(w, f[row], r);
+      y[row] = __dmul_rn(r, 1.0 / d[row]);
+   }
+   else if (OPK == T_L_FIRST)
+   {
+      // OP_TSGS_FIRST: z' = (L z) .* (1 ./ D) ; u = (u + z) + mult z'   (flag: u is known to be zero; w is mult)
+      const double z = __dmul_rn(sum, 1.0 / d[row]);
+      y[row] = z;
+      u[row] = __fma_rn(w, z, __dadd_rn(flag ? 0.0 : u[row], x[row]));
+   }
+   else
+   {
+      // OP_TSGS: z'' = (L z') .* (1 ./ D) ; u += mult z''
+      const double z = __dmul_rn(sum, 1.0 / d[row]);
+      y[row] = z;
+      u[row] = __fma_rn(w, z, u[row]);
+   }
+}
+
+// sum of row [s, e) of (j, a) times x with W lanes (this lane: sub), NB entries in flight: 4 out of LDS, more when the
+// operator streams from global memory: 24 (a lane's share of a row is then one trip, or two); LOWER: columns below `row` only
+template <int NB, bool LOWER>
 __device__ __forceinline__ double tail_row_sum(const int *__restrict__ j, const double *__restrict__ a, int s, int e, int sub, int W,
-                                               const double *x, int r32)
+                                               const double *x, int r32, int row)
 {
    double sum = 0.0;
    for (int k = s + sub; k < e; k += NB * W)
@@ -60,7 +104,7 @@ __device__ __forceinline__ double tail_row_sum(const int *__restrict__ j, const 
 #pragma unroll
       for (int i = 0; i < NB; i++)
       {
-         if (k + i * W < e)
+         if (k + i * W < e && (!LOWER || c[i] < row))
          {
 #pragma clang fp contract(off)
             const double pr = v[i] * x[c[i]];
@@ -72,13 +116,12 @@ __device__ __forceinline__ double tail_row_sum(const int *__restrict__ j, const 
    return sum;
 }
 
-enum { T_RESID = 0, T_RESTRICT = 1, T_RESTRICT_DIV = 2, T_INTERP_ADD = 3, T_JACOBI = 4 };
-
 // one matrix pass over n rows: y (and u) from the row sums, W lanes per row.  Row pointers, x, f, d, y, u in LDS; the
-// columns and values in LDS (NB = 4) or where the matrix lies (NB = 16)
+// columns and values in LDS (NB = 4) or where the matrix lies (NB = 24)
 template <int OPK, int NB>
 __device__ __forceinline__ void tail_pass(const int *__restrict__ Mi, const int *__restrict__ Mj, const double *__restrict__ Ma, int n, int W,
-                                          const double *x, const double *f, const double *d, double w, double *y, double *u, int r32)
+                                          const double *x, const double *f, const double *d, double w, double *y, double *u, int r32,
+                                          int flag = 0)
 {
    const int tid = threadIdx.x, sub = tid & (W - 1), G = TAIL_THREADS / W;
    for (int base = 0; base < n; base += G)
@@ -86,38 +129,26 @@ __device__ __forceinline__ void tail_pass(const int *__restrict__ Mi, const int 
       const int row = base + tid / W;
       const bool live = row < n;
       const int s = live ? Mi[row] : 0, e = live ? Mi[row + 1] : 0;
-      const double sum = tail_row_sum<NB>(Mj, Ma, s, e, sub, W, x, r32);
-      if (live && sub == 0)
-      {
-         if (OPK == T_RESID) { y[row] = __fma_rn(1.0, f[row], __dmul_rn(-1.0, sum)); }            // OP_AXPBY, alpha -1, beta 1
-         else if (OPK == T_RESTRICT) { y[row] = __dmul_rn(1.0, sum); }                               // OP_AXPBY, alpha 1, beta 0
-         else if (OPK == T_RESTRICT_DIV) { const double r = __dmul_rn(1.0, sum); y[row] = r; u[row] = __dmul_rn(w, r) / d[row]; }
-         else if (OPK == T_INTERP_ADD) { y[row] = __fma_rn(1.0, y[row], __dmul_rn(1.0, sum)); }      // OP_AXPBY in place, beta 1
-         else
-         {
-            // OP_JACOBI: y = x + (w f - w (A x)) / d, out of place
-            const double t = __fma_rn(w, f[row], -__dmul_rn(w, sum));
-            y[row] = __dadd_rn(x[row], t / d[row]);
-         }
-      }
+      const double sum = tail_row_sum<NB, tail_lower<OPK>::value>(Mj, Ma, s, e, sub, W, x, r32, row);
+      if (live && sub == 0) { tail_epilogue<OPK>(row, sum, x, f, d, w, y, u, flag); }
    }
 }
 
 // The first level's operator out of REGISTERS: when its rows times their lanes fill the workgroup once (n W <= 1024) and a
 // lane's share of a row is at most TAIL_REG entries, the lane fetches that share once — at the start, beside the image —
-// and both passes over the operator (residual, sweep) multiply from registers: the largest operator of the tail costs no
+// and every pass over the operator (residual, sweeps) multiplies from registers: the largest operator of the tail costs no
 // LDS and no second trip.
 constexpr int TAIL_REG = 16;
 template <int OPK, int NR>
 __device__ __forceinline__ void tail_pass_reg(const double (&av)[NR], const int (&ac)[NR], int s, int e, int n, int W,
-                                              const double *x, const double *f, const double *d, double w, double *y)
+                                              const double *x, const double *f, const double *d, double w, double *y, double *u, int flag = 0)
 {
    const int tid = threadIdx.x, sub = tid & (W - 1), row = tid / W;
    double sum = 0.0;
 #pragma unroll
    for (int i = 0; i < NR; i++)
    {
-      if (s + sub + i * W < e)
+      if (s + sub + i * W < e && (!tail_lower<OPK>::value || ac[i] < row))
       {
 #pragma clang fp contract(off)
          const double pr = av[i] * x[ac[i]];
@@ -125,15 +156,7 @@ __device__ __forceinline__ void tail_pass_reg(const double (&av)[NR], const int 
       }
    }
    for (int off = W >> 1; off > 0; off >>= 1) { sum += __shfl_xor(sum, off, 64); }
-   if (row < n && sub == 0)
-   {
-      if (OPK == T_RESID) { y[row] = __fma_rn(1.0, f[row], __dmul_rn(-1.0, sum)); }
-      else
-      {
-         const double t = __fma_rn(w, f[row], -__dmul_rn(w, sum));
-         y[row] = __dadd_rn(x[row], t / d[row]);
-      }
-   }
+   if (row < n && sub == 0) { tail_epilogue<OPK>(row, sum, x, f, d, w, y, u, flag); }
 }
 
 // Everything the walk reads lies in LDS: the plan's image of the levels' arrays (operators, interpolation, restriction,
@@ -204,7 +227,7 @@ void small_tail_kernel(SmallTailArgs t)
    }
    __syncthreads();
    TAIL_STAMP(1);
-   if (!t.first_presmoothed)
+   if (!t.first_presmoothed && t.kind_down == 0)
    {
       // u = (w f) / d (scaled_div_kernel)
       const SmallTailLevel &L0 = t.lv[0];
@@ -213,20 +236,47 @@ void small_tail_kernel(SmallTailArgs t)
       for (int i = tid; i < L0.n; i += TAIL_THREADS) { u0[i] = (L0.w * f0[i]) / d0[i]; }
       __syncthreads();
    }
+   // a pass over the operator of level l in whatever form the kernel holds it
+#define A_PASS(OPK, l, F, x, f, d, w, y, u, flag)                                                                                     \
+   do {                                                                                                                               \
+      if (REG && (l) == 0) { tail_pass_reg<OPK, (REG ? TAIL_REG : 1)>(av, ac, rs0, re0, (F).n, (F).wA, x, f, d, w, y, u, flag); }       \
+      else if (!REG && (F).gAj) { tail_pass<OPK, 24>(ip((F).Ai), (F).gAj, (F).gAa, (F).n, (F).wA, x, f, d, w, y, u, r32, flag); }      \
+      else { tail_pass<OPK, 4>(ip((F).Ai), ip((F).Aj), dp((F).Aa), (F).n, (F).wA, x, f, d, w, y, u, r32, flag); }                     \
+   } while (0)
+   // two-stage Gauss-Seidel sweep of level l in place (hypre_BoomerAMGRelaxTwoStageGaussSeidelDevice, fused form):
+   //   z = (w f - w A u) .* (1 ./ D)  [from zero: (w f) .* (1 ./ D)] ; z' = (L z) .* (1 ./ D), u = (u + z) - z' ; [z'' = (L z') .* (1 ./ D), u += z'']
+   auto tsgs = [&](int l, bool from_zero, int inner)
+   {
+      const SmallTailLevel &F = t.lv[l];
+      double *z0 = wp(F.alt), *z1 = vt;
+      if (from_zero)
+      {
+         const double *f = dp(F.f), *d = dp(F.d);
+         for (int i = tid; i < F.n; i += TAIL_THREADS) { z0[i] = __dmul_rn(__dmul_rn(F.w, f[i]), 1.0 / d[i]); }      // scaled_recip_kernel
+      }
+      else { A_PASS(T_RESID_RD, l, F, dp(F.u), dp(F.f), dp(F.d), F.w, z0, nullptr, 0); }
+      __syncthreads();
+      A_PASS(T_L_FIRST, l, F, z0, nullptr, dp(F.d), -1.0, z1, wp(F.u), from_zero ? 1 : 0);
+      __syncthreads();
+      if (inner > 1)
+      {
+         A_PASS(T_L_NEXT, l, F, z1, nullptr, dp(F.d), 1.0, z0, wp(F.u), 0);
+         __syncthreads();
+      }
+   };
+   if (t.kind_down == 1) { tsgs(0, true, t.inner_down); }
    // down: residual, restriction (+ the next level's sweep from zero)
    for (int l = 0; l < nl - 1; l++)
    {
       const SmallTailLevel &F = t.lv[l], &C = t.lv[l + 1];
       TAIL_STAMP(2 + 2 * l);
-      // (an operator the image leaves where it is streams from there: a trip per pass instead of none)
-      if (REG && l == 0) { tail_pass_reg<T_RESID, (REG ? TAIL_REG : 1)>(av, ac, rs0, re0, F.n, F.wA, dp(F.u), dp(F.f), nullptr, 0.0, vt); }
-      else if (!REG && F.gAj) { tail_pass<T_RESID, 24>(ip(F.Ai), F.gAj, F.gAa, F.n, F.wA, dp(F.u), dp(F.f), nullptr, 0.0, vt, nullptr, r32); }
-      else { tail_pass<T_RESID, 4>(ip(F.Ai), ip(F.Aj), dp(F.Aa), F.n, F.wA, dp(F.u), dp(F.f), nullptr, 0.0, vt, nullptr, r32); }
+      A_PASS(T_RESID, l, F, dp(F.u), dp(F.f), nullptr, 0.0, vt, nullptr, 0);
       __syncthreads();
       TAIL_STAMP(3 + 2 * l);
-      if (l + 1 < nl - 1) { tail_pass<T_RESTRICT_DIV, 4>(ip(F.Ri), ip(F.Rj), dp(F.Ra), C.n, F.wR, vt, nullptr, dp(C.d), C.w, wp(C.f), wp(C.u), r32); }
+      if (l + 1 < nl - 1 && t.kind_down == 0) { tail_pass<T_RESTRICT_DIV, 4>(ip(F.Ri), ip(F.Rj), dp(F.Ra), C.n, F.wR, vt, nullptr, dp(C.d), C.w, wp(C.f), wp(C.u), r32); }
       else { tail_pass<T_RESTRICT, 4>(ip(F.Ri), ip(F.Rj), dp(F.Ra), C.n, F.wR, vt, nullptr, nullptr, 0.0, wp(C.f), nullptr, r32); }
       __syncthreads();
+      if (l + 1 < nl - 1 && t.kind_down == 1) { tsgs(l + 1, true, t.inner_down); }
    }
    // the coarsest level: substitution with the factors of the pivot-free elimination (coarse_solve_kernel)
    TAIL_STAMP(20);
@@ -272,7 +322,7 @@ void small_tail_kernel(SmallTailArgs t)
       }
       __syncthreads();
    }
-   // up: interpolation, sweep (out of place: the level's two buffers swap)
+   // up: interpolation, sweep (Jacobi: out of place into the level's second buffer; two-stage Gauss-Seidel: in place)
    TAIL_STAMP(21);
    for (int l = nl - 2; l >= 0; l--)
    {
@@ -281,23 +331,26 @@ void small_tail_kernel(SmallTailArgs t)
       tail_pass<T_INTERP_ADD, 4>(ip(F.Pi), ip(F.Pj), dp(F.Pa), F.n, F.wP, dp(C.u), nullptr, nullptr, 0.0, wp(F.u), nullptr, r32);
       __syncthreads();
       TAIL_STAMP(23 + 2 * l);
-      if (REG && l == 0) { tail_pass_reg<T_JACOBI, (REG ? TAIL_REG : 1)>(av, ac, rs0, re0, F.n, F.wA, dp(F.u), dp(F.f), dp(F.d), F.w, wp(F.alt)); }
-      else if (!REG && F.gAj) { tail_pass<T_JACOBI, 24>(ip(F.Ai), F.gAj, F.gAa, F.n, F.wA, dp(F.u), dp(F.f), dp(F.d), F.w, wp(F.alt), nullptr, r32); }
-      else { tail_pass<T_JACOBI, 4>(ip(F.Ai), ip(F.Aj), dp(F.Aa), F.n, F.wA, dp(F.u), dp(F.f), dp(F.d), F.w, wp(F.alt), nullptr, r32); }
-      __syncthreads();
-      if (l > 0)
+      if (t.kind_up == 1) { tsgs(l, false, t.inner_up); }
+      else
       {
-         double *u = wp(F.u);
-         const double *a = dp(F.alt);
-         for (int i = tid; i < F.n; i += TAIL_THREADS) { u[i] = a[i]; }
+         A_PASS(T_JACOBI, l, F, dp(F.u), dp(F.f), dp(F.d), F.w, wp(F.alt), nullptr, 0);
          __syncthreads();
+         if (l > 0)
+         {
+            double *u = wp(F.u);
+            const double *a = dp(F.alt);
+            for (int i = tid; i < F.n; i += TAIL_THREADS) { u[i] = a[i]; }
+            __syncthreads();
+         }
       }
    }
    {
       const SmallTailLevel &L0 = t.lv[0];
-      const double *a = dp(L0.alt);
+      const double *a = t.kind_up == 1 ? dp(L0.u) : dp(L0.alt);
       for (int i = tid; i < L0.n; i += TAIL_THREADS) { t.u_io[i] = a[i]; }
    }
+#undef A_PASS
    TAIL_STAMP(40);
 #undef ip
 #undef dp

@@ -876,10 +876,12 @@ def test_the_fusions_across_the_steps_of_a_cycle_change_no_bit(gpu_lib, oracle, 
 
 @pytest.mark.parametrize("kw", [dict(relax_type=18), dict(relax_type=7, relax_wt=0.8), dict(relax_type=18, mixed=True),
                                 dict(relax_type=18, problem="27pt"), dict(relax_type=18, n=(40, 12, 9)),
-                                dict(relax_type=18, cycle_type=2), dict(relax_type=18, relax_order=1), dict(relax_type=11)])
+                                dict(relax_type=18, cycle_type=2), dict(relax_type=18, relax_order=1), dict(relax_type=11),
+                                dict(relax_type=12, problem="27pt"), dict(relax_type=11, mixed=True), dict(relax_type=18, relax_up=12),
+                                dict(relax_type=16)])
 def test_the_smallest_levels_in_one_kernel(gpu_lib, oracle, kw):
     """hypre_amd_SetSmallTail.  From the first level whose operators hold at most 20 000 entries down to the direct solve and
-    back up, a V(1,1) cycle with Jacobi / l1-Jacobi smoothing runs as ONE kernel of one workgroup instead of a dozen launches
+    back up, a V(1,1) cycle with Jacobi / l1-Jacobi or two-stage Gauss-Seidel smoothing runs as ONE kernel of one workgroup instead of a dozen launches
     (tail_kernels.hip).  The cycle with it is the cycle without it up to the order of a row's sum (1e-13), the same bits
     eager, recorded in the coarse-tail graph and replayed, it is the oracle's cycle, and configurations it does not serve
     (W-cycles, C/F-ordered sweeps, other smoothers) leave it out."""
@@ -888,7 +890,7 @@ def test_the_smallest_levels_in_one_kernel(gpu_lib, oracle, kw):
     kw = dict(kw)
     mixed = kw.pop("mixed", False)
     dims = kw.pop("n", (30, 29, 28))
-    served = kw.get("cycle_type", 1) == 1 and kw.get("relax_order", 0) == 0 and kw["relax_type"] in (7, 18)
+    served = kw.get("cycle_type", 1) == 1 and kw.get("relax_order", 0) == 0 and kw["relax_type"] in (7, 18, 11, 12)
     opt, A, s = _setup(lib, n=dims, coarsen_type=8, **kw)
     if mixed:
         lib.hypre_amd_BoomerAMGSetMixedPrecision(s, 1)
