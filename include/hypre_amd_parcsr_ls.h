@@ -293,7 +293,8 @@ HYPRE_Int hypre_amd_BoomerAMGSetMixedPrecision(HYPRE_Solver solver, HYPRE_Int on
  * of a kernel of its own reading f_c and d_c again (par_cycle.c:340-420 runs the two as separate steps).  Same bits either
  * way; the switch is for comparisons.  on < 0 leaves the setting; returns it. */
 HYPRE_Int hypre_amd_SetCycleFusion(HYPRE_Int on);
-/* The smallest levels of a V(1,1) cycle with Jacobi / l1-Jacobi smoothing (relax 7 / 18, no C/F ordering) and a direct
+/* The smallest levels of a V(1,1) cycle with Jacobi / l1-Jacobi or two-stage Gauss-Seidel smoothing (relax 7 / 18 / 11 / 12,
+ * no C/F ordering) and a direct
  * coarse solve in ONE kernel of one workgroup (default on; environment HYPRE_AMD_SMALL_TAIL=0): from the first level whose
  * operator — and every coarser one — holds at most 20 000 entries (HYPRE_AMD_SMALL_TAIL_NNZ) down and back up, every step
  * of par_cycle.c:23-803 is a launch of ~5 us for a fraction of a microsecond of work; one workgroup walks them with a
