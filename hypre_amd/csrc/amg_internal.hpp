@@ -94,6 +94,8 @@ struct AmgPrivate
    int            small_tail_nnz   = [] { const char *e = getenv("HYPRE_AMD_SMALL_TAIL_NNZ"); return e ? atoi(e) : 20000; }();
    int            small_tail_level = -2;      // -2: not decided yet
    int            small_tail_used  = -2;      // level the last cycle entered the tail at (-1: it did not; tests)
+   bool           replica          = false;   // this hierarchy is a replicated tail: its two-stage Gauss-Seidel sweeps keep the
+                                              // ranks' own lower triangles (par_amg_replicate.cpp), which the one-workgroup tail does not
    void          *tail_image       = nullptr; // device: the tail levels' arrays in the kernel's LDS layout
    unsigned long long tail_image_sig = 0;     // what the image was built from
    int            tail_outside     = -1;      // form of the image (0 all in LDS, 1 first operator in registers, 2 streamed); -1: not known

@@ -165,6 +165,7 @@ void build_replicated_tail(hypre_ParAMGData *d, const std::vector<hypre_ParCSRMa
    HYPRE_BoomerAMGCreate(&ts);
    hypre_ParAMGData *t = (hypre_ParAMGData *) ts;
    AmgPrivate *tp = (AmgPrivate *) t->amd_private;
+   tp->replica = true;
    tp->replicate_rows = 0;
    tp->emulated_threads = pv->emulated_threads;
    tp->mixed_precision = pv->mixed_precision;

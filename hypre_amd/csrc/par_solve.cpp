@@ -741,7 +741,7 @@ HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre
       const int t1 = d->grid_relax_type[1], t2 = d->grid_relax_type[2], t3 = d->grid_relax_type[3];
       const bool ok = small_tail_on() && pv->small_tail_nnz > 0 && cycle_nprocs == 1 && d->cycle_type == 1 && !d->fcycle && !old_version &&
                       L >= 3 && (t1 == 7 || t1 == 18 || t1 == 11 || t1 == 12) && (t2 == 7 || t2 == 18 || t2 == 11 || t2 == 12) &&
-                      is_ge_type(t3) && d->relax_order == 0 &&
+                      !(pv->replica && (t1 == 11 || t1 == 12 || t2 == 11 || t2 == 12)) && is_ge_type(t3) && d->relax_order == 0 &&
                       d->num_grid_sweeps[1] == 1 && d->num_grid_sweeps[2] == 1 && d->num_grid_sweeps[3] == 1 && !pv->tail;
       if (ok)
       {
