@@ -356,6 +356,10 @@ void device_color_matrices(int n, int C, const int *color, const int *order, con
                            const double *Aa, int **ptr_out, int **Cj_out, double **Ca_out, std::vector<int> &slice0, std::vector<int> &slice_nnz,
                            hipStream_t s);
 void launch_mc_diag(int n, const int *Ai, const double *Aa, double *d, hipStream_t s);
+void launch_mc_rowinfo(int n, const int *order, const int *Ai, void *info, hipStream_t s);
+void launch_mc_small_sweep_ahead(int num_colors, int direction, const int *cstart, const void *rowinfo, int nrows, const int *Aj,
+                                 const double *Aa, const float *Aa32, int nnz_matrix, const double *f, const double *d, const int *marker,
+                                 int marker_val, double w, double *u, int n, int nnz, int r_first, hipStream_t s);
 void launch_mc_small_sweep(int num_colors, int direction, const int *cstart, const int *order, const int *Ai, const int *Aj,
                            const double *Aa, const float *Aa32, const double *f, const double *d, const int *marker, int marker_val,
                            double w, double *u, int n, int nnz, hipStream_t s);

@@ -215,7 +215,231 @@ void mc_small_sweep_kernel(int num_colors, int direction, const int *__restrict_
    }
 }
 
+// The same sweep with what does not depend on the iterate fetched AHEAD.  In the kernel above a colour is a chain of five
+// dependent loads (colour bounds -> row -> row pointers -> entries -> u) and a barrier: ~8 us a colour, 158 us a launch on
+// the benchmark hierarchy (round 4 trace), 1.3 ms of a 6.9 ms cycle.  Of that chain only the gathers of u have to wait for
+// the colour before: a row's place (mc_rowinfo: row, first and last entry, one 16-byte record per sorted position), its
+// right-hand side, diagonal, own iterate value (only the row itself writes it) and its first entries are requested one
+// pass ahead, while the current pass is summed — a colour then costs the gathers and the barrier.
+// And a row gets 32 lanes instead of 8: the colours of these levels hold a few dozen rows at most (1003 rows in 44 colours,
+// 185 in 47 on the benchmark hierarchy), so 8 lanes a row left most of the workgroup idle and ten entries a lane to walk;
+// with 32 the four entries a lane fetches ahead cover rows of 128 entries — no second trip for the rest of a row.
+// Same arithmetic; a row's sum is added by 32 lanes (entries gl, gl + 32, ... per lane, then the xor tree) instead of 8.
+template <int PB>
+struct McAhead
+{
+   int    i, b, e, on;
+   double f, d, uo;
+   double v[PB];
+   int    c[PB];
+};
+struct McPass { int q, rb, r1; };      // colour (in sweep order), first row of the pass, end of the colour; q >= num_colors: none
+// The look-ahead is two passes deep: a row's record (mc_rowinfo) is requested two passes ahead, what hangs on it (right-hand
+// side, diagonal, own value, first entries) one pass ahead — by then the record has arrived with the loads of the pass
+// before, so nothing in the loop waits for a load it has just issued except the gathers of u, the one thing that must.
+// ULDS: the level's iterate (at most 8192 rows) lives in LDS for the length of the sweep — copied in at the start, written
+// back at the end —, so what a colour hands to the next (a store that has to reach the L2, a barrier, gathers that come
+// back from the L2: two round trips a colour) becomes LDS traffic.
+template <int MC_GL, int MC_PB, bool ULDS>
+__global__ __launch_bounds__(SMALL_TB)
+void mc_small_sweep_ahead_kernel(int num_colors, int direction, const int *__restrict__ cstart, const int4 *__restrict__ rowinfo, int nrows,
+                                 const int *__restrict__ Aj, const double *__restrict__ Aa, const float *__restrict__ Aa32, int nnz,
+                                 const double *__restrict__ f, const double *__restrict__ d, const int *__restrict__ marker, int marker_val,
+                                 double w, double *ug)
+{
+   extern __shared__ __align__(16) double mc_ulds[];
+   constexpr int GL = MC_GL, NG = SMALL_TB / GL;
+   const int gl = threadIdx.x & (GL - 1), grp = threadIdx.x / GL;
+   double *u = ug;
+   if (ULDS)
+   {
+      for (int i = threadIdx.x; i < nrows; i += SMALL_TB) { mc_ulds[i] = ug[i]; }
+      u = mc_ulds;
+   }
+   auto colour = [&](int q) { return direction > 0 ? q : num_colors - 1 - q; };
+   // the pass after p (the next rows of its colour, or the first of the next colour that holds rows)
+   auto after = [&](McPass p) -> McPass
+   {
+      if (p.q >= num_colors) { return p; }
+      p.rb += NG;
+      while (p.rb >= p.r1)
+      {
+         p.q++;
+         if (p.q >= num_colors) { break; }
+         const int c = colour(p.q);
+         p.rb = cstart[c]; p.r1 = cstart[c + 1];
+      }
+      return p;
+   };
+   auto record = [&](const McPass &p) -> int4 { return rowinfo[min(max(p.rb + grp, 0), nrows - 1)]; };
+   // what a pass needs of this lane's row beyond its record
+   auto fetch = [&](const McPass &p, const int4 &ri) -> McAhead<MC_PB>
+   {
+      McAhead<MC_PB> a;
+      const bool have = p.rb + grp < p.r1;
+      a.i = ri.x; a.b = ri.y; a.e = ri.z;
+      a.on = (have && !(marker && marker[a.i] != marker_val)) ? 1 : 0;
+      a.f = f[a.i]; a.d = d[a.i]; a.uo = ULDS ? 0.0 : ug[a.i];
+#pragma unroll
+      for (int j = 0; j < MC_PB; j++)
+      {
+         const int k = min(max(a.b + gl + j * GL, 0), nnz - 1);
+         a.v[j] = Aa32 ? (double) Aa32[k] : Aa[k];
+         a.c[j] = Aj[k];
+      }
+      return a;
+   };
+   McPass p0 = after(McPass{-1, 0, 0});     // (from q = -1 with no rows left, "after" walks to the first colour that holds rows)
+   if (p0.q >= num_colors) { return; }
+   if (ULDS) { __syncthreads(); }
+   McPass p1 = after(p0), p2 = after(p1);
+   McAhead<MC_PB> cur = fetch(p0, record(p0));
+   int4 ri1 = p1.q < num_colors ? record(p1) : make_int4(0, 0, 0, 0);
+   while (true)
+   {
+      int4 ri2 = make_int4(0, 0, 0, 0);
+      if (p2.q < num_colors) { ri2 = record(p2); }
+      McAhead<MC_PB> nxt = cur;
+      if (p1.q < num_colors) { nxt = fetch(p1, ri1); }
+      // this pass: gathers, sums, the row's update
+      double s = 0.0;
+      if (cur.on)
+      {
+#pragma unroll
+         for (int j = 0; j < MC_PB; j++) { if (cur.b + gl + j * GL < cur.e) { s += cur.v[j] * u[cur.c[j]]; } }
+         if (Aa32) { for (int k = cur.b + gl + MC_PB * GL; k < cur.e; k += GL) { s += (double) Aa32[k] * u[Aj[k]]; } }
+         else { for (int k = cur.b + gl + MC_PB * GL; k < cur.e; k += GL) { s += Aa[k] * u[Aj[k]]; } }
+      }
+#pragma unroll
+      for (int off = GL >> 1; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); }
+      if (cur.on && gl == 0) { u[cur.i] = (ULDS ? u[cur.i] : cur.uo) + w * (cur.f - s) / cur.d; }
+      if (p1.q >= num_colors) { break; }
+      if (p1.q != p0.q) { __syncthreads(); }          // the next colour reads what this one wrote
+      cur = nxt; p0 = p1; p1 = p2; ri1 = ri2; p2 = after(p2);
+   }
+   if (ULDS)
+   {
+      __syncthreads();
+      for (int i = threadIdx.x; i < nrows; i += SMALL_TB) { ug[i] = mc_ulds[i]; }
+   }
+}
+
+// The sweep of a small level out of LDS: the iterate (all n rows of the level), and for the swept rows their record, right-hand
+// side and diagonal live in LDS for the length of the launch — filled in two trips at the start — so a colour hands over to the
+// next through LDS and the only global loads of the loop are the rows' entries, requested three passes ahead (they depend on
+// nothing the sweep changes).  A colour then costs a barrier and LDS latencies instead of two round trips to the L2.
+template <int GL, int PB>
+__global__ __launch_bounds__(SMALL_TB)
+void mc_small_sweep_lds_kernel(int num_colors, int direction, const int *__restrict__ cstart, const int4 *__restrict__ rowinfo, int nrows,
+                               int r_begin, int m, const int *__restrict__ Aj, const double *__restrict__ Aa, const float *__restrict__ Aa32, int nnz,
+                               const double *__restrict__ f, const double *__restrict__ d, const int *__restrict__ marker, int marker_val,
+                               double w, double *ug)
+{
+   extern __shared__ __align__(16) unsigned char mc_smem[];
+   constexpr int NG = SMALL_TB / GL, DEPTH = 3;
+   double *uL = reinterpret_cast<double *>(mc_smem);
+   double *fL = uL + nrows, *dL = fL + m;
+   int4 *infoL = reinterpret_cast<int4 *>(dL + m + ((nrows + 2 * m) & 1));      // (16-byte aligned)
+   int *csL = reinterpret_cast<int *>(infoL + m);
+   const int tid = threadIdx.x, gl = tid & (GL - 1), grp = tid / GL;
+   for (int i = tid; i < nrows; i += SMALL_TB) { uL[i] = ug[i]; }
+   for (int i = tid; i <= num_colors; i += SMALL_TB) { csL[i] = cstart[i]; }
+   for (int r = tid; r < m; r += SMALL_TB)
+   {
+      int4 ri = rowinfo[min(r_begin + r, nrows - 1)];
+      ri.w = (marker && marker[ri.x] != marker_val) ? 0 : 1;
+      infoL[r] = ri;
+      fL[r] = f[ri.x];
+      dL[r] = d[ri.x];
+   }
+   __syncthreads();
+   auto colour = [&](int q) { return direction > 0 ? q : num_colors - 1 - q; };
+   struct Pass { int q, rb, r1; };
+   auto after = [&](Pass p) -> Pass
+   {
+      if (p.q >= num_colors) { return p; }
+      p.rb += NG;
+      while (p.rb >= p.r1)
+      {
+         p.q++;
+         if (p.q >= num_colors) { break; }
+         const int c = colour(p.q);
+         p.rb = csL[c]; p.r1 = csL[c + 1];
+      }
+      return p;
+   };
+   struct Entries { double v[PB]; int c[PB]; };
+   // the first entries of this lane's row in pass p (any valid address for lanes without a row: never used)
+   auto entries = [&](const Pass &p) -> Entries
+   {
+      Entries e;
+      const int r = min(max(p.rb + grp - r_begin, 0), m - 1);
+      const int b = (p.q < num_colors) ? infoL[r].y : 0;
+#pragma unroll
+      for (int j = 0; j < PB; j++)
+      {
+         const int k = min(max(b + gl + j * GL, 0), nnz - 1);
+         e.v[j] = Aa32 ? (double) Aa32[k] : Aa[k];
+         e.c[j] = Aj[k];
+      }
+      return e;
+   };
+   Pass p[DEPTH + 1];
+   p[0] = after(Pass{-1, 0, 0});
+   if (p[0].q < num_colors)
+   {
+#pragma unroll
+      for (int k = 1; k <= DEPTH; k++) { p[k] = after(p[k - 1]); }
+      // three slots of entries, each consumed in place and then asked for again (for the pass three ahead): no register of
+      // a slot is copied, so nothing waits for a load that was only just issued
+      Entries E0 = entries(p[0]), E1 = entries(p[1]), E2 = entries(p[2]);
+      auto step = [&](Entries &E) -> bool
+      {
+         const int r = p[0].rb + grp;
+         const bool have = r < p[0].r1;
+         const int rl = min(max(r - r_begin, 0), m - 1);
+         const int4 ri = infoL[rl];
+         const bool on = have && ri.w != 0;
+         double s = 0.0;
+         if (on)
+         {
+#pragma unroll
+            for (int j = 0; j < PB; j++) { if (ri.y + gl + j * GL < ri.z) { s += E.v[j] * uL[E.c[j]]; } }
+            if (Aa32) { for (int k = ri.y + gl + PB * GL; k < ri.z; k += GL) { s += (double) Aa32[k] * uL[Aj[k]]; } }
+            else { for (int k = ri.y + gl + PB * GL; k < ri.z; k += GL) { s += Aa[k] * uL[Aj[k]]; } }
+         }
+#pragma unroll
+         for (int off = GL >> 1; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); }
+         if (on && gl == 0) { uL[ri.x] = uL[ri.x] + w * (fL[rl] - s) / dL[rl]; }
+         if (p[1].q >= num_colors) { return false; }
+         if (p[1].q != p[0].q) { __syncthreads(); }       // the next colour reads what this one wrote
+         E = entries(p[DEPTH]);
+#pragma unroll
+         for (int k = 0; k < DEPTH; k++) { p[k] = p[k + 1]; }
+         p[DEPTH] = after(p[DEPTH]);
+         return true;
+      };
+      while (step(E0) && step(E1) && step(E2)) { }
+   }
+   __syncthreads();
+   for (int i = tid; i < nrows; i += SMALL_TB) { ug[i] = uL[i]; }
+}
+
+__global__ void mc_rowinfo_kernel(int n, const int *__restrict__ order, const int *__restrict__ Ai, int4 *__restrict__ info)
+{
+   const int r = blockIdx.x * blockDim.x + threadIdx.x;
+   if (r >= n) { return; }
+   const int i = order[r];
+   info[r] = make_int4(i, Ai[i], Ai[i + 1], 0);
+}
+
 }  // namespace
+
+// rows colour by colour -> (row, first entry, last entry) records of the look-ahead sweep
+void launch_mc_rowinfo(int n, const int *order, const int *Ai, void *info, hipStream_t s)
+{
+   if (n > 0) { hipLaunchKernelGGL(mc_rowinfo_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, order, Ai, (int4 *) info); }
+}
 
 // Greedy first-fit colouring in row order of the pattern of A + A^T (both given as device CSR patterns).  color: n ints
 // (device).  Returns the number of colours.  round_budget: rounds after which the row order is given up for the hashed one.
@@ -367,6 +591,42 @@ void launch_mc_small_sweep(int num_colors, int direction, const int *cstart, con
    account_bytes((double) nnz * (Aa32 ? 8.0 : 12.0) + (double) n * 44.0);
    hipLaunchKernelGGL(mc_small_sweep_kernel, dim3(1), dim3(SMALL_TB), 0, s, num_colors, direction, cstart, order, Ai, Aj, Aa, Aa32, f, d,
                       marker, marker_val, w, u);
+}
+
+// the same with the look-ahead kernels: rowinfo holds (row, first entry, last entry) for every position of the colour order
+// (nrows of them: the level's rows), the matrix nnz_matrix entries; the launch sweeps the n rows from position r_first on
+void launch_mc_small_sweep_ahead(int num_colors, int direction, const int *cstart, const void *rowinfo, int nrows, const int *Aj,
+                                 const double *Aa, const float *Aa32, int nnz_matrix, const double *f, const double *d, const int *marker,
+                                 int marker_val, double w, double *u, int n, int nnz, int r_first, hipStream_t s)
+{
+   if (num_colors <= 0 || nrows <= 0 || nnz_matrix <= 0 || n <= 0) { return; }
+   account_bytes((double) nnz * (Aa32 ? 8.0 : 12.0) + (double) n * 44.0);
+   // a level of at most 12 288 rows whose swept rows' records fit beside its iterate: the sweep out of LDS
+   const int r_begin = r_first;
+   const size_t lds = sizeof(double) * ((size_t) nrows + 2 * (size_t) n + 2) + 16 * (size_t) n + sizeof(int) * ((size_t) num_colors + 2);
+   if (nrows <= 12288 && lds <= (size_t) 150 * 1024)
+   {
+      static bool raised = false;
+      if (!raised)
+      {
+         (void) hipFuncSetAttribute((const void *) (mc_small_sweep_lds_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+         (void) hipGetLastError();
+         raised = true;
+      }
+      hipLaunchKernelGGL((mc_small_sweep_lds_kernel<32, 4>), dim3(1), dim3(SMALL_TB), lds, s, num_colors, direction, cstart, (const int4 *) rowinfo, nrows,
+                         r_begin, n, Aj, Aa, Aa32, nnz_matrix, f, d, marker, marker_val, w, u);
+      return;
+   }
+   if (nrows <= 8192)
+   {
+      hipLaunchKernelGGL((mc_small_sweep_ahead_kernel<32, 4, true>), dim3(1), dim3(SMALL_TB), sizeof(double) * (size_t) nrows, s, num_colors, direction, cstart,
+                         (const int4 *) rowinfo, nrows, Aj, Aa, Aa32, nnz_matrix, f, d, marker, marker_val, w, u);
+   }
+   else
+   {
+      hipLaunchKernelGGL((mc_small_sweep_ahead_kernel<32, 4, false>), dim3(1), dim3(SMALL_TB), 0, s, num_colors, direction, cstart,
+                         (const int4 *) rowinfo, nrows, Aj, Aa, Aa32, nnz_matrix, f, d, marker, marker_val, w, u);
+   }
 }
 
 void preload_mc_kernels() { hipFuncAttributes at; (void) hipFuncGetAttributes(&at, (const void *) mc_round_kernel<64>); (void) hipGetLastError(); }

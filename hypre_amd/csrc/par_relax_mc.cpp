@@ -45,6 +45,7 @@ struct McPlan
    std::vector<int>               cstart;      // [num_colors + 1] where every colour starts in d_order
    int    *d_cstart = nullptr;                 // the same on the device
    int    *d_order = nullptr;                  // [n] the rows colour by colour, ascending inside a colour
+   void   *d_rowinfo = nullptr;                // [n] (row, first entry, last entry, 0) for every position of d_order (look-ahead sweep)
    int    *d_ptr = nullptr, *d_cj = nullptr;   // large levels: the colour-sorted copy of the matrix the views point into
    double *d_ca = nullptr;
    int    *d_color = nullptr;                  // [n] colour of every row (device; for the tests / oracle)
@@ -52,6 +53,14 @@ struct McPlan
    MatrixWatch watch;                          // the classes hold COPIES of the matrix: every sweep checks it is still the same
    const int *rowmap(int c) const { return d_order + cstart[(size_t) c]; }
 };
+
+// the one-workgroup sweeps fetch what does not depend on the iterate one pass ahead (mc_small_sweep_ahead_kernel; default on;
+// HYPRE_AMD_MC_LOOK_AHEAD=0 / hypre_amd_SetMcLookAhead: the plain kernel, for comparisons)
+int &mc_look_ahead()
+{
+   static int on = [] { const char *e = getenv("HYPRE_AMD_MC_LOOK_AHEAD"); return e ? atoi(e) : 1; }();
+   return on;
+}
 
 std::unordered_map<const hypre_CSRMatrix *, McPlan *> &mc_table()
 {
@@ -65,6 +74,7 @@ void free_mc(McPlan *m)
    for (hypre_CSRMatrix *c : m->rows_of) { if (c) { hypre_CSRMatrixDestroy(c); } }        // views: drops their plans only
    if (m->d_cstart) { HIP_CHECK(hipFree(m->d_cstart)); }
    if (m->d_order) { HIP_CHECK(hipFree(m->d_order)); }
+   if (m->d_rowinfo) { HIP_CHECK(hipFree(m->d_rowinfo)); }
    if (m->d_ptr) { HIP_CHECK(hipFree(m->d_ptr)); }
    if (m->d_cj) { HIP_CHECK(hipFree(m->d_cj)); }
    if (m->d_ca) { HIP_CHECK(hipFree(m->d_ca)); }
@@ -125,6 +135,8 @@ McPlan *get_mc(hypre_CSRMatrix *A)
    HIP_CHECK(hipMalloc((void **) &m->d_cstart, sizeof(int) * ((size_t) C + 1)));
    HIP_CHECK(hipMemcpyAsync(m->d_cstart, m->cstart.data(), sizeof(int) * ((size_t) C + 1), hipMemcpyHostToDevice, s));
    HIP_CHECK(hipStreamSynchronize(s));
+   if (n > 0 && hipMalloc(&m->d_rowinfo, sizeof(int) * 4 * (size_t) n) == hipSuccess) { launch_mc_rowinfo(n, m->d_order, A->i, m->d_rowinfo, s); }
+   else { (void) hipGetLastError(); m->d_rowinfo = nullptr; }
    m->small = A->num_nonzeros <= MC_SMALL_NNZ;
    if (!m->small)
    {
@@ -154,8 +166,11 @@ McPlan *get_mc(hypre_CSRMatrix *A)
    }
    if (timing)
    {
-      fprintf(stderr, "   multicolour plan: %d rows, %d colours, colouring %.3fs (%d rounds), classes%s %.3fs\n", n, C, t1 - t0, rounds,
+      fprintf(stderr, "   multicolour plan: %d rows, %d colours, colouring %.3fs (%d rounds), classes%s %.3fs", n, C, t1 - t0, rounds,
               m->small ? "" : " + matrices + plans", omp_get_wtime() - t1);
+      if (m->small) { fprintf(stderr, "; one workgroup sweeps all colours\n"); }
+      else if (m->tail_from >= 0) { fprintf(stderr, "; colours %d .. %d (%d rows) swept by one workgroup\n", m->tail_from, C - 1, m->cstart[(size_t) C] - m->cstart[(size_t) m->tail_from]); }
+      else { fprintf(stderr, "\n"); }
    }
    if (n > 0) { watch_record(m->watch, A, true, s); }
    t[A] = m;
@@ -209,6 +224,14 @@ HYPRE_Int hypre_amd_ParCSRMatrixMultiColoring(hypre_ParCSRMatrix *A, HYPRE_Int *
 // (u_g^old: ghost values of the iterate the call started from, as in the hybrid sweeps of par_relax.c:735-754).
 // cf_marker / relax_points restrict the rows as in hypre_BoomerAMGRelax.  diag: smoother diagonal (the cycle hands
 // the l1_norms option-5 vector = a_ii with 0 -> 1), or NULL for the stored diagonal entries.
+// The one-workgroup multicolour sweeps with (1, default) or without (0) the look-ahead; < 0: unchanged.  Returns the setting.
+// Same results either way (a switch for comparisons and for the recorded coarse tail's signature).
+HYPRE_Int hypre_amd_SetMcLookAhead(HYPRE_Int on)
+{
+   if (on >= 0) { mc_look_ahead() = on != 0; }
+   return mc_look_ahead();
+}
+
 HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A, hypre_ParVector *f, HYPRE_Int *cf_marker,
                                                           HYPRE_Int relax_points, HYPRE_Real relax_weight, HYPRE_Real *diag,
                                                           hypre_ParVector *u, hypre_ParVector *Vtemp, HYPRE_Int direction)
@@ -255,8 +278,16 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
    if (m->small)
    {
       const bool masked = relax_points != 0 && cf_marker;
+      if (m->d_rowinfo && mc_look_ahead())
+      {
+         launch_mc_small_sweep_ahead(C, direction, m->d_cstart, m->d_rowinfo, n, dg->j, dg->data, handle().fp32_values ? fp32_values_of(dg) : nullptr,
+                                     dg->num_nonzeros, ft, d, masked ? cf_marker : nullptr, relax_points, relax_weight, ud, n, dg->num_nonzeros, 0, s);
+      }
+      else
+      {
       launch_mc_small_sweep(C, direction, m->d_cstart, m->d_order, dg->i, dg->j, dg->data, handle().fp32_values ? fp32_values_of(dg) : nullptr,
                             ft, d, masked ? cf_marker : nullptr, relax_points, relax_weight, ud, n, dg->num_nonzeros, s);
+      }
    }
    else
    {
@@ -266,10 +297,18 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
    {
       if (big >= C) { return; }
       const bool masked = relax_points != 0 && cf_marker;
+      const int trows = m->cstart[(size_t) C] - m->cstart[(size_t) big];
+      const int tnnz = (int) ((long long) trows * dg->num_nonzeros / std::max(n, 1));
+      if (m->d_rowinfo && mc_look_ahead())
+      {
+         launch_mc_small_sweep_ahead(C - big, direction, m->d_cstart + big, m->d_rowinfo, n, dg->j, dg->data,
+                                     handle().fp32_values ? fp32_values_of(dg) : nullptr, dg->num_nonzeros, ft, d, masked ? cf_marker : nullptr,
+                                     relax_points, relax_weight, ud, trows, tnnz, m->cstart[(size_t) big], s);
+         return;
+      }
       launch_mc_small_sweep(C - big, direction, m->d_cstart + big, m->d_order, dg->i, dg->j, dg->data,
                             handle().fp32_values ? fp32_values_of(dg) : nullptr, ft, d, masked ? cf_marker : nullptr, relax_points,
-                            relax_weight, ud, m->cstart[(size_t) C] - m->cstart[(size_t) big],
-                            (int) ((long long) (m->cstart[(size_t) C] - m->cstart[(size_t) big]) * dg->num_nonzeros / std::max(n, 1)), s);
+                            relax_weight, ud, trows, tnnz, s);
    };
    if (direction <= 0) { sweep_tail(); }
    for (int q = 0; q < big; q++)

@@ -649,7 +649,8 @@ unsigned long long tail_signature(hypre_ParAMGData *d, AmgPrivate *pv, int gl, h
    }
    mix(plan_generation());            // a plan dropped or rebuilt anywhere (the recorded kernels point into plans' tables)
    mix((unsigned long long) cycle_fusion());     // (the recorded tail leaves out what a fused restriction into it did)
-   mix((unsigned long long) (small_tail_on() ? pv->small_tail_nnz : 0)); mix((unsigned long long) (small_tail_forced_form() + 1));     // (one kernel instead of a dozen launches in the recorded tail)
+   mix((unsigned long long) (small_tail_on() ? pv->small_tail_nnz : 0)); mix((unsigned long long) (small_tail_forced_form() + 1));
+   mix((unsigned long long) hypre_amd_SetMcLookAhead(-1));     // (one kernel instead of a dozen launches in the recorded tail)
    SpmvArgs a{};
    spmv_default_flags(a);
    mix((unsigned long long) a.variant); mix((unsigned long long) a.gather_t); mix((unsigned long long) a.xcd_map);

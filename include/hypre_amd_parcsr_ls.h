@@ -413,6 +413,10 @@ HYPRE_Int hypre_BoomerAMGRelaxMultiColorGaussSeidelDevice(hypre_ParCSRMatrix *A,
 /* number of colours of A's diagonal block (greedy first-fit over the symmetrised pattern, built on demand);
  * colors_out: host array of one colour per local row, or NULL */
 HYPRE_Int hypre_amd_ParCSRMatrixMultiColoring(hypre_ParCSRMatrix *A, HYPRE_Int *colors_out);
+/* The one-workgroup multicolour sweeps (small levels, the tails of small colours of larger ones) request what does not depend
+ * on the iterate — a row's place, right-hand side, diagonal, own value and first entries — one pass ahead (default 1), or
+ * walk the plain chain of dependent loads (0); < 0 leaves the setting; returns it.  Same results. */
+HYPRE_Int hypre_amd_SetMcLookAhead(HYPRE_Int on);
 HYPRE_Int hypre_GaussElimSetup(hypre_ParAMGData *amg_data, HYPRE_Int level, HYPRE_Int relax_type);
 HYPRE_Int hypre_GaussElimSolve(hypre_ParAMGData *amg_data, HYPRE_Int level, HYPRE_Int relax_type);
 HYPRE_Int hypre_BoomerAMGCycle(void *amg_vdata, hypre_ParVector **F_array, hypre_ParVector **U_array);

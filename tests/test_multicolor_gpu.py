@@ -83,6 +83,43 @@ def test_single_sweep(gpu_lib, oracle, relax_type, relax_points, w, zero, level,
     lib.HYPRE_BoomerAMGDestroy(s)
 
 
+@pytest.mark.parametrize("problem,n,level", [("laplacian", (14, 13, 12), 1), ("27pt", (14, 13, 12), 1), ("laplacian", (40, 40, 36), 2),
+                                             ("laplacian", (40, 40, 36), 3), ("27pt", (30, 28, 26), 1)])
+@pytest.mark.parametrize("relax_type,relax_points", [(21, 0), (22, 0), (21, 1), (22, -1)])
+def test_look_ahead_sweeps_are_the_plain_sweeps(gpu_lib, oracle, problem, n, level, relax_type, relax_points):
+    """hypre_amd_SetMcLookAhead: the one-workgroup sweeps (whole small levels; the tails of small colours of larger levels)
+    with everything that does not depend on the iterate requested a pass ahead (and 32 lanes a row instead of 8) are the plain
+    sweeps up to the order of a row's sum: forward and backward, all points and C / F points only, rows longer than what the
+    lanes fetch ahead."""
+    from hypre_amd import binding as B
+    lib = gpu_lib
+    opt, A0, s = _setup(lib, n=n, problem=problem, relax_type=relax_type, coarsen_type=8, relax_order=1 if relax_points else 0)
+    nl = lib.hypre_amd_BoomerAMGGetNumLevels(s)
+    if level >= nl - 1:
+        level = nl - 2
+    A, cf, l1 = _level(lib, s, level)
+    nrow = A.contents.diag.contents.num_rows
+    f = rand_vector(nrow, 3)
+    u0 = rand_vector(nrow, 4)
+    out = {}
+    try:
+        for on in (1, 0):
+            assert lib.hypre_amd_SetMcLookAhead(on) == on
+            du, df, dv = B.parvec_from_numpy(u0), B.parvec_from_numpy(f), B.parvec_from_numpy(np.zeros(nrow))
+            for _ in range(2):
+                err = lib.hypre_BoomerAMGRelax(A, df, cf, relax_type, relax_points, 0.9, 1.0, l1, du, dv, dv)
+                assert err == 0
+            B.check()
+            out[on] = B.parvec_to_numpy(du)
+            for v in (du, df, dv):
+                lib.hypre_ParVectorDestroy(v)
+    finally:
+        lib.hypre_amd_SetMcLookAhead(1)
+    # (the same products; a row's sum is added by 32 lanes instead of 8: rounding)
+    assert np.max(np.abs(out[1] - out[0])) <= 1e-13 * np.max(np.abs(out[0]))
+    lib.HYPRE_BoomerAMGDestroy(s)
+
+
 def test_sweep_equals_the_level_scheduled_gauss_seidel_on_the_permuted_matrix(gpu_lib):
     """The parity statement end to end on the device: multicolour sweep of A == the library's own (bit-exact, golden-
     pinned) hybrid Gauss-Seidel sweep, relax 3, of P A P^T."""
