@@ -582,6 +582,7 @@ def main():
                        "exchanges_by_level": exchange_plan, "overlap": overlap,
                        "rccl_self_test": (None if world == 1 else ("passed" if transport == "rccl" else "not run (transport %s)" % transport)),
                        "coarse_tail_graph_from_level": g_level.value, "coarse_tail_graph_nodes": g_nodes.value,
+                       "one_workgroup_tail_from_level": int(L.hypre_amd_BoomerAMGGetSmallTailLevel(s)),
                        "levels": int(L.hypre_amd_BoomerAMGGetNumLevels(s)), "grid_complexity": g.value,
                        "operator_complexity": o.value, "setup_seconds": setup_s, "setup_path": setup_path,
                        "matrix_generation_seconds": matrix_s},
