@@ -517,8 +517,8 @@ int &small_tail_on()
 // The image of levels st .. L-1 the one-workgroup tail copies into LDS (tail_kernels.hip): every array the walk reads, at the
 // offset the kernel addresses it, and behind it the room of the work vectors.  Built when the hierarchy (its arrays'
 // addresses) is new; false: the levels do not fit the LDS of one workgroup.
-// form: 0 every array in LDS; 1 the first level's operator in the lanes' registers (its rows times their lanes fill the
-// workgroup once, a lane's share is at most 16 entries); 2 the first level's operator streamed from where it lies
+// form: 0 every array in LDS; 1 the first level's operator in the lanes' registers (its rows times their lanes fit the
+// workgroup's 768 lanes, a lane's share is at most 32 entries); 2 the first level's operator streamed from where it lies
 bool build_small_tail_image(hypre_ParAMGData *d, AmgPrivate *pv, int st, hipStream_t s, int form = 0)
 {
    const bool first_operator_outside = form != 0;
@@ -551,13 +551,14 @@ bool build_small_tail_image(hypre_ParAMGData *d, AmgPrivate *pv, int st, hipStre
       int longest = 0;
       for (HYPRE_Int r = 0; r < Ad->num_rows; r++) { longest = std::max(longest, (int) (ri[(size_t) r + 1] - ri[(size_t) r])); }
       // (the lanes per row the other forms take, where a lane's share then fits its registers: the same order of the sums)
+      // (the register form runs 768 lanes, a lane holding at most 32 entries: tail_kernels.hip)
       int wmax = 1, wlen = 1;
-      while (2 * wmax <= 64 && 2LL * wmax * std::max((int) Ad->num_rows, 1) <= 1024) { wmax *= 2; }
+      while (2 * wmax <= 64 && 2LL * wmax * std::max((int) Ad->num_rows, 1) <= 768) { wmax *= 2; }
       const int avg = Ad->num_rows > 0 ? (int) ((Ad->num_nonzeros + Ad->num_rows - 1) / Ad->num_rows) : 1;
       while (wlen < avg && wlen < 64) { wlen *= 2; }
       int W = std::min(wmax, wlen);
-      while (16 * W < longest && W < 64) { W *= 2; }
-      if (16 * W < longest || (long long) W * Ad->num_rows > 1024 || Ad->num_nonzeros < 1) { return false; }
+      while (32 * W < longest && W < 64) { W *= 2; }
+      if (32 * W < longest || (long long) W * Ad->num_rows > 768 || Ad->num_nonzeros < 1) { return false; }
       reg_lanes = W;
    }
    SmallTailArgs &ta = pv->tail_args;

@@ -22,7 +22,8 @@ namespace hamd {
 
 namespace {
 
-constexpr int TAIL_THREADS = 1024;
+constexpr int TAIL_THREADS = 1024;         // lanes of the workgroup; the register form runs 768 (twelve waves: 170 registers a lane)
+constexpr int TAIL_THREADS_REG = 768;
 #ifndef TAIL_TIMING
 #define TAIL_TIMING 0          // experiment: ticks of the 100 MHz wall clock at the steps of the walk (hypre_amd_TailTiming)
 #endif
@@ -123,7 +124,7 @@ __device__ __forceinline__ void tail_pass(const int *__restrict__ Mi, const int 
                                           const double *x, const double *f, const double *d, double w, double *y, double *u, int r32,
                                           int flag = 0)
 {
-   const int tid = threadIdx.x, sub = tid & (W - 1), G = TAIL_THREADS / W;
+   const int tid = threadIdx.x, sub = tid & (W - 1), G = (int) blockDim.x / W;
    for (int base = 0; base < n; base += G)
    {
       const int row = base + tid / W;
@@ -135,10 +136,11 @@ __device__ __forceinline__ void tail_pass(const int *__restrict__ Mi, const int 
 }
 
 // The first level's operator out of REGISTERS: when its rows times their lanes fill the workgroup once (n W <= 1024) and a
-// lane's share of a row is at most TAIL_REG entries, the lane fetches that share once — at the start, beside the image —
+// lane's share of a row is at most TAIL_REG entries (the workgroup then runs twelve waves instead of sixteen, so that a lane
+// may keep 3 x 32 registers of entries), the lane fetches that share once — at the start, beside the image —
 // and every pass over the operator (residual, sweeps) multiplies from registers: the largest operator of the tail costs no
 // LDS and no second trip.
-constexpr int TAIL_REG = 16;
+constexpr int TAIL_REG = 32;
 template <int OPK, int NR>
 __device__ __forceinline__ void tail_pass_reg(const double (&av)[NR], const int (&ac)[NR], int s, int e, int n, int W,
                                               const double *x, const double *f, const double *d, double w, double *y, double *u, int flag = 0)
@@ -165,9 +167,10 @@ __device__ __forceinline__ void tail_pass_reg(const double (&av)[NR], const int 
 // L2 or HBM per dependent load (a first version that walked the arrays in global memory took as long as the launches it
 // replaced: three dependent loads a pass, a dozen passes).
 template <bool REG>
-__global__ __launch_bounds__(TAIL_THREADS)
+__global__ __launch_bounds__(REG ? TAIL_THREADS_REG : TAIL_THREADS)
 void small_tail_kernel(SmallTailArgs t)
 {
+   constexpr int NT = REG ? TAIL_THREADS_REG : TAIL_THREADS;
    extern __shared__ __align__(16) unsigned char smem[];
    const int tid = threadIdx.x, nl = t.nl, r32 = t.round32;
    TAIL_STAMP(0);
@@ -183,13 +186,13 @@ void small_tail_kernel(SmallTailArgs t)
       const uint4 *src = reinterpret_cast<const uint4 *>(t.image);
       uint4 *dst = reinterpret_cast<uint4 *>(smem);
       const int quads = t.image_bytes >> 4;
-      for (int base = 0; base < quads; base += 8 * TAIL_THREADS)
+      for (int base = 0; base < quads; base += 8 * NT)
       {
          uint4 v[8];
 #pragma unroll
-         for (int i = 0; i < 8; i++) { v[i] = src[min(base + i * TAIL_THREADS + tid, quads - 1)]; }
+         for (int i = 0; i < 8; i++) { v[i] = src[min(base + i * NT + tid, quads - 1)]; }
 #pragma unroll
-         for (int i = 0; i < 8; i++) { if (base + i * TAIL_THREADS + tid < quads) { dst[base + i * TAIL_THREADS + tid] = v[i]; } }
+         for (int i = 0; i < 8; i++) { if (base + i * NT + tid < quads) { dst[base + i * NT + tid] = v[i]; } }
       }
    }
    if (!REG && t.lv[0].gAj)
@@ -197,10 +200,10 @@ void small_tail_kernel(SmallTailArgs t)
       // a streamed operator: one load per 128-byte line of its columns and values now, with the image's loads, so that the
       // two passes over it find the lines (and their page) in the L2 instead of paying for them on the critical path
       const int last = t.nnz0 - 1;
-      for (int q = 16 * tid; q <= last; q += 16 * TAIL_THREADS)
+      for (int q = 16 * tid; q <= last; q += 16 * NT)
       {
          const double v0 = t.lv[0].gAa[q];
-         const int c0 = t.lv[0].gAj[min(2 * q, last)], c1 = t.lv[0].gAj[min(2 * q + 32 * TAIL_THREADS, last)];
+         const int c0 = t.lv[0].gAj[min(2 * q, last)], c1 = t.lv[0].gAj[min(2 * q + 32 * NT, last)];
          asm volatile("" :: "v"(v0), "v"(c0), "v"(c1));
       }
    }
@@ -223,7 +226,7 @@ void small_tail_kernel(SmallTailArgs t)
       // the first level's right-hand side and, when the restriction into it wrote it, its sweep from zero
       const SmallTailLevel &L0 = t.lv[0];
       double *f0 = wp(L0.f), *u0 = wp(L0.u);
-      for (int i = tid; i < L0.n; i += TAIL_THREADS) { f0[i] = t.f_in[i]; if (t.first_presmoothed) { u0[i] = t.u_io[i]; } }
+      for (int i = tid; i < L0.n; i += NT) { f0[i] = t.f_in[i]; if (t.first_presmoothed) { u0[i] = t.u_io[i]; } }
    }
    __syncthreads();
    TAIL_STAMP(1);
@@ -233,7 +236,7 @@ void small_tail_kernel(SmallTailArgs t)
       const SmallTailLevel &L0 = t.lv[0];
       const double *f0 = dp(L0.f), *d0 = dp(L0.d);
       double *u0 = wp(L0.u);
-      for (int i = tid; i < L0.n; i += TAIL_THREADS) { u0[i] = (L0.w * f0[i]) / d0[i]; }
+      for (int i = tid; i < L0.n; i += NT) { u0[i] = (L0.w * f0[i]) / d0[i]; }
       __syncthreads();
    }
    // a pass over the operator of level l in whatever form the kernel holds it
@@ -252,7 +255,7 @@ void small_tail_kernel(SmallTailArgs t)
       if (from_zero)
       {
          const double *f = dp(F.f), *d = dp(F.d);
-         for (int i = tid; i < F.n; i += TAIL_THREADS) { z0[i] = __dmul_rn(__dmul_rn(F.w, f[i]), 1.0 / d[i]); }      // scaled_recip_kernel
+         for (int i = tid; i < F.n; i += NT) { z0[i] = __dmul_rn(__dmul_rn(F.w, f[i]), 1.0 / d[i]); }      // scaled_recip_kernel
       }
       else { A_PASS(T_RESID_RD, l, F, dp(F.u), dp(F.f), dp(F.d), F.w, z0, nullptr, 0); }
       __syncthreads();
@@ -285,7 +288,7 @@ void small_tail_kernel(SmallTailArgs t)
       const int n = t.ncoarse;
       const double *lu = dp(t.lu_off);
       double *xc = wp(C.u);
-      for (int i = tid; i < n; i += TAIL_THREADS) { xc[i] = dp(C.f)[i]; }
+      for (int i = tid; i < n; i += NT) { xc[i] = dp(C.f)[i]; }
       __syncthreads();
       // lane j of the first wave holds x[j]: step k of the elimination updates every j > k at once (x[k] from lane k), the
       // back substitution every j < k — each x[j] sees the operations of the one-lane loop in its order (the same bits)
@@ -340,7 +343,7 @@ void small_tail_kernel(SmallTailArgs t)
          {
             double *u = wp(F.u);
             const double *a = dp(F.alt);
-            for (int i = tid; i < F.n; i += TAIL_THREADS) { u[i] = a[i]; }
+            for (int i = tid; i < F.n; i += NT) { u[i] = a[i]; }
             __syncthreads();
          }
       }
@@ -348,7 +351,7 @@ void small_tail_kernel(SmallTailArgs t)
    {
       const SmallTailLevel &L0 = t.lv[0];
       const double *a = t.kind_up == 1 ? dp(L0.u) : dp(L0.alt);
-      for (int i = tid; i < L0.n; i += TAIL_THREADS) { t.u_io[i] = a[i]; }
+      for (int i = tid; i < L0.n; i += NT) { t.u_io[i] = a[i]; }
    }
 #undef A_PASS
    TAIL_STAMP(40);
@@ -376,7 +379,7 @@ void launch_small_tail(const SmallTailArgs &t, hipStream_t s)
       (void) hipGetLastError();
       raised = true;
    }
-   if (t.reg_first) { hipLaunchKernelGGL(small_tail_kernel<true>, dim3(1), dim3(TAIL_THREADS), (size_t) t.lds_bytes, s, t); }
+   if (t.reg_first) { hipLaunchKernelGGL(small_tail_kernel<true>, dim3(1), dim3(TAIL_THREADS_REG), (size_t) t.lds_bytes, s, t); }
    else { hipLaunchKernelGGL(small_tail_kernel<false>, dim3(1), dim3(TAIL_THREADS), (size_t) t.lds_bytes, s, t); }
 }
 
