@@ -77,7 +77,11 @@ struct AmgPrivate
    // creates plans and scratch, which a capture cannot) and replayed as one graph.  A signature of everything the recorded
    // launches depend on (options, weights, operator and vector addresses) is checked at every cycle; a mismatch drops
    // the graph and records again.
-   int            graph_rows   = 100000;      // levels with at most this many rows belong to the tail (0: no graph)
+   // levels with at most this many rows belong to the tail (0: no graph — the default since the end of round 4: with the
+   // smallest levels in one kernel the recorded tail holds 13 - 25 launches, the host runs ahead of them anyway, and a graph
+   // costs ~8 us where it hands back to the eager stream: eager cycles measured 0.5 - 1.4 % faster on every configuration;
+   // HYPRE_AMD_CYCLE_GRAPH_ROWS / hypre_amd_BoomerAMGSetGraphThreshold switch it on)
+   int            graph_rows   = [] { const char *e = getenv("HYPRE_AMD_CYCLE_GRAPH_ROWS"); return e ? atoi(e) : 0; }();
    int            graph_level  = -1;          // first level of the tail (>= 1), fixed when the first cycle runs
    int            graph_state  = 0;           // 0: nothing yet, 1: warmed up (record next), 2: graph ready
    unsigned long long graph_sig = 0;

@@ -276,10 +276,13 @@ HYPRE_Int hypre_amd_SetSetupDeviceDist(HYPRE_Int on);
  * rank then repeats that step with the host routine — the agreed fall-back, which real problems reach only through rows of
  * more than a thousand entries. */
 HYPRE_Int hypre_amd_SetupDistTestDecline(HYPRE_Int what, HYPRE_Int rank, HYPRE_Int count);
-/* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows, default 100000; 0: off) is recorded once as a
- * HIP graph and replayed: its kernels are a few microseconds each behind launches that cost as much.  No reference
- * counterpart (the reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded
- * graph (-1: none) and its node count. */
+/* The coarse tail of a single-rank V-cycle (levels of at most `rows` rows; 0: off) can be recorded once as a HIP graph and
+ * replayed: its kernels are a few microseconds each behind launches that cost as much.  Off by default since the end of
+ * round 4 (environment HYPRE_AMD_CYCLE_GRAPH_ROWS=100000 or this call switch it on): with the smallest levels in one kernel
+ * (hypre_amd_SetSmallTail) the tail is 13 - 25 launches the host runs ahead of anyway, and eager cycles measured 0.5 - 1.4 %
+ * faster than replayed ones on every benchmark configuration.  No reference counterpart (the
+ * reference launches and synchronises per operation).  GetGraphInfo: first level of the recorded graph (-1: none) and its
+ * node count. */
 HYPRE_Int hypre_amd_BoomerAMGSetGraphThreshold(HYPRE_Solver solver, HYPRE_Int rows);
 HYPRE_Int hypre_amd_BoomerAMGGetGraphInfo(HYPRE_Solver solver, HYPRE_Int *level, HYPRE_Int *nodes);
 /* Mixed precision (BASELINE config C5): inside the cycle the SpMV-class kernels stream an fp32 copy of every level's matrix
