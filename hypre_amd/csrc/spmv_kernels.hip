@@ -1838,7 +1838,10 @@ void spmv_rs_kernel(SpmvArgs p, const int *__restrict__ rs_desc, const int *__re
    double sum = 0.0;
    // (two at a time where the registers are tight: the sweeps' three row operands on top of 32 entries a lane would cost the
    // fifth wave per SIMD)
-   constexpr int FG = (KP >= 32 && !F32 && OP != OP_AXPBY) ? 2 : 4;
+#ifndef RS_FG_SWEEPS
+#define RS_FG_SWEEPS 2            // (experiment switch: 4 = the sweeps' LDS reads four at a time too)
+#endif
+   constexpr int FG = (KP >= 32 && !F32 && OP != OP_AXPBY) ? RS_FG_SWEEPS : 4;
 #pragma unroll
    for (int g = 0; g < KP / FG; g++)
    {
